@@ -1,0 +1,175 @@
+"""ctypes bindings for the CPU oracle (oracle/dlm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (bayesian_dlms_amd) never
+imports this module.
+
+All matrices are column-major (Breeze DenseMatrix.data order); numpy arrays are
+passed as flat fp64 buffers.  Helper `cm(A)` flattens a 2-D numpy array
+column-major, `from_cm(buf, r, c)` goes back.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdlm_oracle.so")
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (no GPU needed)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "dlm_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "libdlm_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_normal.restype = ctypes.c_double
+        _lib.oracle_normal.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
+    return _lib
+
+
+def cm(a):
+    """Column-major flat fp64 copy of a 1-D/2-D array."""
+    a = np.asarray(a, dtype=np.float64)
+    return np.ascontiguousarray(a.T).reshape(-1) if a.ndim == 2 else np.ascontiguousarray(a).reshape(-1)
+
+
+def from_cm(buf, r, c):
+    return np.asarray(buf, dtype=np.float64).reshape(c, r).T.copy()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+class Model:
+    """Host-materialised model: F [nF][d*p], G [nG][d*d] (column-major each),
+    g_index [T] (or None), dt [T] (or None)."""
+
+    def __init__(self, d, p, T, F, G, g_index=None, dt=None, f_stride=0):
+        self.d, self.p, self.T = int(d), int(p), int(T)
+        self.F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1)
+        self.G = np.ascontiguousarray(G, dtype=np.float64).reshape(-1)
+        self.g_index = None if g_index is None else np.ascontiguousarray(g_index, dtype=np.int32)
+        self.dt = None if dt is None else np.ascontiguousarray(dt, dtype=np.float64)
+        self.f_stride = int(f_stride)
+
+
+def kf_filter(M, V, W, m0, C0, y):
+    """KalmanFilter(...).filter: returns dict of m,C,a,R,f,Q with T+1 records
+    (matrices column-major flattened in the last axis)."""
+    d, p, T = M.d, M.p, M.T
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(T, p)
+    out = {
+        "m": np.empty((T + 1, d)), "C": np.empty((T + 1, d * d)),
+        "a": np.empty((T + 1, d)), "R": np.empty((T + 1, d * d)),
+        "f": np.empty((T + 1, p)), "Q": np.empty((T + 1, p * p)),
+    }
+    V, W, m0, C0 = cm(V), cm(W), cm(m0), cm(C0)
+    rc = lib().oracle_kf_filter(
+        d, p, T, _p(M.F), ctypes.c_long(M.f_stride), _p(M.G), _pi(M.g_index), _p(M.dt),
+        _p(V), _p(W), _p(m0), _p(C0), _p(y),
+        _p(out["m"]), _p(out["C"]), _p(out["a"]), _p(out["R"]), _p(out["f"]), _p(out["Q"]))
+    out["rc"] = rc
+    return out
+
+
+def smoother(M, filt, compat_q1=False):
+    d, T = M.d, M.T
+    s = np.empty((T + 1, d)); S = np.empty((T + 1, d * d))
+    rc = lib().oracle_smoother(d, T, _p(M.G), _pi(M.g_index), _p(filt["m"]), _p(filt["C"]),
+                               _p(filt["a"]), _p(filt["R"]), int(bool(compat_q1)), _p(s), _p(S))
+    return {"s": s, "S": S, "rc": rc}
+
+
+def backward_sample(M, W, filt, z, factor="eig"):
+    d, T = M.d, M.T
+    z = np.ascontiguousarray(z, dtype=np.float64).reshape(T + 1, d)
+    theta = np.empty((T + 1, d)); h = np.empty((T + 1, d)); H = np.empty((T + 1, d * d))
+    W = cm(W)
+    rc = lib().oracle_backward_sample(d, T, _p(M.G), _pi(M.g_index), _p(M.dt), _p(W),
+                                      _p(filt["m"]), _p(filt["C"]), _p(filt["a"]), _p(filt["R"]),
+                                      _p(z), 0 if factor == "eig" else 1, _p(theta), _p(h), _p(H))
+    return {"theta": theta, "h": h, "H": H, "rc": rc}
+
+
+def gibbs_stats(M, y, theta, want_outer=False):
+    d, p, T = M.d, M.p, M.T
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(T, p)
+    theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(T + 1, d)
+    ssy = np.empty(p); n = np.empty(p); ss = np.empty(d)
+    outer = np.empty(d * d) if want_outer else None
+    lib().oracle_gibbs_stats(d, p, T, _p(M.F), ctypes.c_long(M.f_stride), _p(M.G), _pi(M.g_index),
+                             _p(M.dt), _p(y), _p(theta), _p(ssy), _p(n), _p(ss), _p(outer))
+    return {"ssy": ssy, "n": n, "ss": ss, "outer": outer}
+
+
+def sqrt_svd(Mx, inverse=False):
+    Mx = np.asarray(Mx, dtype=np.float64)
+    n = Mx.shape[0]
+    out = np.empty(n * n)
+    flat = cm(Mx)
+    lib().oracle_sqrt_svd(n, _p(flat), int(bool(inverse)), _p(out))
+    return from_cm(out, n, n)
+
+
+def svd_filter(M, V, W, m0, C0, y, raw_w_q2=False):
+    d, p, T = M.d, M.p, M.T
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(T, p)
+    out = {"m": np.empty((T + 1, d)), "dc": np.empty((T + 1, d)), "uc": np.empty((T + 1, d * d)),
+           "a": np.empty((T + 1, d)), "dr": np.empty((T + 1, d)), "ur": np.empty((T + 1, d * d))}
+    V, W, m0, C0 = cm(V), cm(W), cm(m0), cm(C0)
+    lib().oracle_svd_filter(d, p, T, _p(M.F), ctypes.c_long(M.f_stride), _p(M.G), _pi(M.g_index),
+                            _p(M.dt), _p(V), _p(W), _p(m0), _p(C0), _p(y), int(bool(raw_w_q2)),
+                            _p(out["m"]), _p(out["dc"]), _p(out["uc"]), _p(out["a"]),
+                            _p(out["dr"]), _p(out["ur"]))
+    return out
+
+
+def svd_backward_sample(M, W, sf, z, literal_q9=True):
+    d, T = M.d, M.T
+    z = np.ascontiguousarray(z, dtype=np.float64).reshape(T + 1, d)
+    theta = np.empty((T + 1, d)); h = np.empty((T + 1, d))
+    dh = np.empty((T + 1, d)); uh = np.empty((T + 1, d * d))
+    W = cm(W)
+    lib().oracle_svd_backward_sample(d, T, _p(M.G), _pi(M.g_index), _p(W), _p(sf["m"]), _p(sf["dc"]),
+                                     _p(sf["uc"]), _p(sf["a"]), _p(z), int(bool(literal_q9)), _p(theta), _p(h), _p(dh), _p(uh))
+    return {"theta": theta, "h": h, "dh": dh, "uh": uh}
+
+
+def normals(seed, series, T1, d):
+    z = np.empty((T1, d))
+    lib().oracle_normals(ctypes.c_uint64(seed), ctypes.c_uint64(series), T1, d, _p(z))
+    return z
+
+
+def filter_smooth_batch(N, M, V, W, m0, C0, y, want_out=True):
+    """Batched CPU baseline (OpenMP over series). y [N][T][p]."""
+    d, p, T = M.d, M.p, M.T
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(N, T, p)
+    rec = d + d * d
+    filt = np.empty((N, T + 1, rec)) if want_out else None
+    sm = np.empty((N, T + 1, rec)) if want_out else None
+    V, W, m0, C0 = cm(V), cm(W), cm(m0), cm(C0)
+    bad = lib().oracle_filter_smooth_batch(N, d, p, T, _p(M.F), _p(M.G), _p(V), _p(W), _p(m0), _p(C0),
+                                           _p(y), _p(filt), _p(sm))
+    return filt, sm, bad
