@@ -1,0 +1,394 @@
+// C-ABI implementation (include/dlm_engine.h): argument checking, host<->device staging,
+// kernel-variant dispatch, RCCL wrapper.  No torch types, no exceptions across the boundary.
+#include "../../include/dlm_engine.h"
+#include "dlm_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using dlm::KArgs;
+
+struct dlm_engine {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  const char* variant = "none";
+  void* arena = nullptr;      // device staging arena for DLM_MEM_HOST calls
+  size_t arena_bytes = 0;
+  ncclComm_t comm = nullptr;
+  bool has_comm = false;
+};
+
+namespace {
+
+int fail(dlm_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  return code;
+}
+
+#define HIP_TRY(e, expr)                                                                    \
+  do {                                                                                      \
+    hipError_t _err = (expr);                                                               \
+    if (_err != hipSuccess)                                                                 \
+      return fail((e), DLM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_err));   \
+  } while (0)
+
+// Collects the buffers of one call.  Device mode: pointers pass through.  Host mode: every
+// buffer gets a slot in the engine's arena; inputs are copied up before the launch, outputs
+// are copied back by finish().
+class Stager {
+ public:
+  Stager(dlm_engine* e, bool host) : e_(e), host_(host) {}
+
+  template <class T>
+  void in(const T** field, const T* p, size_t count) { add((void**)field, (void*)p, count * sizeof(T), true, false); }
+  template <class T>
+  void out(T** field, T* p, size_t count) { add((void**)field, (void*)p, count * sizeof(T), false, true); }
+  template <class T>
+  void zeroed_out(T** field, T* p, size_t count) { add((void**)field, (void*)p, count * sizeof(T), false, true, true); }
+
+  int commit() {
+    if (host_) {
+      size_t need = 0;
+      for (auto& b : bufs_) if (b.user) { b.offset = need; need += (b.bytes + 255) & ~(size_t)255; }
+      if (need > e_->arena_bytes) {
+        if (e_->arena) { HIP_TRY(e_, hipStreamSynchronize(e_->stream)); HIP_TRY(e_, hipFree(e_->arena)); e_->arena = nullptr; e_->arena_bytes = 0; }
+        HIP_TRY(e_, hipMalloc(&e_->arena, need));
+        e_->arena_bytes = need;
+      }
+    }
+    for (auto& b : bufs_) {
+      if (!b.user) { *b.field = nullptr; continue; }
+      void* dev = host_ ? (void*)((char*)e_->arena + b.offset) : b.user;
+      b.dev = dev;
+      *b.field = dev;
+      if (host_ && b.is_in) HIP_TRY(e_, hipMemcpyAsync(dev, b.user, b.bytes, hipMemcpyHostToDevice, e_->stream));
+      if (b.zero) HIP_TRY(e_, hipMemsetAsync(dev, 0, b.bytes, e_->stream));
+    }
+    return DLM_OK;
+  }
+
+  int finish(bool async) {
+    if (host_) {
+      for (auto& b : bufs_)
+        if (b.user && b.is_out) HIP_TRY(e_, hipMemcpyAsync(b.user, b.dev, b.bytes, hipMemcpyDeviceToHost, e_->stream));
+      HIP_TRY(e_, hipStreamSynchronize(e_->stream));
+    } else if (!async) {
+      HIP_TRY(e_, hipStreamSynchronize(e_->stream));
+    }
+    return DLM_OK;
+  }
+
+ private:
+  struct Buf { void** field; void* user; size_t bytes; bool is_in, is_out, zero; size_t offset; void* dev; };
+  void add(void** field, void* p, size_t bytes, bool is_in, bool is_out, bool zero = false) {
+    bufs_.push_back(Buf{field, p, bytes, is_in, is_out, zero, 0, nullptr});
+  }
+  dlm_engine* e_;
+  bool host_;
+  std::vector<Buf> bufs_;
+};
+
+int check_common(dlm_engine* e, const dlm_model_desc* m, const dlm_params_desc* p, const dlm_options* o) {
+  if (!e) return DLM_ERR_ARG;
+  if (!m || !p || !o) return fail(e, DLM_ERR_ARG, "null descriptor");
+  if (m->d < 1 || m->p < 1 || m->T < 1 || m->N < 1) return fail(e, DLM_ERR_ARG, "d, p, T, N must be >= 1 (the reference throws on empty input, KalmanFilter.scala:116-117)");
+  if (!m->F || !m->G || m->n_g < 1) return fail(e, DLM_ERR_ARG, "model tables F/G missing");
+  if (m->n_g > 1 && !m->g_index) return fail(e, DLM_ERR_ARG, "n_g > 1 needs g_index");
+  if (m->f_stride != 0 && m->f_stride != (int64_t)m->d * m->p) return fail(e, DLM_ERR_ARG, "f_stride must be 0 or d*p");
+  if (!p->V || !p->W || !p->m0 || !p->C0) return fail(e, DLM_ERR_ARG, "parameter arrays missing");
+  if (o->mem != DLM_MEM_DEVICE && o->mem != DLM_MEM_HOST) return fail(e, DLM_ERR_ARG, "opts->mem");
+  if (m->d > 64 || m->p > 64) return fail(e, DLM_ERR_UNSUPPORTED, "d and p are limited to 64 in this build");
+  HIP_TRY(e, hipSetDevice(e->device));
+  return DLM_OK;
+}
+
+// model + params -> staged KArgs fields
+void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params_desc* p, const dlm_options* o) {
+  const size_t d = m->d, pp = m->p, T = m->T, N = m->N;
+  k.d = m->d; k.p = m->p; k.T = m->T; k.N = m->N;
+  k.f_stride = m->f_stride; k.v_stride = p->v_stride; k.w_stride = p->w_stride;
+  k.m0_stride = p->m0_stride; k.c0_stride = p->c0_stride;
+  k.flags = o->flags; k.seed = o->seed; k.series_offset = o->series_offset;
+  st.in(&k.F, m->F, (m->f_stride ? T : 1) * d * pp);
+  st.in(&k.G, m->G, (size_t)m->n_g * d * d);
+  st.in(&k.g_index, (const int*)m->g_index, m->g_index ? T : 0);
+  st.in(&k.dt, m->dt, m->dt ? T : 0);
+  st.in(&k.V, p->V, p->v_stride ? (N - 1) * (size_t)p->v_stride + pp * pp : pp * pp);
+  st.in(&k.W, p->W, p->w_stride ? (N - 1) * (size_t)p->w_stride + d * d : d * d);
+  st.in(&k.m0, p->m0, p->m0_stride ? (N - 1) * (size_t)p->m0_stride + d : d);
+  st.in(&k.C0, p->C0, p->c0_stride ? (N - 1) * (size_t)p->c0_stride + d * d : d * d);
+}
+
+bool use_fast(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::mfma16_supported(k); }
+
+int run_filter(dlm_engine* e, const KArgs& k) {
+  if (use_fast(k) && !k.prior) {
+    e->variant = "mfma16";
+    HIP_TRY(e, dlm::launch_mfma16_filter(k, e->stream));
+  } else {
+    e->variant = "generic";
+    HIP_TRY(e, dlm::launch_generic_filter(k, e->stream));
+  }
+  return DLM_OK;
+}
+
+int run_smoother(dlm_engine* e, const KArgs& k) {
+  if (use_fast(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1)) {
+    e->variant = "mfma16";
+    HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->stream));
+  } else {
+    e->variant = "generic";
+    HIP_TRY(e, dlm::launch_generic_smoother(k, e->stream));
+  }
+  return DLM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dlm_version(void) { return "bayesian_dlms_amd 0.1.0 (gfx950)"; }
+
+int dlm_engine_create(int device, dlm_engine** out) {
+  if (!out) return DLM_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return DLM_ERR_HIP;
+  dlm_engine* e = new dlm_engine();
+  e->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete e;
+    return DLM_ERR_HIP;
+  }
+  e->stream = e->own_stream;
+  *out = e;
+  return DLM_OK;
+}
+
+void dlm_engine_destroy(dlm_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->has_comm) ncclCommDestroy(e->comm);
+  if (e->arena) (void)hipFree(e->arena);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+const char* dlm_last_error(const dlm_engine* e) { return e ? e->err.c_str() : "null engine"; }
+const char* dlm_last_variant(const dlm_engine* e) { return e ? e->variant : "none"; }
+
+int dlm_engine_set_stream(dlm_engine* e, void* hip_stream) {
+  if (!e) return DLM_ERR_ARG;
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return DLM_OK;
+}
+
+int dlm_engine_sync(dlm_engine* e) {
+  if (!e) return DLM_ERR_ARG;
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return DLM_OK;
+}
+
+int32_t dlm_stats_len(int32_t d, int32_t p, uint32_t flags) { return dlm::stats_len(d, p, flags); }
+
+int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                     const double* y, const dlm_options* opts, double* filt, double* prior,
+                     double* fq, int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  if (!y || !filt) return fail(e, DLM_ERR_ARG, "y and filt are required");
+  const size_t d = model->d, p = model->p, T = model->T, N = model->N, rec = d + d * d;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  st.in(&k.y, y, N * T * p);
+  st.out(&k.filt, filt, N * (T + 1) * rec);
+  st.out(&k.prior, prior, N * (T + 1) * rec);
+  st.out(&k.fq, fq, N * (T + 1) * (p + p * p));
+  st.zeroed_out(&k.status, (int*)status, N);
+  if ((rc = st.commit())) return rc;
+  if ((rc = run_filter(e, k))) return rc;
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
+int dlm_smooth_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                     const double* filt, const dlm_options* opts, double* smooth, int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  if (!filt || !smooth) return fail(e, DLM_ERR_ARG, "filt and smooth are required");
+  const size_t d = model->d, T = model->T, N = model->N, rec = d + d * d;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  st.in(&k.filt_in, filt, N * (T + 1) * rec);
+  st.out(&k.smooth, smooth, N * (T + 1) * rec);
+  st.zeroed_out(&k.status, (int*)status, N);
+  if ((rc = st.commit())) return rc;
+  if ((rc = run_smoother(e, k))) return rc;
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
+int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
+                            const dlm_params_desc* params, const double* y,
+                            const dlm_options* opts, double* filt, double* smooth,
+                            int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  if (!y || !filt || !smooth) return fail(e, DLM_ERR_ARG, "y, filt and smooth are required");
+  const size_t d = model->d, p = model->p, T = model->T, N = model->N, rec = d + d * d;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  st.in(&k.y, y, N * T * p);
+  st.out(&k.filt, filt, N * (T + 1) * rec);
+  st.out(&k.smooth, smooth, N * (T + 1) * rec);
+  st.zeroed_out(&k.status, (int*)status, N);
+  if ((rc = st.commit())) return rc;
+  if ((rc = run_filter(e, k))) return rc;
+  k.filt_in = k.filt;
+  if ((rc = run_smoother(e, k))) return rc;
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
+static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                          const double* y, const double* z, const dlm_options* opts,
+                          const double* filt_in, double* filt_ws, double* theta, double* cond,
+                          double* stats, int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  const bool forward = filt_ws != nullptr;
+  if (forward && !y) return fail(e, DLM_ERR_ARG, "y is required");
+  if (!forward && !filt_in) return fail(e, DLM_ERR_ARG, "filter records are required");
+  if (stats && !y) return fail(e, DLM_ERR_ARG, "sufficient statistics need y");
+  const size_t d = model->d, p = model->p, T = model->T, N = model->N, rec = d + d * d;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  st.in(&k.y, y, y ? N * T * p : 0);
+  st.in(&k.z, z, z ? N * (T + 1) * d : 0);
+  if (forward) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
+  else st.in(&k.filt_in, filt_in, N * (T + 1) * rec);
+  st.out(&k.theta, theta, N * (T + 1) * d);
+  st.out(&k.cond, cond, N * (T + 1) * rec);
+  st.out(&k.stats, stats, N * (size_t)dlm_stats_len(model->d, model->p, opts->flags));
+  st.zeroed_out(&k.status, (int*)status, N);
+  if ((rc = st.commit())) return rc;
+  if (forward) {
+    if ((rc = run_filter(e, k))) return rc;
+    k.filt_in = k.filt;
+  }
+  e->variant = "generic";
+  HIP_TRY(e, dlm::launch_generic_sampler(k, e->stream));
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
+int dlm_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                   const double* y, const double* z, const dlm_options* opts, double* filt_ws,
+                   double* theta, double* cond, double* stats, int32_t* status) {
+  if (e && !filt_ws) return fail(e, DLM_ERR_ARG, "filt_ws workspace is required");
+  return sampler_common(e, model, params, y, z, opts, nullptr, filt_ws, theta, cond, stats, status);
+}
+
+int dlm_backward_sample_batch(dlm_engine* e, const dlm_model_desc* model,
+                              const dlm_params_desc* params, const double* y, const double* filt,
+                              const double* z, const dlm_options* opts, double* theta,
+                              double* cond, double* stats, int32_t* status) {
+  return sampler_common(e, model, params, y, z, opts, filt, nullptr, theta, cond, stats, status);
+}
+
+int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
+                         const dlm_params_desc* params, const double* y,
+                         const dlm_options* opts, double* svd_rec, int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  if (!y || !svd_rec) return fail(e, DLM_ERR_ARG, "y and svd_rec are required");
+  const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  double* rec_dev = nullptr;
+  st.in(&k.y, y, N * T * p);
+  st.out(&rec_dev, svd_rec, N * (T + 1) * srec);
+  st.zeroed_out(&k.status, (int*)status, N);
+  if ((rc = st.commit())) return rc;
+  e->variant = "svd-jacobi";
+  HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
+int dlm_svd_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                       const double* y, const double* z, const dlm_options* opts,
+                       double* svd_ws, double* theta, double* stats, int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  if (!y || !svd_ws) return fail(e, DLM_ERR_ARG, "y and svd_ws are required");
+  const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  double* rec_dev = nullptr;
+  st.in(&k.y, y, N * T * p);
+  st.in(&k.z, z, z ? N * (T + 1) * d : 0);
+  st.out(&rec_dev, svd_ws, N * (T + 1) * srec);
+  st.out(&k.theta, theta, N * (T + 1) * d);
+  st.out(&k.stats, stats, N * (size_t)dlm_stats_len(model->d, model->p, opts->flags));
+  st.zeroed_out(&k.status, (int*)status, N);
+  if ((rc = st.commit())) return rc;
+  e->variant = "svd-jacobi";
+  HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
+  HIP_TRY(e, dlm::launch_svd_sampler(k, rec_dev, e->stream));
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
+int dlm_stats_pool(dlm_engine* e, const double* stats, int32_t N, int32_t L, double* pooled,
+                   const dlm_options* opts) {
+  if (!e) return DLM_ERR_ARG;
+  if (!stats || !pooled || !opts || N < 1 || L < 1) return fail(e, DLM_ERR_ARG, "dlm_stats_pool arguments");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const double* s_dev = nullptr; double* p_dev = nullptr;
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  st.in(&s_dev, stats, (size_t)N * L);
+  st.out(&p_dev, pooled, (size_t)L);
+  int rc = st.commit();
+  if (rc) return rc;
+  HIP_TRY(e, dlm::launch_stats_pool(s_dev, N, L, p_dev, e->stream));
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
+int dlm_comm_unique_id(uint8_t id[DLM_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= DLM_COMM_ID_BYTES, "id buffer too small");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return DLM_ERR_RCCL;
+  memset(id, 0, DLM_COMM_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return DLM_OK;
+}
+
+int dlm_comm_init_rank(dlm_engine* e, int32_t nranks, int32_t rank, const uint8_t id[DLM_COMM_ID_BYTES]) {
+  if (!e || !id || nranks < 1 || rank < 0 || rank >= nranks) return DLM_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclResult_t r = ncclCommInitRank(&e->comm, nranks, u, rank);
+  if (r != ncclSuccess) return fail(e, DLM_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  e->has_comm = true;
+  return DLM_OK;
+}
+
+int dlm_gibbs_suffstats_allreduce(dlm_engine* e, double* stats_dev, int64_t count) {
+  if (!e || !stats_dev || count < 1) return DLM_ERR_ARG;
+  if (!e->has_comm) return fail(e, DLM_ERR_RCCL, "no communicator: call dlm_comm_init_rank first");
+  HIP_TRY(e, hipSetDevice(e->device));
+  ncclResult_t r = ncclAllReduce(stats_dev, stats_dev, (size_t)count, ncclDouble, ncclSum, e->comm, e->stream);
+  if (r != ncclSuccess) return fail(e, DLM_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return DLM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Internal declarations shared by the engine's translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dlm {
+
+// Device-pointer view of one batched call.  All pointers are device pointers.
+struct KArgs {
+  int d, p, T, N;
+  const double* F; long long f_stride;
+  const double* G; const int* g_index; const double* dt;
+  const double* V; long long v_stride;
+  const double* W; long long w_stride;
+  const double* m0; long long m0_stride;
+  const double* C0; long long c0_stride;
+  const double* y;     // [N][T][p]
+  const double* z;     // [N][T+1][d] injected normals or nullptr
+  const double* filt_in;  // [N][T+1][d+dd] (smoother / sampler input)
+  double* filt;        // outputs (nullable where optional)
+  double* prior;
+  double* fq;
+  double* smooth;
+  double* theta;
+  double* cond;
+  double* stats;
+  int* status;
+  unsigned flags;
+  unsigned long long seed, series_offset;
+};
+
+__host__ __device__ inline int stats_len(int d, int p, unsigned flags) {
+  return 2 * p + ((flags & (1u << 4)) ? d * d : d) + 1;  // DLM_OPT_STATS_OUTER
+}
+
+// ---- generic wave-per-series kernels (any d <= 64, p <= 64), dlm_generic.hip ----------
+size_t generic_filter_lds_bytes(int d, int p);
+size_t generic_smoother_lds_bytes(int d, int p);
+size_t generic_sampler_lds_bytes(int d, int p);
+hipError_t launch_generic_filter(const KArgs& a, hipStream_t s);
+hipError_t launch_generic_smoother(const KArgs& a, hipStream_t s);
+hipError_t launch_generic_sampler(const KArgs& a, hipStream_t s);
+hipError_t launch_stats_pool(const double* stats, int N, int L, double* pooled, hipStream_t s);
+
+// ---- specialised d <= 16, p == 1 kernels on the fp64 MFMA layout, dlm_mfma16.hip ------
+bool mfma16_supported(const KArgs& a);
+hipError_t launch_mfma16_filter(const KArgs& a, hipStream_t s);
+hipError_t launch_mfma16_smoother(const KArgs& a, hipStream_t s);
+
+// ---- SVD filter / sampler (one-sided Jacobi in LDS), dlm_svd.hip ----------------------
+size_t svd_filter_lds_bytes(int d, int p);
+hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s);
+hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s);
+
+// ---- counter-based normals (same stream as oracle_normal in oracle/dlm_oracle.c) ------
+__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__device__ __forceinline__ double philox_normal(unsigned long long seed, unsigned long long series,
+                                                unsigned t, unsigned i) {
+  unsigned c[4] = {(unsigned)series, (unsigned)(series >> 32), t, i >> 1};
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  double u1 = ((double)c[0] * 4294967296.0 + (double)c[1] + 1.0) * (1.0 / 18446744073709551616.0);
+  double u2 = ((double)c[2] * 4294967296.0 + (double)c[3]) * (1.0 / 18446744073709551616.0);
+  double r = sqrt(-2.0 * log(u1));
+  double ang = 6.283185307179586476925286766559 * u2;
+  return (i & 1) ? r * sin(ang) : r * cos(ang);
+}
+
+}  // namespace dlm

@@ -1,0 +1,246 @@
+"""Python handle over the C ABI.  numpy arrays => DLM_MEM_HOST (the engine stages them),
+torch CUDA tensors => DLM_MEM_DEVICE (zero-copy; PyTorch is only the allocator here)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from .dlm import DlmParameters, MaterialisedModel
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _cm(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.ascontiguousarray(a.T).reshape(-1) if a.ndim == 2 else np.ascontiguousarray(a).reshape(-1)
+
+
+def pack_params(params: Union[DlmParameters, Sequence[DlmParameters]], N: int):
+    """DlmParameters (shared) or a sequence of N DlmParameters (per series) -> flat
+    column-major arrays and strides in doubles."""
+    if isinstance(params, DlmParameters):
+        return (_cm(params.v), 0, _cm(params.w), 0, _cm(params.m0), 0, _cm(params.c0), 0)
+    params = list(params)
+    if len(params) != N:
+        raise ValueError(f"need {N} DlmParameters, got {len(params)}")
+    V = np.stack([_cm(q.v) for q in params]); W = np.stack([_cm(q.w) for q in params])
+    m0 = np.stack([_cm(q.m0) for q in params]); C0 = np.stack([_cm(q.c0) for q in params])
+    return (V.reshape(-1), V.shape[1], W.reshape(-1), W.shape[1], m0.reshape(-1), m0.shape[1],
+            C0.reshape(-1), C0.shape[1])
+
+
+class _Host:
+    mem = _lib.DLM_MEM_HOST
+
+    @staticmethod
+    def put(a, dtype=np.float64):
+        return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+    @staticmethod
+    def empty(shape, dtype=np.float64):
+        return np.empty(shape, dtype=dtype)
+
+    @staticmethod
+    def ptr(a):
+        return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class _Device:
+    mem = _lib.DLM_MEM_DEVICE
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+
+    def put(self, a, dtype=np.float64):
+        if a is None:
+            return None
+        t = self.torch
+        if isinstance(a, t.Tensor):
+            want = t.float64 if dtype == np.float64 else t.int32
+            return a.to(device=self.device, dtype=want).contiguous()
+        return t.as_tensor(np.ascontiguousarray(a, dtype=dtype), device=self.device)
+
+    def empty(self, shape, dtype=np.float64):
+        t = self.torch
+        return t.empty(shape, dtype=t.float64 if dtype == np.float64 else t.int32, device=self.device)
+
+    @staticmethod
+    def ptr(a):
+        return None if a is None else ctypes.c_void_p(a.data_ptr())
+
+
+class Engine:
+    """One engine per GPU (not thread-safe), mirroring `dlm_engine`."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self.lib.dlm_engine_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise EngineError(f"dlm_engine_create(device={device}) failed with {rc}: no usable HIP device")
+        self.h = h
+        self.device = int(device)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dlm_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(f"engine call failed ({rc}): {self.lib.dlm_last_error(self.h).decode()}")
+
+    @property
+    def last_variant(self) -> str:
+        return self.lib.dlm_last_variant(self.h).decode()
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        self._check(self.lib.dlm_engine_set_stream(self.h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def sync(self):
+        self._check(self.lib.dlm_engine_sync(self.h))
+
+    def _backend(self, y):
+        if isinstance(y, np.ndarray) or y is None:
+            return _Host()
+        return _Device(self.device)
+
+    def prepare(self, mat: MaterialisedModel, params, N: int, be, flags=0, seed=0, series_offset=0):
+        """Build the descriptors; returns (model, params, opts, keepalive list)."""
+        V, vs, W, ws, m0, m0s, C0, c0s = pack_params(params, N) if not isinstance(params, tuple) else params
+        bufs = dict(F=be.put(mat.F), G=be.put(mat.G), gi=be.put(mat.g_index, np.int32), dt=be.put(mat.dt),
+                    V=be.put(V), W=be.put(W), m0=be.put(m0), C0=be.put(C0))
+        P = lambda a: (be.ptr(a).value if a is not None else None)
+        md = _lib.ModelDesc(mat.d, mat.p, mat.T, N, P(bufs["F"]), mat.f_stride, P(bufs["G"]), mat.n_g,
+                            P(bufs["gi"]), P(bufs["dt"]))
+        pd = _lib.ParamsDesc(P(bufs["V"]), vs, P(bufs["W"]), ws, P(bufs["m0"]), m0s, P(bufs["C0"]), c0s)
+        op = _lib.Options(flags, be.mem, seed, series_offset)
+        return md, pd, op, bufs
+
+    # -- entry points --------------------------------------------------------------
+    def filter(self, mat, params, y, *, want_prior=False, want_fq=False, flags=0):
+        be = self._backend(y)
+        N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
+        rec = d + d * d
+        yb = be.put(y).reshape(N, T, p)
+        md, pd, op, keep = self.prepare(mat, params, N, be, flags)
+        filt = be.empty((N, T + 1, rec))
+        prior = be.empty((N, T + 1, rec)) if want_prior else None
+        fq = be.empty((N, T + 1, p + p * p)) if want_fq else None
+        status = be.empty((N,), np.int32)
+        self._check(self.lib.dlm_filter_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(filt), be.ptr(prior),
+                                              be.ptr(fq), be.ptr(status)))
+        return {"filt": filt, "prior": prior, "fq": fq, "status": status}
+
+    def smooth(self, mat, params, filt, *, flags=0):
+        be = self._backend(filt)
+        N = int(filt.shape[0]); d, T = mat.d, mat.T
+        md, pd, op, keep = self.prepare(mat, params, N, be, flags)
+        fb = be.put(filt)
+        smooth = be.empty((N, T + 1, d + d * d))
+        status = be.empty((N,), np.int32)
+        self._check(self.lib.dlm_smooth_batch(self.h, md, pd, be.ptr(fb), op, be.ptr(smooth), be.ptr(status)))
+        return {"smooth": smooth, "status": status}
+
+    def filter_smooth(self, mat, params, y, *, flags=0, out=None):
+        be = self._backend(y)
+        N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
+        yb = be.put(y).reshape(N, T, p)
+        md, pd, op, keep = self.prepare(mat, params, N, be, flags)
+        filt = out["filt"] if out else be.empty((N, T + 1, d + d * d))
+        smooth = out["smooth"] if out else be.empty((N, T + 1, d + d * d))
+        status = out["status"] if out else be.empty((N,), np.int32)
+        self._check(self.lib.dlm_filter_smooth_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(filt),
+                                                     be.ptr(smooth), be.ptr(status)))
+        return {"filt": filt, "smooth": smooth, "status": status}
+
+    def ffbs(self, mat, params, y, *, z=None, seed=0, series_offset=0, flags=0, want_theta=True,
+             want_cond=False, want_stats=True, filt=None):
+        """FFBS (filt=None) or backward sampling from existing filter records (filt given)."""
+        be = self._backend(y)
+        N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
+        rec = d + d * d
+        yb = be.put(y).reshape(N, T, p)
+        zb = be.put(z)
+        md, pd, op, keep = self.prepare(mat, params, N, be, flags, seed, series_offset)
+        theta = be.empty((N, T + 1, d)) if want_theta else None
+        cond = be.empty((N, T + 1, rec)) if want_cond else None
+        L = self.lib.dlm_stats_len(d, p, flags)
+        stats = be.empty((N, L)) if want_stats else None
+        status = be.empty((N,), np.int32)
+        if filt is None:
+            ws = be.empty((N, T + 1, rec))
+            self._check(self.lib.dlm_ffbs_batch(self.h, md, pd, be.ptr(yb), be.ptr(zb), op, be.ptr(ws),
+                                                be.ptr(theta), be.ptr(cond), be.ptr(stats), be.ptr(status)))
+        else:
+            ws = be.put(filt)
+            self._check(self.lib.dlm_backward_sample_batch(self.h, md, pd, be.ptr(yb), be.ptr(ws), be.ptr(zb),
+                                                           op, be.ptr(theta), be.ptr(cond), be.ptr(stats),
+                                                           be.ptr(status)))
+        return {"theta": theta, "cond": cond, "stats": stats, "filt": ws, "status": status}
+
+    def svd_filter(self, mat, params, y, *, flags=0):
+        be = self._backend(y)
+        N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
+        yb = be.put(y).reshape(N, T, p)
+        md, pd, op, keep = self.prepare(mat, params, N, be, flags)
+        rec = be.empty((N, T + 1, 2 * d + d * d))
+        status = be.empty((N,), np.int32)
+        self._check(self.lib.dlm_svd_filter_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(rec), be.ptr(status)))
+        return {"svd": rec, "status": status}
+
+    def svd_ffbs(self, mat, params, y, *, z=None, seed=0, series_offset=0, flags=0, want_stats=True):
+        be = self._backend(y)
+        N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
+        yb = be.put(y).reshape(N, T, p)
+        zb = be.put(z)
+        md, pd, op, keep = self.prepare(mat, params, N, be, flags, seed, series_offset)
+        ws = be.empty((N, T + 1, 2 * d + d * d))
+        theta = be.empty((N, T + 1, d))
+        L = self.lib.dlm_stats_len(d, p, flags)
+        stats = be.empty((N, L)) if want_stats else None
+        status = be.empty((N,), np.int32)
+        self._check(self.lib.dlm_svd_ffbs_batch(self.h, md, pd, be.ptr(yb), be.ptr(zb), op, be.ptr(ws),
+                                                be.ptr(theta), be.ptr(stats), be.ptr(status)))
+        return {"svd": ws, "theta": theta, "stats": stats, "status": status}
+
+    def stats_pool(self, stats):
+        be = self._backend(stats)
+        N, L = int(stats.shape[0]), int(stats.shape[1])
+        sb = be.put(stats)
+        pooled = be.empty((L,))
+        op = _lib.Options(0, be.mem, 0, 0)
+        self._check(self.lib.dlm_stats_pool(self.h, be.ptr(sb), N, L, be.ptr(pooled), op))
+        return pooled
+
+    # -- RCCL ----------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = self.lib.dlm_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(f"dlm_comm_unique_id failed ({rc})")
+        return buf.raw
+
+    def comm_init_rank(self, nranks: int, rank: int, uid: bytes):
+        self._check(self.lib.dlm_comm_init_rank(self.h, nranks, rank, ctypes.create_string_buffer(uid, _lib.COMM_ID_BYTES)))
+
+    def allreduce_stats(self, stats_dev):
+        """In-place RCCL sum of a device fp64 tensor."""
+        self._check(self.lib.dlm_gibbs_suffstats_allreduce(self.h, ctypes.c_void_p(stats_dev.data_ptr()),
+                                                           stats_dev.numel()))
+        return stats_dev

@@ -1,0 +1,182 @@
+/*
+ * dlm_engine.h -- C ABI of the MI355X batched Kalman filter / smoother / FFBS engine.
+ *
+ * This is the drop-in boundary.  The reference (jonnylaw/bayesian_dlms, Scala) has no
+ * FFI/plugin interface: its seams are per-timestep closures (KalmanFilter.scala:32,
+ * SvdFilter.scala:22, Smoothing.scala:114-116), far too fine for a JNI crossing.  The
+ * boundary therefore sits one level up, at the whole-series calls, widened to a batch of
+ * N independent series that share one model (`Dlm`) and one time grid.  Each entry point
+ * names the reference call it replaces; the JNI / Scala binding is in INTEGRATION.md.
+ *
+ * Conventions (all citations relative to /root/reference/core/src/main/scala/dlm/model/):
+ *  - fp64 everywhere; matrices column-major (Breeze `DenseMatrix.data`).
+ *  - F is d x p and is used as F^T (KalmanFilter.scala:317).
+ *  - A missing observation component (`None`, Dlm.scala:94) is NaN in `y`.
+ *  - Outputs carry T+1 records; record 0 is the initial state at t0-1 (`.filter` keeps it,
+ *    Filter.scala:41-45; KalmanFilter.initialiseState, KalmanFilter.scala:112-118).
+ *  - A "state record" is d + d*d doubles: mean (d) then covariance (d x d, column-major).
+ *  - The caller owns every buffer.  `opts->mem` says whether ALL data pointers of the call
+ *    (descriptors' arrays, y, outputs, status) are device (HIP) pointers or host pointers;
+ *    in host mode the engine stages H2D/D2H through its own workspace.
+ *  - Return value: 0 = OK, negative = error (message via dlm_last_error).  Numerical trouble
+ *    is reported per series in `status[N]` bit flags; the batch still completes.
+ *  - An engine handle is not thread-safe; use one handle per thread / per GPU.
+ */
+#ifndef DLM_ENGINE_H
+#define DLM_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dlm_engine dlm_engine;
+
+enum {
+  DLM_OK = 0,
+  DLM_ERR_ARG = -1,         /* bad argument / shape                                   */
+  DLM_ERR_HIP = -2,         /* HIP runtime error                                      */
+  DLM_ERR_UNSUPPORTED = -3, /* shape outside what the kernels cover   */
+  DLM_ERR_RCCL = -4         /* RCCL error                                             */
+};
+
+enum { DLM_MEM_DEVICE = 0, DLM_MEM_HOST = 1 };
+
+/* dlm_options.flags */
+enum {
+  DLM_OPT_SMOOTHER_COMPAT_Q1 = 1u << 0, /* literal Smoothing.scala:44 (J X J, no transpose) */
+  DLM_OPT_SVD_RAW_W_Q2 = 1u << 1,       /* literal SvdFilter.filterDlm: raw W as sqrt(W)    */
+  DLM_OPT_SVD_SAMPLER_Q9 = 1u << 2,     /* literal SvdSampler.step: sqrt(W) for sqrt(W)^-1  */
+  DLM_OPT_FORCE_GENERIC = 1u << 3,      /* disable the specialised (MFMA) kernels           */
+  DLM_OPT_STATS_OUTER = 1u << 4,        /* Gibbs stats: full outer product (GibbsWishart)   */
+  DLM_OPT_ASYNC = 1u << 5               /* do not synchronise the stream before returning   */
+};
+
+/* per-series status bits */
+enum {
+  DLM_ST_NONFINITE = 1, /* a non-finite value appeared in the state                        */
+  DLM_ST_NOT_PD = 2,    /* a matrix that must be positive definite was not (Q, R or H)     */
+  DLM_ST_NOCONV = 4     /* Jacobi SVD did not converge                                     */
+};
+
+/* The model, materialised on the host from the reference's closures
+ * (`Dlm(f, g)`, Dlm.scala:14-15): F_t = f(time_t), G_k = g(dt_k) per distinct dt. */
+typedef struct {
+  int32_t d, p, T, N;
+  const double *F;        /* [nF][d*p]; nF = 1 if f_stride == 0 else T                     */
+  int64_t f_stride;       /* 0: time-invariant F; else F_t = F + t * f_stride (doubles)    */
+  const double *G;        /* [n_g][d*d]                                                   */
+  int32_t n_g;
+  const int32_t *g_index; /* [T] table index of step t; NULL: all 0                        */
+  const double *dt;       /* [T] time increments; NULL: all 1.0.  dt == 0 means "no        */
+                          /* advance" exactly as KalmanFilter.advState (:279-280)          */
+} dlm_model_desc;
+
+/* `DlmParameters(v, w, m0, c0)` (Dlm.scala:36-39); a stride of 0 shares the array between
+ * all series, otherwise series n reads base + n * stride (doubles). */
+typedef struct {
+  const double *V;  int64_t v_stride;   /* p x p */
+  const double *W;  int64_t w_stride;   /* d x d */
+  const double *m0; int64_t m0_stride;  /* d     */
+  const double *C0; int64_t c0_stride;  /* d x d */
+} dlm_params_desc;
+
+typedef struct {
+  uint32_t flags;     /* DLM_OPT_*                                                        */
+  int32_t mem;        /* DLM_MEM_DEVICE or DLM_MEM_HOST                                   */
+  uint64_t seed;      /* Philox key for FFBS draws                                        */
+  uint64_t series_offset; /* global index of series 0 of this call (multi-GPU shards       */
+                          /* draw the same normals as a single-GPU run)                   */
+} dlm_options;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+int dlm_engine_create(int device, dlm_engine **out);
+void dlm_engine_destroy(dlm_engine *e);
+const char *dlm_last_error(const dlm_engine *e);
+const char *dlm_version(void);
+/* Launch on a caller-owned hipStream_t (NULL = the engine's own stream). */
+int dlm_engine_set_stream(dlm_engine *e, void *hip_stream);
+int dlm_engine_sync(dlm_engine *e);
+/* Name of the kernel variant the last call dispatched to ("generic", "mfma16", ...). */
+const char *dlm_last_variant(const dlm_engine *e);
+
+/* ---- Kalman filter ----------------------------------------------------------------
+ * Replaces KalmanFilter(KalmanFilter.advanceState(p, mod.g)).filter(mod, ys, p)
+ * (KalmanFilter.scala:262-294, Filter.scala:41-45) for N series.
+ *   y      [N][T][p]
+ *   filt   [N][T+1][d+d*d]   (m_t, C_t)
+ *   prior  [N][T+1][d+d*d]   (a_t, R_t)            optional (NULL)
+ *   fq     [N][T+1][p+p*p]   (f_t, Q_t; record 0 NaN) optional (NULL)
+ *   status [N]                                      optional (NULL) */
+int dlm_filter_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
+                     const double *y, const dlm_options *opts, double *filt, double *prior,
+                     double *fq, int32_t *status);
+
+/* ---- RTS smoother -----------------------------------------------------------------
+ * Replaces Smoothing.backwardsSmoother(mod)(kfStates) (Smoothing.scala:31-64).
+ * Takes the filter records and recomputes a_{t+1}, R_{t+1} from (m_t, C_t) instead of
+ * reading them back.  smooth [N][T+1][d+d*d] = (s_t, S_t). */
+int dlm_smooth_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
+                     const double *filt, const dlm_options *opts, double *smooth, int32_t *status);
+
+/* ---- fused filter + smoother (the headline metric path) ---------------------------- */
+int dlm_filter_smooth_batch(dlm_engine *e, const dlm_model_desc *model,
+                            const dlm_params_desc *params, const double *y,
+                            const dlm_options *opts, double *filt, double *smooth,
+                            int32_t *status);
+
+/* ---- FFBS + Gibbs sufficient statistics --------------------------------------------
+ * Replaces Smoothing.ffbsDlm (Smoothing.scala:173-180) and, when `stats` is given, the
+ * sums inside GibbsSampling.sampleObservationMatrix / sampleSystemMatrix
+ * (Gibbs.scala:23-78) or GibbsWishart.sampleSystemMatrix (GibbsWishart.scala:16-35).
+ *   filt_ws [N][T+1][d+d*d]  workspace for the forward pass (required)
+ *   z       [N][T+1][d]      injected standard normals; NULL = Philox4x32-10 stream
+ *                            keyed by (opts->seed, opts->series_offset + n, t, i)
+ *   theta   [N][T+1][d]      the draw                     optional
+ *   cond    [N][T+1][d+d*d]  conditional (h_t, H_t)       optional
+ *   stats   [N][L]           L = dlm_stats_len(d, p, flags):
+ *                            [ssy(p) | n(p) | ss(d) | T]            (d-Inverse-Gamma)
+ *                            [ssy(p) | n(p) | outer(d*d) | T]       (DLM_OPT_STATS_OUTER)
+ * The draw uses the lower Cholesky factor of H_t (theta = h + L z); the reference's eigSym
+ * factor has LAPACK-defined signs and an unseedable RNG, so draw-level parity with Breeze is
+ * not defined -- see DESIGN.md. */
+int dlm_ffbs_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
+                   const double *y, const double *z, const dlm_options *opts, double *filt_ws,
+                   double *theta, double *cond, double *stats, int32_t *status);
+int32_t dlm_stats_len(int32_t d, int32_t p, uint32_t flags);
+
+/* Backward sampling only, from existing filter records (Smoothing.sampleDlm,
+ * Smoothing.scala:164-165). */
+int dlm_backward_sample_batch(dlm_engine *e, const dlm_model_desc *model,
+                              const dlm_params_desc *params, const double *y, const double *filt,
+                              const double *z, const dlm_options *opts, double *theta,
+                              double *cond, double *stats, int32_t *status);
+
+/* ---- SVD (square-root) filter / sampler -------------------------------------------
+ * Replaces SvdFilter.filterDlm (SvdFilter.scala:158-161) and SvdSampler.ffbsDlm
+ * (SvdSampler.scala:79-82).  svd_rec [N][T+1][d + d + d*d] = (m_t, dc_t, uc_t) with
+ * C_t = uc diag(dc^2) uc^T. */
+int dlm_svd_filter_batch(dlm_engine *e, const dlm_model_desc *model,
+                         const dlm_params_desc *params, const double *y,
+                         const dlm_options *opts, double *svd_rec, int32_t *status);
+int dlm_svd_ffbs_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
+                       const double *y, const double *z, const dlm_options *opts,
+                       double *svd_ws, double *theta, double *stats, int32_t *status);
+
+/* ---- pooled-parameter Gibbs: reduce over series, then over GPUs --------------------
+ * dlm_stats_pool sums stats [N][L] over the N series of this shard into pooled[L] (device).
+ * dlm_comm_* wrap RCCL (one rank per engine / GPU); dlm_gibbs_suffstats_allreduce is one
+ * ncclAllReduce(sum, fp64) of `count` doubles in place.  The only collective on the path. */
+int dlm_stats_pool(dlm_engine *e, const double *stats, int32_t N, int32_t L, double *pooled,
+                   const dlm_options *opts);
+#define DLM_COMM_ID_BYTES 128
+int dlm_comm_unique_id(uint8_t id[DLM_COMM_ID_BYTES]);
+int dlm_comm_init_rank(dlm_engine *e, int32_t nranks, int32_t rank,
+                       const uint8_t id[DLM_COMM_ID_BYTES]);
+int dlm_gibbs_suffstats_allreduce(dlm_engine *e, double *stats_dev, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLM_ENGINE_H */

@@ -1,0 +1,290 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle and the
+reference's golden vectors.  Tolerances are fp64 and stated per test."""
+import csv
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from bayesian_dlms_amd import _lib
+from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [0, _lib.OPT_FORCE_GENERIC]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bayesian_dlms_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def omodel(mat):
+    return oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+
+
+def split(rec, d):
+    """[.., d+d*d] records -> (mean [.., d], cov column-major flat [.., d*d])"""
+    return rec[..., :d], rec[..., d:]
+
+
+def seasonal_model(T):
+    mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    w = np.diag([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4])
+    return mod, mat, DlmParameters([[1.0]], w, np.zeros(13), np.eye(13))
+
+
+def simulate(mat, p, N, seed, missing=0.0):
+    rng = np.random.default_rng(seed)
+    d, q, T = mat.d, mat.p, mat.T
+    G = oracle.from_cm(mat.G[: d * d], d, d); F = oracle.from_cm(mat.F[: d * q], d, q)
+    Lw = np.linalg.cholesky(p.w + 1e-300 * np.eye(d)); Lv = np.linalg.cholesky(p.v)
+    y = np.empty((N, T, q))
+    for n in range(N):
+        x = p.m0 + np.linalg.cholesky(p.c0) @ rng.standard_normal(d)
+        for t in range(T):
+            x = G @ x + Lw @ rng.standard_normal(d)
+            y[n, t] = F.T @ x + Lv @ rng.standard_normal(q)
+    if missing > 0:
+        y[rng.random(y.shape) < missing] = np.nan
+    return y
+
+
+def oracle_filter_smooth(mat, p, y, compat=False):
+    om = omodel(mat)
+    f = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y)
+    s = oracle.smoother(om, f, compat_q1=compat)
+    return f, s
+
+
+# ------------------------------------------------------------------------------------------
+# golden vectors straight from the reference
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags", VARIANTS)
+def test_first_order_golden_csv(eng, golden_dir, flags):
+    rows = list(csv.reader(open(os.path.join(golden_dir, "first_order_dlm.csv"))))[1:]
+    times = np.array([float(r[0]) for r in rows]); y = np.array([float(r[1]) for r in rows]).reshape(1, -1, 1)
+    mat = materialise(Dlm.polynomial(1), times)
+    p = DlmParameters([[2.0]], [[3.0]], [0.0], [[10.0]])
+    out = eng.filter_smooth(mat, p, y, flags=flags)
+    fr = list(csv.reader(open(os.path.join(golden_dir, "first_order_dlm_filtered.csv"))))[1:]
+    sr = list(csv.reader(open(os.path.join(golden_dir, "first_order_dlm_smoothed.csv"))))[1:]
+    # tolerance: 1e-12 relative (the CSVs hold the reference's full-precision doubles)
+    np.testing.assert_allclose(out["filt"][0, :, 0], [float(r[1]) for r in fr], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["filt"][0, :, 1], [float(r[2]) for r in fr], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["smooth"][0, :, 0], [float(r[1]) for r in sr], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(out["smooth"][0, :, 1], [float(r[2]) for r in sr], rtol=1e-11, atol=1e-11)
+    assert int(out["status"][0]) == 0
+    fq = eng.filter(mat, p, y, want_fq=True, flags=flags)["fq"]
+    np.testing.assert_allclose(fq[0, 1:, 0], [float(r[3]) for r in fr[1:]], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(fq[0, 1:, 1], [float(r[4]) for r in fr[1:]], rtol=1e-12, atol=1e-12)
+
+
+def test_kalman_filter_test_table(eng, golden_dir):
+    """core/src/test/scala/KalmanFilter.scala:78-189 through the engine (generic kernel: p = 2)."""
+    g = json.load(open(os.path.join(golden_dir, "kalman_filter_test.json")))
+    mod = Dlm.polynomial(1) * Dlm.polynomial(1)
+    p = DlmParameters(np.diag(g["v"]), np.diag(g["w"]), np.array(g["m0"]), np.diag(g["c0"]))
+    y = np.array([[np.nan if v is None else v for v in row] for row in g["obs"]]).reshape(1, 6, 2)
+    mat = materialise(mod, g["times"])
+    out = eng.filter(mat, p, y, want_prior=True, want_fq=True)
+    m, C = split(out["filt"][0], 2); a, R = split(out["prior"][0], 2)
+    f, Q = out["fq"][0][:, :2], out["fq"][0][:, 2:]
+    got = {"m": m, "a": a, "f": f}
+    gotm = {"C": C, "R": R, "Q": Q}
+    for k, exp in g["steps"].items():
+        t = int(k)
+        for name in ("a", "f", "m"):
+            if name in exp:
+                np.testing.assert_allclose(got[name][t], exp[name], atol=g["tol"], rtol=0)
+        for name in ("R", "Q", "C"):
+            if name in exp:
+                np.testing.assert_allclose(oracle.from_cm(gotm[name][t], 2, 2), np.diag(exp[name]), atol=g["tol"], rtol=0)
+    assert abs(m[6][0] - g["steps"]["6"]["m_first_commented"]) < 1e-4
+    assert np.all(np.isnan(out["fq"][0][0]))
+
+
+# ------------------------------------------------------------------------------------------
+# engine vs oracle on seeded inputs
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags", VARIANTS)
+@pytest.mark.parametrize("missing", [0.0, 0.15])
+def test_seasonal_d13_filter_smooth(eng, flags, missing):
+    mod, mat, p = seasonal_model(T=200)
+    N = 5
+    y = simulate(mat, p, N, seed=42, missing=missing)
+    out = eng.filter_smooth(mat, p, y, flags=flags)
+    assert np.all(out["status"] == 0)
+    for n in range(N):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], 13); sm, S = split(out["smooth"][n], 13)
+        # tolerance: 1e-9 relative + 1e-10 absolute over T = 200 steps of d = 13 recursions
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+
+
+def test_smoother_q1_compat_switch(eng):
+    """DLM_OPT_SMOOTHER_COMPAT_Q1 reproduces the literal Smoothing.scala:44 form."""
+    mod, mat, p = seasonal_model(T=60)
+    y = simulate(mat, p, 2, seed=1)
+    out = eng.filter_smooth(mat, p, y, flags=_lib.OPT_SMOOTHER_COMPAT_Q1)
+    assert eng.last_variant == "generic"
+    for n in range(2):
+        f, s = oracle_filter_smooth(mat, p, y[n], compat=True)
+        sm, S = split(out["smooth"][n], 13)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+
+
+def test_multivariate_d8_p4_missing_irregular(eng):
+    """|*| of four polynomial(2) models: p = 4 observations, partial missingness, irregular dt."""
+    mod = Dlm.polynomial(2)
+    for _ in range(3):
+        mod = mod * Dlm.polynomial(2)
+    times = np.cumsum(np.array([1, 1, 2, 1, 1, 3, 1, 1, 1, 2] * 5, dtype=np.float64))
+    mat = materialise(mod, times)
+    assert mat.d == 8 and mat.p == 4 and mat.dt is not None
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((8, 8))
+    p = DlmParameters(np.diag([1.0, 2.0, 0.5, 1.5]), A @ A.T / 8 + 0.1 * np.eye(8), rng.standard_normal(8), np.eye(8) * 2)
+    y = simulate(mat, p, 3, seed=5, missing=0.25)
+    out = eng.filter_smooth(mat, p, y)
+    pr = eng.filter(mat, p, y, want_prior=True, want_fq=True)
+    for n in range(3):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], 8); sm, S = split(out["smooth"][n], 8)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+        a, R = split(pr["prior"][n], 8)
+        np.testing.assert_allclose(a, f["a"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(R, f["R"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(pr["fq"][n][1:, :4], f["f"][1:], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(pr["fq"][n][1:, 4:], f["Q"][1:], rtol=1e-9, atol=1e-10)
+
+
+def test_per_series_parameters(eng):
+    mod, mat, p = seasonal_model(T=50)
+    rng = np.random.default_rng(2)
+    ps = [DlmParameters(p.v * rng.uniform(0.5, 2), p.w * rng.uniform(0.5, 2), rng.standard_normal(13), np.eye(13) * rng.uniform(0.5, 3))
+          for _ in range(4)]
+    y = simulate(mat, p, 4, seed=8)
+    for flags in VARIANTS:
+        out = eng.filter_smooth(mat, ps, y, flags=flags)
+        for n in range(4):
+            f, s = oracle_filter_smooth(mat, ps[n], y[n])
+            m, C = split(out["filt"][n], 13); sm, S = split(out["smooth"][n], 13)
+            np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(C, f["C"], rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+
+
+def test_d40_p20_config4_small(eng):
+    """Config C4 shape (|*| of 20 polynomial(2)), small N and T."""
+    mod = Dlm.polynomial(2)
+    for _ in range(19):
+        mod = mod * Dlm.polynomial(2)
+    mat = materialise(mod, np.arange(1, 21, dtype=np.float64))
+    assert mat.d == 40 and mat.p == 20
+    rng = np.random.default_rng(40)
+    A = rng.standard_normal((40, 40))
+    p = DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
+    y = simulate(mat, p, 2, seed=40, missing=0.05)
+    out = eng.filter_smooth(mat, p, y)
+    for n in range(2):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], 40); sm, S = split(out["smooth"][n], 40)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-7, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------
+# FFBS: conditional moments, draws under a shared RNG, sufficient statistics
+# ------------------------------------------------------------------------------------------
+def test_ffbs_moments_draws_and_stats(eng):
+    mod, mat, p = seasonal_model(T=80)
+    N = 3
+    y = simulate(mat, p, N, seed=77, missing=0.1)
+    seed = 20240611
+    out = eng.ffbs(mat, p, y, seed=seed, series_offset=5, want_cond=True)
+    assert np.all(out["status"] == 0)
+    om = omodel(mat)
+    for n in range(N):
+        f = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y[n])
+        z = oracle.normals(seed, 5 + n, 81, 13)
+        o = oracle.backward_sample(om, p.w, f, z, factor="chol")
+        # (ii) draws equal the oracle's under the shared Philox stream and the Cholesky factor
+        np.testing.assert_allclose(out["theta"][n], o["theta"], rtol=1e-7, atol=1e-8)
+        # (i) conditional moments (h_t, H_t) given the same theta_{t+1}
+        h, H = split(out["cond"][n], 13)
+        np.testing.assert_allclose(h, o["h"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(H, o["H"], rtol=1e-7, atol=1e-8)
+        st = oracle.gibbs_stats(om, y[n], o["theta"])
+        L = out["stats"].shape[1]
+        assert L == 1 + 1 + 13 + 1
+        np.testing.assert_allclose(out["stats"][n, 0], st["ssy"][0], rtol=1e-7)
+        assert out["stats"][n, 1] == st["n"][0]
+        np.testing.assert_allclose(out["stats"][n, 2:15], st["ss"], rtol=1e-7)
+        assert out["stats"][n, 15] == 80
+    # injected normals path + outer-product statistics (GibbsWishart)
+    zin = np.random.default_rng(3).standard_normal((N, 81, 13))
+    out2 = eng.ffbs(mat, p, y, z=zin, flags=_lib.OPT_STATS_OUTER)
+    for n in range(N):
+        f = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y[n])
+        o = oracle.backward_sample(om, p.w, f, zin[n], factor="chol")
+        np.testing.assert_allclose(out2["theta"][n], o["theta"], rtol=1e-7, atol=1e-8)
+        st = oracle.gibbs_stats(om, y[n], o["theta"], want_outer=True)
+        np.testing.assert_allclose(out2["stats"][n, 2:2 + 169], st["outer"], rtol=1e-6, atol=1e-8)
+    pooled = eng.stats_pool(out2["stats"])
+    np.testing.assert_allclose(pooled, out2["stats"].sum(axis=0), rtol=1e-12)
+
+
+def test_ffbs_distribution_matches_rts(eng):
+    """(iii) many draws of one series: sample mean/cov of theta_t match the RTS smoother."""
+    mod = Dlm.polynomial(2)
+    mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
+    p = DlmParameters([[3.0]], np.diag([1.0, 0.3]), [0.0, 0.0], np.eye(2) * 0.5)
+    y1 = simulate(mat, p, 1, seed=4)
+    N = 4000
+    y = np.repeat(y1, N, axis=0)
+    out = eng.ffbs(mat, p, y, seed=99)
+    f, s = oracle_filter_smooth(mat, p, y1[0])
+    th = out["theta"]
+    for t in (0, 10, 30):
+        mean = th[:, t].mean(axis=0)
+        cov = np.cov(th[:, t].T)
+        S = oracle.from_cm(s["S"][t], 2, 2)
+        se = np.sqrt(np.diag(S) / N)
+        assert np.all(np.abs(mean - s["s"][t]) < 5 * se)
+        np.testing.assert_allclose(cov, S, rtol=0.15, atol=0.02)
+
+
+def test_argument_errors(eng):
+    mod, mat, p = seasonal_model(T=10)
+    from bayesian_dlms_amd.engine import EngineError
+    y = np.zeros((1, 10, 1))
+    bad = materialise(mod, np.arange(1, 11, dtype=np.float64))
+    bad.T = 0
+    with pytest.raises(EngineError):
+        eng.filter(bad, p, np.zeros((1, 0, 1)))
+
+
+def test_device_pointer_mode_matches_host_mode(eng):
+    import torch
+    mod, mat, p = seasonal_model(T=64)
+    y = simulate(mat, p, 8, seed=12)
+    host = eng.filter_smooth(mat, p, y)
+    dev = eng.filter_smooth(mat, p, torch.as_tensor(y, device="cuda:0"))
+    np.testing.assert_array_equal(dev["filt"].cpu().numpy(), host["filt"])
+    np.testing.assert_array_equal(dev["smooth"].cpu().numpy(), host["smooth"])
