@@ -53,6 +53,7 @@ SYMBOLS = [
     ("dlm_filter_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V, _V, _V]),
     ("dlm_smooth_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V]),
     ("dlm_filter_smooth_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V, _V]),
+    ("dlm_last_timing", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_double * 2)]),
     ("dlm_ffbs_batch", ctypes.c_int, [_V, _MP, _PP, _V, _V, _OP, _V, _V, _V, _V, _V]),
     ("dlm_stats_len", ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32]),
     ("dlm_backward_sample_batch", ctypes.c_int, [_V, _MP, _PP, _V, _V, _V, _OP, _V, _V, _V, _V]),

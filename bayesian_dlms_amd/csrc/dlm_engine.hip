@@ -20,6 +20,10 @@ struct dlm_engine {
   const char* variant = "none";
   void* arena = nullptr;      // device staging arena for DLM_MEM_HOST calls
   size_t arena_bytes = 0;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around the forward and backward kernels
+  bool timed = false;
+  double* side = nullptr;     // forward->backward innovations buffer of the fused fast path
+  size_t side_bytes = 0;
   ncclComm_t comm = nullptr;
   bool has_comm = false;
 };
@@ -127,10 +131,22 @@ void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params
 
 bool use_fast(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::mfma16_supported(k); }
 
-int run_filter(dlm_engine* e, const KArgs& k) {
+int ensure_side(dlm_engine* e, const KArgs& k) {
+  const size_t need = sizeof(double) * 2 * (size_t)k.N * ((size_t)k.T + 1);
+  if (need > e->side_bytes) {
+    if (e->side) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->side)); e->side = nullptr; e->side_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->side, need));
+    e->side_bytes = need;
+  }
+  return DLM_OK;
+}
+
+// want_side: the caller will run the fast backward pass on this filter's output
+int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
   if (use_fast(k) && !k.prior) {
     e->variant = "mfma16";
-    HIP_TRY(e, dlm::launch_mfma16_filter(k, e->stream));
+    if (want_side) { int rc = ensure_side(e, k); if (rc) return rc; }
+    HIP_TRY(e, dlm::launch_mfma16_filter(k, want_side ? e->side : nullptr, e->stream));
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_filter(k, e->stream));
@@ -138,10 +154,13 @@ int run_filter(dlm_engine* e, const KArgs& k) {
   return DLM_OK;
 }
 
-int run_smoother(dlm_engine* e, const KArgs& k) {
-  if (use_fast(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1)) {
+bool fast_smoother_ok(const KArgs& k) { return use_fast(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1); }
+
+// have_side: the preceding run_filter(.., want_side = true) of THIS call filled e->side
+int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
+  if (have_side && fast_smoother_ok(k)) {
     e->variant = "mfma16";
-    HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->stream));
+    HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->side, e->stream));
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_smoother(k, e->stream));
@@ -167,6 +186,7 @@ int dlm_engine_create(int device, dlm_engine** out) {
     return DLM_ERR_HIP;
   }
   e->stream = e->own_stream;
+  for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   *out = e;
   return DLM_OK;
 }
@@ -176,6 +196,8 @@ void dlm_engine_destroy(dlm_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->has_comm) ncclCommDestroy(e->comm);
   if (e->arena) (void)hipFree(e->arena);
+  if (e->side) (void)hipFree(e->side);
+  for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -192,6 +214,17 @@ int dlm_engine_set_stream(dlm_engine* e, void* hip_stream) {
 int dlm_engine_sync(dlm_engine* e) {
   if (!e) return DLM_ERR_ARG;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return DLM_OK;
+}
+
+int dlm_last_timing(dlm_engine* e, double ms[2]) {
+  if (!e || !ms) return DLM_ERR_ARG;
+  if (!e->timed) return fail(e, DLM_ERR_ARG, "no fused call has been timed yet");
+  float f = 0.f, b = 0.f;
+  HIP_TRY(e, hipEventSynchronize(e->ev[2]));
+  HIP_TRY(e, hipEventElapsedTime(&f, e->ev[0], e->ev[1]));
+  HIP_TRY(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+  ms[0] = f; ms[1] = b;
   return DLM_OK;
 }
 
@@ -213,7 +246,7 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   st.out(&k.fq, fq, N * (T + 1) * (p + p * p));
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
-  if ((rc = run_filter(e, k))) return rc;
+  if ((rc = run_filter(e, k, false))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
@@ -230,7 +263,7 @@ int dlm_smooth_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   st.out(&k.smooth, smooth, N * (T + 1) * rec);
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
-  if ((rc = run_smoother(e, k))) return rc;
+  if ((rc = run_smoother(e, k, false))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
@@ -250,9 +283,14 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   st.out(&k.smooth, smooth, N * (T + 1) * rec);
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
-  if ((rc = run_filter(e, k))) return rc;
+  const bool fused_fast = fast_smoother_ok(k);
+  HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+  if ((rc = run_filter(e, k, fused_fast))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
   k.filt_in = k.filt;
-  if ((rc = run_smoother(e, k))) return rc;
+  if ((rc = run_smoother(e, k, fused_fast))) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
+  e->timed = true;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
@@ -280,7 +318,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if (forward) {
-    if ((rc = run_filter(e, k))) return rc;
+    if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }
   e->variant = "generic";

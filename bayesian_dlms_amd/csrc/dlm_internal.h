@@ -44,8 +44,9 @@ hipError_t launch_stats_pool(const double* stats, int N, int L, double* pooled, 
 
 // ---- specialised d <= 16, p == 1 kernels on the fp64 MFMA layout, dlm_mfma16.hip ------
 bool mfma16_supported(const KArgs& a);
-hipError_t launch_mfma16_filter(const KArgs& a, hipStream_t s);
-hipError_t launch_mfma16_smoother(const KArgs& a, hipStream_t s);
+// `side` [N][T+1][2] carries (e_t/Q_t, 1/Q_t) from the forward to the backward pass (NaN = no update)
+hipError_t launch_mfma16_filter(const KArgs& a, double* side, hipStream_t s);
+hipError_t launch_mfma16_smoother(const KArgs& a, const double* side, hipStream_t s);
 
 // ---- SVD filter / sampler (one-sided Jacobi in LDS), dlm_svd.hip ----------------------
 size_t svd_filter_lds_bytes(int d, int p);

@@ -169,6 +169,12 @@ class Engine:
                                                      be.ptr(smooth), be.ptr(status)))
         return {"filt": filt, "smooth": smooth, "status": status}
 
+    def last_timing(self):
+        """(forward_ms, backward_ms) of the last fused call, from HIP events on the engine stream."""
+        ms = (ctypes.c_double * 2)()
+        self._check(self.lib.dlm_last_timing(self.h, ctypes.byref(ms)))
+        return float(ms[0]), float(ms[1])
+
     def ffbs(self, mat, params, y, *, z=None, seed=0, series_offset=0, flags=0, want_theta=True,
              want_cond=False, want_stats=True, filt=None):
         """FFBS (filt=None) or backward sampling from existing filter records (filt given)."""

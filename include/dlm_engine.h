@@ -126,6 +126,10 @@ int dlm_filter_smooth_batch(dlm_engine *e, const dlm_model_desc *model,
                             const dlm_options *opts, double *filt, double *smooth,
                             int32_t *status);
 
+/* Device time of the forward (ms[0]) and backward (ms[1]) kernel of the LAST
+ * dlm_filter_smooth_batch call, from HIP events recorded on the engine's stream. */
+int dlm_last_timing(dlm_engine *e, double ms[2]);
+
 /* ---- FFBS + Gibbs sufficient statistics --------------------------------------------
  * Replaces Smoothing.ffbsDlm (Smoothing.scala:173-180) and, when `stats` is given, the
  * sums inside GibbsSampling.sampleObservationMatrix / sampleSystemMatrix
