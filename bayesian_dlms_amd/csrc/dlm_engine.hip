@@ -22,6 +22,8 @@ struct dlm_engine {
   size_t arena_bytes = 0;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around the forward and backward kernels
   bool timed = false;
+  dlm::SparseT* sp_dev = nullptr;  // [2]: row table, column table of G (structured fast path)
+  int sparse_k = 0;           // 0: G is not structured (dense MFMA path)
   double* side = nullptr;     // forward->backward innovations buffer of the fused fast path
   size_t side_bytes = 0;
   ncclComm_t comm = nullptr;
@@ -131,6 +133,28 @@ void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params
 
 bool use_fast(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::mfma16_supported(k); }
 
+// Inspect G (one table entry, fast path only) and upload its sparse tables when it is
+// structured.  `G_user` is the caller's pointer (host or device according to host_mode).
+int analyse_g(dlm_engine* e, const KArgs& k, const double* G_user, bool host_mode) {
+  e->sparse_k = 0;
+  if (!use_fast(k)) return DLM_OK;
+  const size_t dd = (size_t)k.d * k.d;
+  std::vector<double> g(dd);
+  if (host_mode) memcpy(g.data(), G_user, dd * sizeof(double));
+  else {
+    HIP_TRY(e, hipMemcpyAsync(g.data(), G_user, dd * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  dlm::SparseT tabs[2];
+  const int K = dlm::sparse16_analyse(g.data(), k.d, &tabs[0], &tabs[1]);
+  if (K > 4) return DLM_OK;
+  if (!e->sp_dev) HIP_TRY(e, hipMalloc((void**)&e->sp_dev, sizeof(tabs)));
+  HIP_TRY(e, hipMemcpyAsync(e->sp_dev, tabs, sizeof(tabs), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));  // tabs is on this stack frame
+  e->sparse_k = K;
+  return DLM_OK;
+}
+
 int ensure_side(dlm_engine* e, const KArgs& k) {
   const size_t need = sizeof(double) * 2 * (size_t)k.N * ((size_t)k.T + 1);
   if (need > e->side_bytes) {
@@ -144,9 +168,15 @@ int ensure_side(dlm_engine* e, const KArgs& k) {
 // want_side: the caller will run the fast backward pass on this filter's output
 int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
   if (use_fast(k) && !k.prior) {
-    e->variant = "mfma16";
     if (want_side) { int rc = ensure_side(e, k); if (rc) return rc; }
-    HIP_TRY(e, dlm::launch_mfma16_filter(k, want_side ? e->side : nullptr, e->stream));
+    double* side = want_side ? e->side : nullptr;
+    if (e->sparse_k) {
+      e->variant = "sparse16";
+      HIP_TRY(e, dlm::launch_sparse16_filter(k, e->sparse_k, e->sp_dev, side, e->stream));
+    } else {
+      e->variant = "mfma16";
+      HIP_TRY(e, dlm::launch_mfma16_filter(k, side, e->stream));
+    }
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_filter(k, e->stream));
@@ -159,8 +189,13 @@ bool fast_smoother_ok(const KArgs& k) { return use_fast(k) && !(k.flags & DLM_OP
 // have_side: the preceding run_filter(.., want_side = true) of THIS call filled e->side
 int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
   if (have_side && fast_smoother_ok(k)) {
-    e->variant = "mfma16";
-    HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->side, e->stream));
+    if (e->sparse_k) {
+      e->variant = "sparse16";
+      HIP_TRY(e, dlm::launch_sparse16_smoother(k, e->sparse_k, e->sp_dev + 1, e->side, e->stream));
+    } else {
+      e->variant = "mfma16";
+      HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->side, e->stream));
+    }
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_smoother(k, e->stream));
@@ -197,6 +232,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->has_comm) ncclCommDestroy(e->comm);
   if (e->arena) (void)hipFree(e->arena);
   if (e->side) (void)hipFree(e->side);
+  if (e->sp_dev) (void)hipFree(e->sp_dev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -246,6 +282,7 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   st.out(&k.fq, fq, N * (T + 1) * (p + p * p));
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
+  if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
   if ((rc = run_filter(e, k, false))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
@@ -283,6 +320,7 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   st.out(&k.smooth, smooth, N * (T + 1) * rec);
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
+  if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
   const bool fused_fast = fast_smoother_ok(k);
   HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
   if ((rc = run_filter(e, k, fused_fast))) return rc;
@@ -318,6 +356,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if (forward) {
+    if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }

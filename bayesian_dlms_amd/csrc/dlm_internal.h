@@ -48,6 +48,12 @@ bool mfma16_supported(const KArgs& a);
 hipError_t launch_mfma16_filter(const KArgs& a, double* side, hipStream_t s);
 hipError_t launch_mfma16_smoother(const KArgs& a, const double* side, hipStream_t s);
 
+// ---- structured-G variant of the fast path (<= 4 nonzeros per row/column), dlm_sparse16.hip
+struct SparseT { int K; int pad; int idx[16][4]; double val[16][4]; };
+int sparse16_analyse(const double* G_host, int d, SparseT* rows, SparseT* cols);
+hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev, double* side, hipStream_t s);
+hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s);
+
 // ---- SVD filter / sampler (one-sided Jacobi in LDS), dlm_svd.hip ----------------------
 size_t svd_filter_lds_bytes(int d, int p);
 hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s);

@@ -147,15 +147,18 @@ __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restri
       if (sd && lane == 0) { sd[2 * (t + 1)] = __builtin_nan(""); sd[2 * (t + 1) + 1] = __builtin_nan(""); }
     }
     if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
-    bool bad = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * r + g;
-      if (vr[r] && vc) { o[d + i * d + c] = cc[r]; bad |= !isfinite(cc[r]); }
-      if (vr[r] && col15) { o[i] = mrow[r]; bad |= !isfinite(mrow[r]); }
+      if (vr[r] && vc) o[d + i * d + c] = cc[r];
+      if (vr[r] && col15) o[i] = mrow[r];
     }
-    if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   }
+  // a non-finite value, once present, propagates to every later state: test the last one
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bad |= (vr[r] && vc && !isfinite(cc[r])) || (vr[r] && col15 && !isfinite(mrow[r]));
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256) void k_smoother_mfma16(KArgs a, const double* 
   }
   d4 P = {0.0, 0.0, 0.0, 0.0}, qrow = {0.0, 0.0, 0.0, 0.0};
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+  bool bad = false;  // P and q carry any non-finite value down to record 0: test that one
 
   // software prefetch of the next record
   d4 ncc, nm;
@@ -234,15 +238,14 @@ __global__ __launch_bounds__(256) void k_smoother_mfma16(KArgs a, const double* 
 
     // s_t = m_t + C_t q_t ; S_t = C_t - C_t P_t C_t
     double* o = out + (size_t)t * rec;
-    bool bad = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * r + g;
       const double Sv = cc[r] - x2[r], sv = mrow[r] + x2[r];
-      if (vr[r] && vc) { o[d + i * d + c] = Sv; bad |= !isfinite(Sv); }
-      if (vr[r] && col15) { o[i] = sv; bad |= !isfinite(sv); }
+      if (vr[r] && vc) o[d + i * d + c] = Sv;
+      if (vr[r] && col15) o[i] = sv;
+      if (t == 0) bad |= (vr[r] && vc && !isfinite(Sv)) || (vr[r] && col15 && !isfinite(sv));
     }
-    if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
     if (t == 0) break;
 
     // (q_{t-1}, P_{t-1}) from (q_t, P_t)
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(256) void k_smoother_mfma16(KArgs a, const double* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { P[r] = col15 ? 0.0 : pn[r]; qrow[r] = pn[r]; }
   }
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 

@@ -1,0 +1,403 @@
+// Fast path for structured system matrices: d <= 15, p == 1, one G, regular grid, and at
+// most K <= 4 nonzeros in every row AND every column of G.  Every model the reference can
+// build satisfies this (polynomial: bidiagonal, seasonal: 2x2 rotation blocks, regression:
+// identity, autoregressive: diagonal; Dlm.scala:139-243), and |+| / |*| keep it
+// (block-diagonal composition, Dlm.scala:107-122, :197-208).  Dense G uses dlm_mfma16.hip.
+//
+// Same register layout as dlm_mfma16.hip (fp64 MFMA accumulator layout, one wavefront per
+// series).  What changes: the congruence T X T^T with a sparse T (T = G in the forward
+// pass, T = G^T in the backward pass) costs O(K d^2) instead of two dense products.  It runs
+// as two gather passes through a wave-private LDS image with an odd leading dimension (17
+// doubles), so that both the row-wise and the transposed read are bank-conflict free:
+//     pass 1   Y[i][j] = sum_s X[i][idx_s(j)] val_s(j)          (= X T^T)
+//     pass 2   Z[i][j] = sum_s Y[idx_s(j)][i] val_s(j)          (= (T Y)^T = T X T^T, symmetric)
+// where (idx_s(j), val_s(j)) are the nonzeros of row j of T.  The fp64 MFMA pipe is then
+// used only for the two genuinely dense products of the backward pass (P C and C (P C)),
+// and runs concurrently with the VALU work of the other resident waves.
+//
+// Recursions and reference citations: see dlm_mfma16.hip (identical algebra).
+#include "dlm_internal.h"
+#include "../../include/dlm_engine.h"
+
+namespace dlm {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+constexpr int LD = 17;                        // leading dimension of an LDS image
+constexpr int IMG = 16 * LD;                  // doubles per image
+constexpr int WAVE_LDS = 2 * IMG + 5 * 16;    // two images + five 16-vectors per wave
+
+__device__ __forceinline__ d4 mmT(const d4& x, const d4& y) {  // X^T * Y
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], y[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], y[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], y[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], y[3], acc, 0, 0, 0);
+  return acc;
+}
+
+// LDS hand-off between lanes of ONE wavefront: the LDS queue is in order per wave, so only
+// the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {  // DPP rotate within a 16-lane row
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a row (over c); every lane of the row gets the sum
+__device__ __forceinline__ double row_sum(double v) {
+  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+  return v;
+}
+// sum over lanes c, c+16, c+32, c+48 (over g) with the gfx950 permlane swaps; all get the sum
+__device__ __forceinline__ double sum_g(double v) {
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+  l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+
+__device__ __forceinline__ double uniform_from_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane((int)__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane((int)__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Z = T X T^T for symmetric X (std layout), T given by the per-column-lane tables idx/val.
+template <int K>
+__device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB, const int (&idx)[K],
+                                         const double (&val)[K], int g, int c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + c] = x[r];
+  wave_sync();
+  d4 y;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double acc = imgA[(4 * r + g) * LD + idx[0]] * val[0];
+#pragma unroll
+    for (int s = 1; s < K; ++s) acc = fma(imgA[(4 * r + g) * LD + idx[s]], val[s], acc);
+    y[r] = acc;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) imgB[(4 * r + g) * LD + c] = y[r];
+  wave_sync();
+  d4 z;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double acc = imgB[idx[0] * LD + 4 * r + g] * val[0];
+#pragma unroll
+    for (int s = 1; s < K; ++s) acc = fma(imgB[idx[s] * LD + 4 * r + g], val[s], acc);
+    z[r] = acc;
+  }
+  return z;
+}
+
+// ---------------------------------------------------------------------------------------
+// forward pass (no MFMA at all: O(K d^2) per step)
+// ---------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
+                                                     double* __restrict__ side) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= a.N) return;
+  double* imgA = lds + wave * WAVE_LDS;
+  double* imgB = imgA + IMG;
+  double* vM = imgB + IMG;       // m, column-indexed
+  double* vRF = vM + 16;         // R F
+  const int d = a.d, T = a.T, rec = d + d * d;
+  const int g = lane >> 4, c = lane & 15;
+  const bool vc = c < d;
+
+  const double* W = a.W + (size_t)n * a.w_stride;
+  const double* C0 = a.C0 + (size_t)n * a.c0_stride;
+  const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+  const double V = a.V[(size_t)n * a.v_stride];
+  const double* y = a.y + (size_t)n * T;
+  double* out = a.filt + (size_t)n * (T + 1) * rec;
+  double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
+  double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
+
+  int idx[K];
+  double val[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { idx[s] = sp->idx[c][s]; val[s] = sp->val[c][s]; }
+  d4 w, cc;
+  double Fr[4];
+  bool vr[4];
+  const double Fc = vc ? a.F[c] : 0.0;
+  double mcol = vc ? m0[c] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    vr[r] = i < d;
+    const bool ok = vr[r] && vc;
+    w[r] = ok ? W[i * d + c] : 0.0;
+    cc[r] = ok ? C0[i * d + c] : 0.0;
+    Fr[r] = vr[r] ? a.F[i] : 0.0;
+  }
+  int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    if (vr[r] && vc) out[d + i * d + c] = cc[r];
+  }
+  if (g == 0 && vc) out[c] = mcol;
+  if (lane == 0) {
+    if (fq) { fq[0] = __builtin_nan(""); fq[1] = __builtin_nan(""); }
+    if (sd) { sd[0] = __builtin_nan(""); sd[1] = __builtin_nan(""); }
+  }
+
+  double ychunk = 0.0;
+  for (int t = 0; t < T; ++t) {
+    if ((t & 63) == 0) ychunk = (t + lane < T) ? y[t + lane] : 0.0;
+    const double yt = uniform_from_lane(ychunk, t & 63);
+
+    // advState: a = G m, R = G C G^T + W
+    vM[c] = mcol;
+    d4 R = congruence<K>(cc, imgA, imgB, idx, val, g, c);   // first wave_sync also covers vM
+    double acol = vM[idx[0]] * val[0];
+#pragma unroll
+    for (int s = 1; s < K; ++s) acol = fma(vM[idx[s]], val[s], acol);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[r] += w[r];
+
+    // f = F^T a ; RF ; Q = F^T R F + V
+    const double f = row_sum(Fc * acol);
+    double rfc = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rfc = fma(R[r], Fr[r], rfc);
+    rfc = sum_g(rfc);                                        // (R F)[c] in every lane
+    vRF[c] = rfc;
+    wave_sync();
+    double rfr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rfr[r] = vRF[4 * r + g];     // (R F)[4r+g]
+    const double Q = row_sum(Fc * rfc) + V;
+
+    double* o = out + (size_t)(t + 1) * rec;
+    if (yt == yt) {
+      const double e = yt - f, rq = 1.0 / Q;
+      const double Kc = rfc * rq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double Kr = rfr[r] * rq;
+        cc[r] = fma(Q * Kr, Kc, fma(-rfr[r], Kc, fma(-Kr, rfc, R[r])));
+      }
+      mcol = fma(Kc, e, acol);
+      if (sd && lane == 0) { sd[2 * (t + 1)] = e * rq; sd[2 * (t + 1) + 1] = rq; }
+    } else {
+      cc = R;
+      mcol = acol;
+      if (sd && lane == 0) { sd[2 * (t + 1)] = __builtin_nan(""); sd[2 * (t + 1) + 1] = __builtin_nan(""); }
+    }
+    if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * r + g;
+      if (vr[r] && vc) o[d + i * d + c] = cc[r];
+    }
+    if (g == 0 && vc) o[c] = mcol;
+    wave_sync();   // vM / images are rewritten at the top of the next step
+  }
+  bool bad = vc && !isfinite(mcol);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bad |= vr[r] && vc && !isfinite(cc[r]);
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+// ---------------------------------------------------------------------------------------
+// backward pass: MFMA for P C and C (P C); gathers for G^T M G
+// ---------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
+                                                       const double* __restrict__ side) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= a.N) return;
+  double* imgA = lds + wave * WAVE_LDS;
+  double* imgB = imgA + IMG;
+  double* vK = imgB + IMG;       // K_t
+  double* vQ = vK + 16;          // q_t
+  double* vPK = vQ + 16;         // P K
+  double* vCQ = vPK + 16;        // C q
+  double* vR = vCQ + 16;         // r
+  const int d = a.d, T = a.T, rec = d + d * d;
+  const int g = lane >> 4, c = lane & 15;
+  const bool vc = c < d, col15 = (c == 15);
+
+  const double V = a.V[(size_t)n * a.v_stride];
+  const double rV = 1.0 / V;
+  const double* fin = a.filt_in + (size_t)n * (T + 1) * rec;
+  double* out = a.smooth + (size_t)n * (T + 1) * rec;
+  const double* sd = side + (size_t)n * (T + 1) * 2;
+
+  int idx[K];
+  double val[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { idx[s] = sp->idx[c][s]; val[s] = sp->val[c][s]; }
+  double Fr[4];
+  bool vr[4];
+  const double Fc = vc ? a.F[c] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { vr[r] = (4 * r + g) < d; Fr[r] = vr[r] ? a.F[4 * r + g] : 0.0; }
+  d4 P = {0.0, 0.0, 0.0, 0.0};
+  double qcol = 0.0;
+  int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+  bool bad = false;
+
+  d4 ncc;
+  double nm;
+  {
+    const double* r0 = fin + (size_t)T * rec;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int i = 4 * r + g; ncc[r] = (vr[r] && vc) ? r0[d + i * d + c] : 0.0; }
+    nm = vc ? r0[c] : 0.0;
+  }
+  double neq = sd[2 * T], niq = sd[2 * T + 1];
+  vQ[c] = 0.0;
+
+  for (int t = T; t >= 0; --t) {
+    const d4 cc = ncc;
+    const double mcol = nm, eq = neq, iq = niq;
+    if (t > 0) {
+      const double* r0 = fin + (size_t)(t - 1) * rec;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int i = 4 * r + g; ncc[r] = (vr[r] && vc) ? r0[d + i * d + c] : 0.0; }
+      nm = vc ? r0[c] : 0.0;
+      neq = sd[2 * (t - 1)]; niq = sd[2 * (t - 1) + 1];
+    }
+    const bool observed = (iq == iq) && t > 0;
+
+    // K_t = C_t F / V
+    double kcol = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kcol = fma(cc[r], Fr[r], kcol);
+    kcol = observed ? sum_g(kcol) * rV : 0.0;
+    vK[c] = kcol;
+    wave_sync();                                             // also publishes vQ of the last step
+    d4 b1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b1[r] = col15 ? vK[4 * r + g] : cc[r];
+    const d4 x1 = mmT(P, b1);                                // [P C | P K]
+    d4 b2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b2[r] = col15 ? vQ[4 * r + g] : x1[r];
+    const d4 x2 = mmT(cc, b2);                               // [C P C | C q]
+
+    // column 15 carries P K (x1) and C q (x2), row-indexed: hand them to every lane
+    if (col15) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { vPK[4 * r + g] = x1[r]; vCQ[4 * r + g] = x2[r]; }
+    }
+    wave_sync();
+    const double scol = mcol + vCQ[c];                       // s_t = m_t + C_t q_t
+    double* o = out + (size_t)t * rec;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * r + g;
+      const double Sv = cc[r] - x2[r];                       // S_t = C_t - C_t P_t C_t
+      if (vr[r] && vc) o[d + i * d + c] = Sv;
+      if (t == 0) bad |= vr[r] && vc && !isfinite(Sv);
+    }
+    if (g == 0 && vc) o[c] = scol;
+    if (t == 0) { bad |= vc && !isfinite(scol); break; }
+
+    // (q_{t-1}, P_{t-1}) from (q_t, P_t)
+    d4 M = P;
+    double rcol = qcol;
+    if (observed) {
+      const double pkc = vPK[c];
+      const double kq = row_sum(kcol * qcol), kpk = row_sum(kcol * pkc);
+      const double sc = iq + kpk;
+      rcol = fma(Fc, eq - kq, qcol);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        M[r] = fma(-vPK[4 * r + g], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
+    }
+    vR[c] = rcol;
+    P = congruence<K>(M, imgA, imgB, idx, val, g, c);        // G^T M G (first sync covers vR)
+    qcol = vR[idx[0]] * val[0];
+#pragma unroll
+    for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
+    vQ[c] = qcol;                                            // published by the next wave_sync
+  }
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: structure detection and launch
+// ---------------------------------------------------------------------------------------
+// Nonzeros of the rows of G (`rows`, forward pass) and of the columns of G (`cols`, backward
+// pass).  Returns the largest count, or 99 if any row/column has more than 4.
+int sparse16_analyse(const double* G /* d x d column-major, host */, int d, SparseT* rows, SparseT* cols) {
+  int kmax = 1;
+  for (int pass = 0; pass < 2; ++pass) {
+    SparseT* t = pass ? cols : rows;
+    for (int j = 0; j < 16; ++j)
+      for (int s = 0; s < 4; ++s) { t->idx[j][s] = 0; t->val[j][s] = 0.0; }
+    for (int j = 0; j < d; ++j) {
+      int cnt = 0;
+      for (int l = 0; l < d; ++l) {
+        const double v = pass ? G[l + j * d] /* G[l][j] */ : G[j + l * d] /* G[j][l] */;
+        if (v != 0.0) {
+          if (cnt == 4) return 99;
+          t->idx[j][cnt] = l; t->val[j][cnt] = v; ++cnt;
+        }
+      }
+      if (cnt > kmax) kmax = cnt;
+    }
+  }
+  rows->K = cols->K = kmax;
+  return kmax;
+}
+
+template <int K>
+static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, hipStream_t s) {
+  hipLaunchKernelGGL(k_filter_sp16<K>, dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
+  hipLaunchKernelGGL(k_smoother_sp16<K>, dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
+  return hipGetLastError();
+}
+
+hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev, double* side, hipStream_t s) {
+  switch (K) {
+    case 1: return launch_f<1>(a, rows_dev, side, s);
+    case 2: return launch_f<2>(a, rows_dev, side, s);
+    case 3: return launch_f<3>(a, rows_dev, side, s);
+    case 4: return launch_f<4>(a, rows_dev, side, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s) {
+  switch (K) {
+    case 1: return launch_s<1>(a, cols_dev, side, s);
+    case 2: return launch_s<2>(a, cols_dev, side, s);
+    case 3: return launch_s<3>(a, cols_dev, side, s);
+    case 4: return launch_s<4>(a, cols_dev, side, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace dlm

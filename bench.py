@@ -159,7 +159,7 @@ def main():
                                    f"{N} series/GPU x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
                        "series_per_gpu": N, "T": T, "d": d, "p": 1, "variant": eng.last_variant,
                        "parallelism": f"series-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_smoother_mfma16" if dom_is_bwd else "k_filter_mfma16",
+            "roofline": {"bound": "hbm", "kernel": ("k_smoother_" if dom_is_bwd else "k_filter_") + {"sparse16": "sp16", "mfma16": "mfma16"}.get(eng.last_variant, eng.last_variant),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,

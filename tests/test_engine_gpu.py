@@ -131,6 +131,48 @@ def test_seasonal_d13_filter_smooth(eng, flags, missing):
         np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
 
 
+def _custom_model(G, F):
+    return Dlm(lambda t: F.reshape(-1, 1), lambda dt: G)
+
+
+@pytest.mark.parametrize("kind,expect", [("dense", "mfma16"), ("band3", "sparse16"), ("band4", "sparse16"),
+                                         ("identity", "sparse16"), ("d15", "sparse16"), ("dense15", "mfma16")])
+def test_fast_path_variants_by_g_structure(eng, kind, expect):
+    """The engine picks its kernel from the structure of G; every variant must match the oracle."""
+    rng = np.random.default_rng({"dense": 1, "band3": 2, "band4": 3, "identity": 4, "d15": 5, "dense15": 6}[kind])
+    d = 15 if kind.endswith("15") else 9
+    if kind.startswith("dense"):
+        A = rng.standard_normal((d, d)); G = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+    elif kind == "band3":
+        G = 0.5 * np.eye(d) + 0.3 * np.eye(d, k=1) - 0.2 * np.eye(d, k=-1)
+    elif kind == "band4":
+        G = 0.4 * np.eye(d) + 0.3 * np.eye(d, k=1) - 0.2 * np.eye(d, k=-1) + 0.1 * np.eye(d, k=3)
+    elif kind == "identity":
+        G = np.eye(d)
+    else:
+        G = 0.7 * np.eye(d) + 0.4 * np.eye(d, k=2)
+    F = rng.standard_normal(d)
+    mod = _custom_model(G, F)
+    mat = materialise(mod, np.arange(1, 121, dtype=np.float64))
+    A = rng.standard_normal((d, d))
+    p = DlmParameters([[0.7]], A @ A.T / d + 0.05 * np.eye(d), rng.standard_normal(d), np.eye(d) * 1.5)
+    y = simulate(mat, p, 6, seed=3, missing=0.1)
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == expect
+    assert np.all(out["status"] == 0)
+    for n in range(6):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], d); sm, S = split(out["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+    fq = eng.filter(mat, p, y, want_fq=True)["fq"]
+    f0 = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[0])
+    np.testing.assert_allclose(fq[0, 1:, 0], f0["f"][1:, 0], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(fq[0, 1:, 1], f0["Q"][1:, 0], rtol=1e-9, atol=1e-10)
+
+
 def test_smoother_q1_compat_switch(eng):
     """DLM_OPT_SMOOTHER_COMPAT_Q1 reproduces the literal Smoothing.scala:44 form."""
     mod, mat, p = seasonal_model(T=60)
