@@ -4,7 +4,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdlm_engine.so")
+# DLM_ENGINE_LIB selects an alternative build of the same C ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("DLM_ENGINE_LIB") or os.path.join(HERE, "libdlm_engine.so")
 
 DLM_MEM_DEVICE, DLM_MEM_HOST = 0, 1
 OPT_SMOOTHER_COMPAT_Q1 = 1 << 0

@@ -19,6 +19,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines):
+    """Experimental build with extra -D flags -> bayesian_dlms_amd/libdlm_engine_<name>.so."""
+    out = os.path.join(HERE, f"libdlm_engine_{name}.so")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-shared", "-o", out] + srcs + ["-L/opt/rocm/lib", "-lrccl"]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, "dlm_internal.h"), os.path.join(HERE, "..", "include", "dlm_engine.h")]
     objs = []

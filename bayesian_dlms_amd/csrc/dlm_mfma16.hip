@@ -58,7 +58,7 @@ bool mfma16_supported(const KArgs& a) {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restrict__ side) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
   if (n >= a.N) return;
   const int d = a.d, T = a.T, rec = d + d * d;
   const int g = lane >> 4, c = lane & 15;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restri
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_smoother_mfma16(KArgs a, const double* __restrict__ side) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
   if (n >= a.N) return;
   const int d = a.d, T = a.T, rec = d + d * d;
   const int g = lane >> 4, c = lane & 15;

@@ -28,13 +28,30 @@ constexpr int LD = 17;                        // leading dimension of an LDS ima
 constexpr int IMG = 16 * LD;                  // doubles per image
 constexpr int WAVE_LDS = 2 * IMG + 5 * 16;    // two images + five 16-vectors per wave
 
+#ifndef DLM_SM_WAVES
+#define DLM_SM_WAVES 4
+#endif
+#ifndef DLM_FI_WAVES
+#define DLM_FI_WAVES 5
+#endif
+
 __device__ __forceinline__ d4 mmT(const d4& x, const d4& y) {  // X^T * Y
+#ifdef DLM_MMT_SPLIT
+  // two independent accumulation chains halve the dependent-MFMA latency
+  const d4 z = {0.0, 0.0, 0.0, 0.0};
+  d4 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], y[0], z, 0, 0, 0);
+  d4 a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], y[1], z, 0, 0, 0);
+  a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], y[2], a0, 0, 0, 0);
+  a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], y[3], a1, 0, 0, 0);
+  return a0 + a1;
+#else
   d4 acc = {0.0, 0.0, 0.0, 0.0};
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], y[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], y[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], y[2], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], y[3], acc, 0, 0, 0);
   return acc;
+#endif
 }
 
 // LDS hand-off between lanes of ONE wavefront: the LDS queue is in order per wave, so only
@@ -75,6 +92,38 @@ __device__ __forceinline__ double uniform_from_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Record I/O through raw buffer instructions: padded lanes carry an out-of-range offset, for
+// which the hardware returns 0 on loads and drops stores -- no exec-mask branches.
+constexpr int OOB = 0x7ffffff0;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+#ifndef DLM_BUF_LOAD
+#define DLM_BUF_LOAD 1
+#endif
+#ifndef DLM_BUF_STORE
+#define DLM_BUF_STORE 1
+#endif
+#ifndef DLM_IMG_XCHG
+#define DLM_IMG_XCHG 1
+#endif
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, const char* base, int voff, int soff) {
+#if DLM_BUF_LOAD
+  const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return __hiloint2double((int)v[1], (int)v[0]);
+#else
+  return voff != OOB ? *(const double*)(base + (size_t)soff + voff) : 0.0;
+#endif
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, char* base, int voff, int soff, double x) {
+#if DLM_BUF_STORE
+  const u2 v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+#else
+  if (voff != OOB) *(double*)(base + (size_t)soff + voff) = x;
+#endif
+}
+
 // Z = T X T^T for symmetric X (std layout), T given by the per-column-lane tables idx/val.
 template <int K>
 __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB, const int (&idx)[K],
@@ -108,10 +157,11 @@ __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB
 // forward pass (no MFMA at all: O(K d^2) per step)
 // ---------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
+__global__ __launch_bounds__(256, DLM_FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                      double* __restrict__ side) {
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * 4 + wave;
   if (n >= a.N) return;
   double* imgA = lds + wave * WAVE_LDS;
@@ -127,7 +177,8 @@ __global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __r
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
   const double V = a.V[(size_t)n * a.v_stride];
   const double* y = a.y + (size_t)n * T;
-  double* out = a.filt + (size_t)n * (T + 1) * rec;
+  char* bout = (char*)(a.filt + (size_t)n * (T + 1) * rec);
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
   double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
 
@@ -138,6 +189,9 @@ __global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __r
   d4 w, cc;
   double Fr[4];
   bool vr[4];
+  int offC[4];                                   // byte offset of C[4r+g][c] inside a record
+  const int offM = (g == 0 && vc) ? c * 8 : OOB; // byte offset of m[c]
+  const int recb = rec * 8;
   const double Fc = vc ? a.F[c] : 0.0;
   double mcol = vc ? m0[c] : 0.0;
 #pragma unroll
@@ -145,6 +199,7 @@ __global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __r
     const int i = 4 * r + g;
     vr[r] = i < d;
     const bool ok = vr[r] && vc;
+    offC[r] = ok ? (d + i * d + c) * 8 : OOB;
     w[r] = ok ? W[i * d + c] : 0.0;
     cc[r] = ok ? C0[i * d + c] : 0.0;
     Fr[r] = vr[r] ? a.F[i] : 0.0;
@@ -152,11 +207,8 @@ __global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __r
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
 
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = 4 * r + g;
-    if (vr[r] && vc) out[d + i * d + c] = cc[r];
-  }
-  if (g == 0 && vc) out[c] = mcol;
+  for (int r = 0; r < 4; ++r) buf_store(rout, bout, offC[r], 0, cc[r]);
+  buf_store(rout, bout, offM, 0, mcol);
   if (lane == 0) {
     if (fq) { fq[0] = __builtin_nan(""); fq[1] = __builtin_nan(""); }
     if (sd) { sd[0] = __builtin_nan(""); sd[1] = __builtin_nan(""); }
@@ -189,7 +241,6 @@ __global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __r
     for (int r = 0; r < 4; ++r) rfr[r] = vRF[4 * r + g];     // (R F)[4r+g]
     const double Q = row_sum(Fc * rfc) + V;
 
-    double* o = out + (size_t)(t + 1) * rec;
     if (yt == yt) {
       const double e = yt - f, rq = 1.0 / Q;
       const double Kc = rfc * rq;
@@ -206,12 +257,10 @@ __global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __r
       if (sd && lane == 0) { sd[2 * (t + 1)] = __builtin_nan(""); sd[2 * (t + 1) + 1] = __builtin_nan(""); }
     }
     if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
+    const int so = (t + 1) * recb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 4 * r + g;
-      if (vr[r] && vc) o[d + i * d + c] = cc[r];
-    }
-    if (g == 0 && vc) o[c] = mcol;
+    for (int r = 0; r < 4; ++r) buf_store(rout, bout, offC[r], so, cc[r]);
+    buf_store(rout, bout, offM, so, mcol);
     wave_sync();   // vM / images are rewritten at the top of the next step
   }
   bool bad = vc && !isfinite(mcol);
@@ -225,10 +274,11 @@ __global__ __launch_bounds__(256) void k_filter_sp16(KArgs a, const SparseT* __r
 // backward pass: MFMA for P C and C (P C); gathers for G^T M G
 // ---------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
+__global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                        const double* __restrict__ side) {
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * 4 + wave;
   if (n >= a.N) return;
   double* imgA = lds + wave * WAVE_LDS;
@@ -244,9 +294,12 @@ __global__ __launch_bounds__(256) void k_smoother_sp16(KArgs a, const SparseT* _
 
   const double V = a.V[(size_t)n * a.v_stride];
   const double rV = 1.0 / V;
-  const double* fin = a.filt_in + (size_t)n * (T + 1) * rec;
-  double* out = a.smooth + (size_t)n * (T + 1) * rec;
+  const char* bin = (const char*)(a.filt_in + (size_t)n * (T + 1) * rec);
+  char* bout = (char*)(a.smooth + (size_t)n * (T + 1) * rec);
+  const __amdgpu_buffer_rsrc_t rin = make_rsrc(bin, (size_t)(T + 1) * rec * 8);
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
   const double* sd = side + (size_t)n * (T + 1) * 2;
+  const int recb = rec * 8;
 
   int idx[K];
   double val[K];
@@ -254,9 +307,17 @@ __global__ __launch_bounds__(256) void k_smoother_sp16(KArgs a, const SparseT* _
   for (int s = 0; s < K; ++s) { idx[s] = sp->idx[c][s]; val[s] = sp->val[c][s]; }
   double Fr[4];
   bool vr[4];
+  int offC[4];
+  const int offM = (g == 0 && vc) ? c * 8 : OOB;     // store of s[c]: one row group only
+  const int offMl = vc ? c * 8 : OOB;                // load of m[c]: every row group
   const double Fc = vc ? a.F[c] : 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { vr[r] = (4 * r + g) < d; Fr[r] = vr[r] ? a.F[4 * r + g] : 0.0; }
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    vr[r] = i < d;
+    Fr[r] = vr[r] ? a.F[i] : 0.0;
+    offC[r] = (vr[r] && vc) ? (d + i * d + c) * 8 : OOB;
+  }
   d4 P = {0.0, 0.0, 0.0, 0.0};
   double qcol = 0.0;
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
@@ -264,24 +325,21 @@ __global__ __launch_bounds__(256) void k_smoother_sp16(KArgs a, const SparseT* _
 
   d4 ncc;
   double nm;
-  {
-    const double* r0 = fin + (size_t)T * rec;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int i = 4 * r + g; ncc[r] = (vr[r] && vc) ? r0[d + i * d + c] : 0.0; }
-    nm = vc ? r0[c] : 0.0;
-  }
+  for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], T * recb);
+  nm = buf_load(rin, bin, offMl, T * recb);
   double neq = sd[2 * T], niq = sd[2 * T + 1];
   vQ[c] = 0.0;
 
   for (int t = T; t >= 0; --t) {
     const d4 cc = ncc;
     const double mcol = nm, eq = neq, iq = niq;
-    if (t > 0) {
-      const double* r0 = fin + (size_t)(t - 1) * rec;
+    {
+      const int tp = t > 0 ? t - 1 : 0;                      // record 0 is re-read harmlessly at the end
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int i = 4 * r + g; ncc[r] = (vr[r] && vc) ? r0[d + i * d + c] : 0.0; }
-      nm = vc ? r0[c] : 0.0;
-      neq = sd[2 * (t - 1)]; niq = sd[2 * (t - 1) + 1];
+      for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], tp * recb);
+      nm = buf_load(rin, bin, offMl, tp * recb);
+      neq = sd[2 * tp]; niq = sd[2 * tp + 1];
     }
     const bool observed = (iq == iq) && t > 0;
 
@@ -294,44 +352,50 @@ __global__ __launch_bounds__(256) void k_smoother_sp16(KArgs a, const SparseT* _
     wave_sync();                                             // also publishes vQ of the last step
     d4 b1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b1[r] = col15 ? vK[4 * r + g] : cc[r];
+    for (int r = 0; r < 4; ++r) { const double kr = vK[4 * r + g]; b1[r] = col15 ? kr : cc[r]; }
     const d4 x1 = mmT(P, b1);                                // [P C | P K]
     d4 b2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b2[r] = col15 ? vQ[4 * r + g] : x1[r];
+    for (int r = 0; r < 4; ++r) { const double qr = vQ[4 * r + g]; b2[r] = col15 ? qr : x1[r]; }
     const d4 x2 = mmT(cc, b2);                               // [C P C | C q]
 
-    // column 15 carries P K (x1) and C q (x2), row-indexed: hand them to every lane
+    // column 15 carries P K (x1) and C q (x2): park both products in the (idle) images and
+    // read column 15 back in whatever indexing each consumer wants -- no masked writes
+#if DLM_IMG_XCHG
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { imgA[(4 * r + g) * LD + c] = x1[r]; imgB[(4 * r + g) * LD + c] = x2[r]; }
+#else
     if (col15) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { vPK[4 * r + g] = x1[r]; vCQ[4 * r + g] = x2[r]; }
+      for (int r = 0; r < 4; ++r) { imgA[(4 * r + g) * LD + 15] = x1[r]; imgB[(4 * r + g) * LD + 15] = x2[r]; }
     }
+#endif
     wave_sync();
-    const double scol = mcol + vCQ[c];                       // s_t = m_t + C_t q_t
-    double* o = out + (size_t)t * rec;
+    const double scol = mcol + imgB[c * LD + 15];            // s_t = m_t + C_t q_t
+    const int so = t * recb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = 4 * r + g;
       const double Sv = cc[r] - x2[r];                       // S_t = C_t - C_t P_t C_t
-      if (vr[r] && vc) o[d + i * d + c] = Sv;
+      buf_store(rout, bout, offC[r], so, Sv);
       if (t == 0) bad |= vr[r] && vc && !isfinite(Sv);
     }
-    if (g == 0 && vc) o[c] = scol;
+    buf_store(rout, bout, offM, so, scol);
     if (t == 0) { bad |= vc && !isfinite(scol); break; }
 
     // (q_{t-1}, P_{t-1}) from (q_t, P_t)
     d4 M = P;
     double rcol = qcol;
     if (observed) {
-      const double pkc = vPK[c];
+      const double pkc = imgA[c * LD + 15];
       const double kq = row_sum(kcol * qcol), kpk = row_sum(kcol * pkc);
       const double sc = iq + kpk;
       rcol = fma(Fc, eq - kq, qcol);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        M[r] = fma(-vPK[4 * r + g], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
+        M[r] = fma(-imgA[(4 * r + g) * LD + 15], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
     }
     vR[c] = rcol;
+    wave_sync();                                             // column-15 reads above precede the image rewrite
     P = congruence<K>(M, imgA, imgB, idx, val, g, c);        // G^T M G (first sync covers vR)
     qcol = vR[idx[0]] * val[0];
 #pragma unroll
