@@ -108,6 +108,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_
 #define DLM_IMG_XCHG 1
 #endif
 __device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, const char* base, int voff, int soff) {
+#ifdef DLM_EXP_NOLOAD
+  soff = 0;  // timing experiment: always re-read record 0 (cache resident)
+#endif
 #if DLM_BUF_LOAD
   const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
   return __hiloint2double((int)v[1], (int)v[0]);
@@ -116,6 +119,10 @@ __device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, const char*
 #endif
 }
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, char* base, int voff, int soff, double x) {
+#ifdef DLM_EXP_NOSTORE
+  asm volatile("" ::"v"(x));  // timing experiment: keep the value live, skip the store
+  return;
+#endif
 #if DLM_BUF_STORE
   const u2 v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
@@ -321,7 +328,6 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
   d4 P = {0.0, 0.0, 0.0, 0.0};
   double qcol = 0.0;
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
-  bool bad = false;
 
   d4 ncc;
   double nm;
@@ -330,10 +336,15 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
   nm = buf_load(rin, bin, offMl, T * recb);
   double neq = sd[2 * T], niq = sd[2 * T + 1];
   vQ[c] = 0.0;
+  d4 Sv = {0.0, 0.0, 0.0, 0.0};
+  double scol = 0.0;
+  const double m15 = col15 ? 1.0 : 0.0;
 
   for (int t = T; t >= 0; --t) {
     const d4 cc = ncc;
-    const double mcol = nm, eq = neq, iq = niq;
+    const double mcol = nm;
+    // the innovations are per-series scalars: keep them in SGPRs so `observed` is a scalar branch
+    const double eq = uniform_from_lane(neq, 0), iq = uniform_from_lane(niq, 0);
     {
       const int tp = t > 0 ? t - 1 : 0;                      // record 0 is re-read harmlessly at the end
 #pragma unroll
@@ -350,58 +361,64 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
     kcol = observed ? sum_g(kcol) * rV : 0.0;
     vK[c] = kcol;
     wave_sync();                                             // also publishes vQ of the last step
+    double kr[4], qr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { kr[r] = vK[4 * r + g]; qr[r] = vQ[4 * r + g]; }
     d4 b1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const double kr = vK[4 * r + g]; b1[r] = col15 ? kr : cc[r]; }
+    for (int r = 0; r < 4; ++r) b1[r] = fma(kr[r], m15, cc[r]);   // column 15 of C is zero
     const d4 x1 = mmT(P, b1);                                // [P C | P K]
     d4 b2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const double qr = vQ[4 * r + g]; b2[r] = col15 ? qr : x1[r]; }
-    const d4 x2 = mmT(cc, b2);                               // [C P C | C q]
+    for (int r = 0; r < 4; ++r) b2[r] = col15 ? qr[r] : x1[r];
+    // [C P C | C q]: only the OUTPUT (s_t, S_t) needs it, so it is consumed at the very end of the
+    // step and its MFMA latency hides behind the recursion work below
+    const d4 x2 = mmT(cc, b2);
 
-    // column 15 carries P K (x1) and C q (x2): park both products in the (idle) images and
-    // read column 15 back in whatever indexing each consumer wants -- no masked writes
-#if DLM_IMG_XCHG
+    if (t > 0) {
+      // (q_{t-1}, P_{t-1}) from (q_t, P_t).  Column 15 of x1 is P K: park x1 in the idle image
+      // and read that column back in both indexings.
+      d4 M = P;
+      double rcol = qcol;
+      if (observed) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { imgA[(4 * r + g) * LD + c] = x1[r]; imgB[(4 * r + g) * LD + c] = x2[r]; }
-#else
-    if (col15) {
+        for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + c] = x1[r];
+        wave_sync();
+        const double pkc = imgA[c * LD + 15];
+        double pkr[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { imgA[(4 * r + g) * LD + 15] = x1[r]; imgB[(4 * r + g) * LD + 15] = x2[r]; }
+        for (int r = 0; r < 4; ++r) pkr[r] = imgA[(4 * r + g) * LD + 15];
+        const double kq = row_sum(kcol * qcol), kpk = row_sum(kcol * pkc);
+        const double sc = iq + kpk;
+        rcol = fma(Fc, eq - kq, qcol);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          M[r] = fma(-pkr[r], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
+      }
+      vR[c] = rcol;
+      wave_sync();                                           // column-15 reads precede the image rewrite
+      P = congruence<K>(M, imgA, imgB, idx, val, g, c);      // G^T M G (its first sync covers vR)
+      qcol = vR[idx[0]] * val[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
+      vQ[c] = qcol;                                          // published by the next wave_sync
+      wave_sync();                                           // pass-2 reads of imgB precede its reuse
     }
-#endif
+
+    // output: s_t = m_t + C_t q_t (column 15 of x2), S_t = C_t - C_t P_t C_t
+#pragma unroll
+    for (int r = 0; r < 4; ++r) imgB[(4 * r + g) * LD + c] = x2[r];
     wave_sync();
-    const double scol = mcol + imgB[c * LD + 15];            // s_t = m_t + C_t q_t
+    scol = mcol + imgB[c * LD + 15];
     const int so = t * recb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double Sv = cc[r] - x2[r];                       // S_t = C_t - C_t P_t C_t
-      buf_store(rout, bout, offC[r], so, Sv);
-      if (t == 0) bad |= vr[r] && vc && !isfinite(Sv);
-    }
+    for (int r = 0; r < 4; ++r) { Sv[r] = cc[r] - x2[r]; buf_store(rout, bout, offC[r], so, Sv[r]); }
     buf_store(rout, bout, offM, so, scol);
-    if (t == 0) { bad |= vc && !isfinite(scol); break; }
-
-    // (q_{t-1}, P_{t-1}) from (q_t, P_t)
-    d4 M = P;
-    double rcol = qcol;
-    if (observed) {
-      const double pkc = imgA[c * LD + 15];
-      const double kq = row_sum(kcol * qcol), kpk = row_sum(kcol * pkc);
-      const double sc = iq + kpk;
-      rcol = fma(Fc, eq - kq, qcol);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        M[r] = fma(-imgA[(4 * r + g) * LD + 15], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
-    }
-    vR[c] = rcol;
-    wave_sync();                                             // column-15 reads above precede the image rewrite
-    P = congruence<K>(M, imgA, imgB, idx, val, g, c);        // G^T M G (first sync covers vR)
-    qcol = vR[idx[0]] * val[0];
-#pragma unroll
-    for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
-    vQ[c] = qcol;                                            // published by the next wave_sync
   }
+  // P and q carry any non-finite value down to record 0: test the last output
+  bool bad = vc && !isfinite(scol);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bad |= vr[r] && vc && !isfinite(Sv[r]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
