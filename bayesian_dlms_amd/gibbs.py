@@ -1,0 +1,168 @@
+"""Gibbs samplers for the DLM variances on top of the batched FFBS engine.
+
+Mirrors GibbsSampling.sample / dinvGammaStep (Gibbs.scala:134-180) and GibbsWishart.sample /
+wishartStep (GibbsWishart.scala:40-80).  Per iteration the engine runs FFBS for every series
+and accumulates the sufficient statistics on the device; only those cross to the host, where
+the conjugate draws (tiny, once per iteration) are made exactly as the reference makes them:
+
+  V_jj ~ InverseGamma(alpha + n_j / 2, beta + ssy_j / 2)          Gibbs.scala:41-48
+  W_ii ~ InverseGamma(alpha + T / 2,   beta + ss_i / 2)           Gibbs.scala:72-77 (shape uses T)
+  W    ~ InverseWishart(nu + T, Psi + sum diff diff^T / dt)       GibbsWishart.scala:31-34
+
+Two modes:
+  per-series (reference semantics for a block-diagonal `|*|` model): every series owns its V, W;
+      series shard across GPUs with no communication at all;
+  pooled: one (V, W) shared by all series; statistics are summed over the shard on the device
+      (dlm_stats_pool) and all-reduced across ranks (RCCL through dlm_gibbs_suffstats_allreduce,
+      or any callable for tests) -- the only collective on the path -- and every rank makes the
+      same draw from the same seed.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Iterator, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .dlm import Dlm, DlmParameters, materialise
+
+
+def shard_bounds(n_series: int, world: int, rank: int):
+    """Contiguous block of series owned by `rank`: [g * ceil(N/G), (g+1) * ceil(N/G))."""
+    per = -(-n_series // world)
+    lo = min(n_series, rank * per)
+    return lo, min(n_series, lo + per)
+
+
+@dataclass
+class InverseGamma:
+    """InverseGamma(shape, scale): draw = 1 / Gamma(shape, 1/scale).draw (InverseGamma.scala:14)."""
+    shape: float
+    scale: float
+
+    def draw(self, rng: np.random.Generator, size=None):
+        return 1.0 / rng.gamma(self.shape, 1.0 / np.asarray(self.scale), size=size)
+
+
+@dataclass
+class InverseWishart:
+    """InverseWishart(nu, psi): draw through the Bartlett factor (InverseWishart.scala:17-25,
+    Wishart.scala:34-43): A lower with sqrt(chi2(nu - i)) on the diagonal, N(0,1) below;
+    L = chol(inv(psi)); draw = inv(L)^T inv(A)^T inv(A) inv(L)."""
+    nu: float
+    psi: np.ndarray
+
+    def draw(self, rng: np.random.Generator):
+        psi = np.asarray(self.psi, dtype=np.float64)
+        d = psi.shape[0]
+        A = np.zeros((d, d))
+        for i in range(d):
+            A[i, i] = np.sqrt(rng.chisquare(self.nu - i))
+            A[i, :i] = rng.standard_normal(i)
+        L = np.linalg.cholesky(np.linalg.inv(psi))
+        invl, inva = np.linalg.inv(L), np.linalg.inv(A)
+        return invl.T @ inva.T @ inva @ invl
+
+
+def split_stats(stats: np.ndarray, d: int, p: int, outer: bool):
+    """[.., L] statistics -> (ssy [.., p], n [.., p], ss [.., d] or outer [.., d, d], T [..])."""
+    ssy, n = stats[..., :p], stats[..., p:2 * p]
+    if outer:
+        body = stats[..., 2 * p:2 * p + d * d].reshape(stats.shape[:-1] + (d, d))
+    else:
+        body = stats[..., 2 * p:2 * p + d]
+    return ssy, n, body, stats[..., -1]
+
+
+def draw_v(prior: InverseGamma, ssy, n, rng) -> np.ndarray:
+    """sampleObservationMatrix (Gibbs.scala:23-50): diagonal V from the residual statistics."""
+    return 1.0 / rng.gamma(prior.shape + 0.5 * np.asarray(n), 1.0 / (prior.scale + 0.5 * np.asarray(ssy)))
+
+
+def draw_w_diag(prior: InverseGamma, ss, t_count, rng) -> np.ndarray:
+    """sampleSystemMatrix (Gibbs.scala:56-78): diagonal W; shape uses the number of transitions."""
+    ss = np.asarray(ss)
+    shape = prior.shape + 0.5 * np.asarray(t_count)[..., None] if np.ndim(t_count) else prior.shape + 0.5 * t_count
+    return 1.0 / rng.gamma(shape, 1.0 / (prior.scale + 0.5 * ss))
+
+
+@dataclass
+class GibbsState:
+    """GibbsSampling.State (Gibbs.scala:8-11), batched: parameters (shared or per series) and,
+    optionally, the last state draw theta [N][T+1][d]."""
+    p: object
+    theta: Optional[np.ndarray]
+    stats: np.ndarray
+
+
+def _params_list(p, N):
+    return [p] * N if isinstance(p, DlmParameters) else list(p)
+
+
+class GibbsSampling:
+    @staticmethod
+    def sample(mod: Dlm, prior_v: InverseGamma, prior_w: InverseGamma, init_params, times, y, engine,
+               *, n_iter: int, seed: int = 0, pooled: bool = False, series_offset: int = 0,
+               allreduce: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+               keep_theta: bool = False, ffbs: Optional[Callable] = None) -> Iterator[GibbsState]:
+        """d-Inverse-Gamma Gibbs (GibbsSampling.sample).  `y` is this rank's shard [N][T][p];
+        `series_offset` its first global series index (keeps the Philox streams identical to a
+        single-GPU run).  Yields one GibbsState per iteration."""
+        return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
+                      series_offset, allreduce, keep_theta, ffbs, wishart=False)
+
+
+class GibbsWishart:
+    @staticmethod
+    def sample(mod: Dlm, prior_v: InverseGamma, prior_w: InverseWishart, init_params, times, y, engine,
+               *, n_iter: int, seed: int = 0, pooled: bool = False, series_offset: int = 0,
+               allreduce=None, keep_theta: bool = False, ffbs=None) -> Iterator[GibbsState]:
+        """Inverse-Wishart Gibbs for W (GibbsWishart.sample; order theta, W, V as wishartStep)."""
+        return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
+                      series_offset, allreduce, keep_theta, ffbs, wishart=True)
+
+
+def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled, series_offset,
+           allreduce, keep_theta, ffbs, wishart):
+    y = np.asarray(y, dtype=np.float64)
+    N = y.shape[0]
+    mat = materialise(mod, times)
+    d, p = mat.d, mat.p
+    flags = _lib.OPT_STATS_OUTER if wishart else 0
+    run = ffbs if ffbs is not None else engine.ffbs
+    params = init_params
+    rng = np.random.default_rng(seed)            # identical on every rank (pooled draws agree)
+    for it in range(n_iter):
+        out = run(mat, params, y, seed=seed * 1000003 + it, series_offset=series_offset, flags=flags,
+                  want_theta=keep_theta, want_stats=True)
+        stats = np.asarray(out["stats"])
+        if pooled:
+            tot = stats.sum(axis=0) if engine is None else np.asarray(engine.stats_pool(stats))
+            if allreduce is not None:
+                tot = allreduce(tot)
+            ssy, n, body, tcount = split_stats(tot, d, p, wishart)
+            base = _params_list(params, 1)[0]
+            if wishart:
+                w = InverseWishart(prior_w.nu + tcount, np.asarray(prior_w.psi) + body).draw(rng)
+            else:
+                w = np.diag(draw_w_diag(prior_w, body, tcount, rng))
+            v = np.diag(draw_v(prior_v, ssy, n, rng))
+            params = DlmParameters(v, w, base.m0, base.c0)
+        else:
+            # independent V, W per series; the draws of series n use a generator keyed by its
+            # GLOBAL index so that sharding does not change them
+            ssy, n, body, tcount = split_stats(stats, d, p, wishart)
+            old = _params_list(params, N)
+            new = []
+            for k in range(N):
+                r = np.random.default_rng([seed, it, series_offset + k])
+                if wishart:
+                    w = InverseWishart(prior_w.nu + tcount[k], np.asarray(prior_w.psi) + body[k]).draw(r)
+                    v = np.diag(draw_v(prior_v, ssy[k], n[k], r))
+                else:
+                    v = np.diag(draw_v(prior_v, ssy[k], n[k], r))
+                    w = np.diag(draw_w_diag(prior_w, body[k], tcount[k], r))
+                new.append(DlmParameters(v, w, old[k].m0, old[k].c0))
+            params = new
+        yield GibbsState(params, np.asarray(out["theta"]) if keep_theta else None, stats)

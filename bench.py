@@ -31,6 +31,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
+def measured_traffic(kernel, N, T):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_hbm_traffic.json: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), valid
+    for the default workload only; None otherwise (PMC counters cannot be read from in here)."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if not os.path.exists(path) or (N, T) != (10000, 1000):
+        return None
+    k = json.load(open(path))["kernels"].get(kernel)
+    return None if k is None else k["hbm_bytes_per_launch"]
+
+
 def seasonal_c2():
     from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
     mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
@@ -150,6 +161,7 @@ def main():
         dom_is_bwd = b_ms >= f_ms
         dom_bytes, dom_ms = (bwd_bytes, b_ms) if dom_is_bwd else (fwd_bytes, f_ms)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        kname = ("k_smoother_" if dom_is_bwd else "k_filter_") + {"sparse16": "sp16", "mfma16": "mfma16"}.get(eng.last_variant, eng.last_variant)
         line = {
             "metric": "Kalman filter+smooth series*timesteps/sec", "value": value,
             "unit": "series*timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -159,9 +171,9 @@ def main():
                                    f"{N} series/GPU x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
                        "series_per_gpu": N, "T": T, "d": d, "p": 1, "variant": eng.last_variant,
                        "parallelism": f"series-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": ("k_smoother_" if dom_is_bwd else "k_filter_") + {"sparse16": "sp16", "mfma16": "mfma16"}.get(eng.last_variant, eng.last_variant),
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kname, N, T),
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                          "forward_ms": f_ms, "backward_ms": b_ms,
                          "path_GBps": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9},
