@@ -1,7 +1,439 @@
-// placeholder until the Jacobi SVD path lands
+// SVD (square-root) Kalman filter and backward sampler: d <= 16, p <= 16.
+//
+// Restates SvdFilter.scala:38-95, :183-236 and SvdSampler.scala:15-60, :94-102 with the two
+// LAPACK dgesdd calls per filter step (one per sampler step) replaced by a per-wavefront
+// one-sided (Hestenes) Jacobi SVD held entirely in LDS: the stacked matrix ((2d) x d or
+// (p+d) x d) and the accumulated right vectors live in the wave's LDS slice, the n/2 disjoint
+// column pairs of a round-robin round are rotated concurrently by 8-lane groups, and the three
+// inner products of a pair are reduced with wave shuffles.  One wavefront per series.
+//
+// Only U D^2 U^T and the means are defined by the algorithm (singular-vector order and sign are
+// LAPACK-defined in the reference); the filter records therefore hold the factors in Jacobi
+// order.  The sampler, whose draw h + U diag(d) z does depend on order and sign, canonicalises
+// its factor: singular values descending, largest-|component| of each column of the FINAL
+// factor positive -- the same convention as oracle/dlm_oracle.c.
+//
+// Quirk switches: DLM_OPT_SVD_RAW_W_Q2 (time update receives the raw W, SvdFilter.scala:158-161)
+// and DLM_OPT_SVD_SAMPLER_Q9 (backward step uses sqrt(W) where sqrt(W)^-1 is needed,
+// SvdSampler.scala:71-73).  Defaults are the mathematically consistent forms.
 #include "dlm_internal.h"
+#include "../../include/dlm_engine.h"
+
 namespace dlm {
-size_t svd_filter_lds_bytes(int, int) { return 0; }
-hipError_t launch_svd_filter(const KArgs&, double*, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_svd_sampler(const KArgs&, const double*, hipStream_t) { return hipErrorNotSupported; }
+
+constexpr int SL = 17;   // leading dimension of the d x d LDS matrices
+constexpr int STL = 33;  // leading dimension of the stacked matrix (<= 32 rows)
+#define M17(buf, i, j) (buf)[(i) + (j) * SL]
+#define STK(i, j) stack[(i) + (j) * STL]
+
+__device__ __forceinline__ void ssync() { __syncthreads(); }  // block == one wavefront
+
+// One-sided Jacobi SVD of the m x n (m <= 32, n <= 16) LDS matrix A (leading dim lda).
+// On return the columns of A are U * Sigma, V (n x n, ld SL) holds the right singular vectors,
+// sig[j] = ||A[:, j]||.  Returns 1 if not converged after 40 sweeps.
+__device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V, double* sig) {
+  for (int k = lane; k < n * n; k += 64) M17(V, k % n, k / n) = (k % n == k / n) ? 1.0 : 0.0;
+  const int np = (n + 1) & ~1, half = np >> 1;
+  const int grp = lane >> 3, sub = lane & 7;
+  bool conv = (n < 2);
+  for (int sweep = 0; sweep < 40 && !conv; ++sweep) {
+    bool rot_any = false;
+    for (int r = 0; r < np - 1; ++r) {
+      ssync();
+      int ca, cb;
+      if (grp == 0) { ca = np - 1; cb = r; }
+      else { ca = (r + grp) % (np - 1); cb = (r + np - 1 - grp) % (np - 1); }
+      const bool act = grp < half && ca < n && cb < n;
+      const int p = ca < cb ? ca : cb, q = ca < cb ? cb : ca;
+      double al = 0.0, be = 0.0, ga = 0.0;
+      if (act)
+        for (int i = sub; i < m; i += 8) {
+          const double x = A[i + p * lda], y = A[i + q * lda];
+          al = fma(x, x, al); be = fma(y, y, be); ga = fma(x, y, ga);
+        }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { al += __shfl_xor(al, o); be += __shfl_xor(be, o); ga += __shfl_xor(ga, o); }
+      // columns count as orthogonal once |a.b| <= 1e-14 |a||b| (fp64 dot products of <= 32 terms)
+      const bool rot = act && ga != 0.0 && fabs(ga) > 1e-14 * sqrt(al * be);
+      if (rot) {
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+        for (int i = sub; i < m; i += 8) {
+          const double x = A[i + p * lda], y = A[i + q * lda];
+          A[i + p * lda] = c * x - s * y; A[i + q * lda] = s * x + c * y;
+        }
+        for (int i = sub; i < n; i += 8) {
+          const double x = M17(V, i, p), y = M17(V, i, q);
+          M17(V, i, p) = c * x - s * y; M17(V, i, q) = s * x + c * y;
+        }
+      }
+      rot_any |= rot;
+    }
+    conv = (__ballot(rot_any) == 0ull);
+  }
+  ssync();
+  if (lane < n) {
+    double s = 0.0;
+    for (int i = 0; i < m; ++i) s = fma(A[i + lane * lda], A[i + lane * lda], s);
+    sig[lane] = sqrt(s);
+  }
+  ssync();
+  return conv ? 0 : 1;
 }
+
+// sqrtSvd / sqrtInvSvd (SvdFilter.scala:210-227): out = diag(sig^{+-1/2}) V^T for the SPD n x n Mx.
+__device__ int sqrt_svd(int lane, int n, const double* Mx /* global, col-major n x n */, bool inverse,
+                        double* out, double* stack, double* Vacc, double* sig) {
+  for (int k = lane; k < n * n; k += 64) STK(k % n, k / n) = Mx[k];
+  ssync();
+  const int rc = jacobi_svd(lane, n, n, stack, STL, Vacc, sig);
+  for (int k = lane; k < n * n; k += 64) {
+    const int i = k % n, j = k / n;
+    const double s = inverse ? 1.0 / sqrt(sig[i]) : sqrt(sig[i]);
+    M17(out, i, j) = s * M17(Vacc, j, i);
+  }
+  ssync();
+  return rc;
+}
+
+// LDS carve shared by both kernels
+struct SvdLds {
+  double *m, *a, *dc, *dr, *sig, *e, *yv, *tv, *uc, *ur, *V, *Wadv, *tmp, *stack, *sVinv, *gs, *sWb;
+  int* idx;
+};
+__device__ __forceinline__ SvdLds carve(double* sm) {
+  SvdLds L;
+  L.m = sm; L.a = L.m + 16; L.dc = L.a + 16; L.dr = L.dc + 16; L.sig = L.dr + 16; L.e = L.sig + 16;
+  L.yv = L.e + 16; L.tv = L.yv + 16;
+  L.uc = L.tv + 16; L.ur = L.uc + 16 * SL; L.V = L.ur + 16 * SL; L.Wadv = L.V + 16 * SL;
+  L.tmp = L.Wadv + 16 * SL; L.sVinv = L.tmp + 16 * SL; L.gs = L.sVinv + 16 * SL; L.sWb = L.gs + 16 * SL;
+  L.stack = L.sWb + 16 * SL;
+  L.idx = (int*)(L.stack + 16 * STL);
+  return L;
+}
+size_t svd_filter_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 16 * SL + 16 * STL) + sizeof(int) * 16 + 16; }
+
+// ---------------------------------------------------------------------------------------
+// SVD filter.  Record t: [m_t (d) | dc_t (d) | uc_t (d x d, column-major)].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__ rec_out) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = 2 * d + dd;
+  SvdLds L = carve(sm);
+  double* stack = L.stack;
+  const double* V = a.V + (size_t)n * a.v_stride;
+  const double* W = a.W + (size_t)n * a.w_stride;
+  const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+  const double* C0 = a.C0 + (size_t)n * a.c0_stride;
+  const double* y = a.y + (size_t)n * T * p;
+  double* out = rec_out + (size_t)n * (T + 1) * srec;
+  int st = 0;
+
+  // transformParams (SvdFilter.scala:232-236)
+  if (a.flags & DLM_OPT_SVD_RAW_W_Q2) {
+    for (int k = lane; k < dd; k += 64) M17(L.Wadv, k % d, k / d) = W[k];
+    ssync();
+  } else if (sqrt_svd(lane, d, W, false, L.Wadv, stack, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (sqrt_svd(lane, p, V, true, L.sVinv, stack, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  // initialiseState (SvdFilter.scala:83-95): svd(C0) -> dc0 = sqrt(sigma), uc0 = V
+  for (int k = lane; k < dd; k += 64) STK(k % d, k / d) = C0[k];
+  ssync();
+  if (jacobi_svd(lane, d, d, stack, STL, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  for (int i = lane; i < d; i += 64) { L.m[i] = m0[i]; L.dc[i] = sqrt(L.sig[i]); out[i] = m0[i]; out[d + i] = sqrt(L.sig[i]); }
+  for (int k = lane; k < dd; k += 64) { M17(L.uc, k % d, k / d) = M17(L.V, k % d, k / d); out[2 * d + k] = M17(L.V, k % d, k / d); }
+  ssync();
+
+  for (int t = 0; t < T; ++t) {
+    const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
+    const double* Ft = a.F + (size_t)t * a.f_stride;
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    // advState (SvdFilter.scala:183-202)
+    if (dt == 0.0) {
+      for (int i = lane; i < d; i += 64) { L.a[i] = L.m[i]; L.dr[i] = L.dc[i]; }
+      for (int k = lane; k < dd; k += 64) M17(L.ur, k % d, k / d) = M17(L.uc, k % d, k / d);
+      ssync();
+    } else {
+      const double sdt = sqrt(dt);
+      for (int i = lane; i < d; i += 64) {
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s = fma(Gt[i + k * d], L.m[k], s);
+        L.a[i] = s;
+      }
+      for (int k = lane; k < dd; k += 64) {   // stack = [diag(dc) uc^T G^T ; Wadv sqrt(dt)]
+        const int i = k % d, j = k / d;
+        double s = 0.0;
+        for (int l = 0; l < d; ++l) s = fma(M17(L.uc, l, i), Gt[j + l * d], s);
+        STK(i, j) = L.dc[i] * s;
+        STK(d + i, j) = M17(L.Wadv, i, j) * sdt;
+      }
+      ssync();
+      if (jacobi_svd(lane, 2 * d, d, stack, STL, L.ur, L.dr)) st |= DLM_ST_NOCONV;   // dr = sigma, ur = V
+    }
+    // updateState (SvdFilter.scala:38-68)
+    const double yl = (lane < p) ? y[(size_t)t * p + lane] : __builtin_nan("");
+    const unsigned long long mask = __ballot(yl == yl);
+    const int pm = __popcll(mask);
+    if (yl == yl) { const int pos = __popcll(mask & ((1ull << lane) - 1ull)); L.idx[pos] = lane; L.yv[pos] = yl; }
+    ssync();
+    if (pm == 0) {
+      for (int i = lane; i < d; i += 64) { L.m[i] = L.a[i]; L.dc[i] = L.dr[i]; }
+      for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = M17(L.ur, k % d, k / d);
+    } else {
+      // e = y - fm^T a ; tmp(pm x d) = vm fm^T   (vm = sqrtVinv[idx, idx], fm = F[:, idx])
+      for (int j = lane; j < pm; j += 64) {
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s = fma(Ft[k + L.idx[j] * d], L.a[k], s);
+        L.e[j] = L.yv[j] - s;
+      }
+      for (int k = lane; k < pm * d; k += 64) {
+        const int i = k % pm, j = k / pm;
+        double s = 0.0;
+        for (int l = 0; l < pm; ++l) s = fma(M17(L.sVinv, L.idx[i], L.idx[l]), Ft[j + L.idx[l] * d], s);
+        M17(L.tmp, i, j) = s;
+      }
+      ssync();
+      // stack ((pm + d) x d) = [vm fm^T ur ; diag(1/dr)]
+      for (int k = lane; k < pm * d; k += 64) {
+        const int i = k % pm, j = k / pm;
+        double s = 0.0;
+        for (int l = 0; l < d; ++l) s = fma(M17(L.tmp, i, l), M17(L.ur, l, j), s);
+        STK(i, j) = s;
+      }
+      for (int k = lane; k < dd; k += 64) { const int i = k % d, j = k / d; STK(pm + i, j) = (i == j) ? 1.0 / L.dr[i] : 0.0; }
+      ssync();
+      if (jacobi_svd(lane, pm + d, d, stack, STL, L.V, L.sig)) st |= DLM_ST_NOCONV;
+      // uc = ur V ; dc = 1 / sigma
+      for (int k = lane; k < dd; k += 64) {
+        const int i = k % d, j = k / d;
+        double s = 0.0;
+        for (int l = 0; l < d; ++l) s = fma(M17(L.ur, i, l), M17(L.V, l, j), s);
+        M17(L.uc, i, j) = s;
+      }
+      for (int i = lane; i < d; i += 64) L.dc[i] = 1.0 / L.sig[i];
+      // tv (pm) = vm^T vm e ; gs (d) = fm tv ; gain e = uc dc^2 uc^T gs
+      for (int j = lane; j < pm; j += 64) {
+        double s = 0.0;
+        for (int l = 0; l < pm; ++l) {
+          double vv = 0.0;   // (vm^T vm)[j][l]
+          for (int r = 0; r < pm; ++r) vv = fma(M17(L.sVinv, L.idx[r], L.idx[j]), M17(L.sVinv, L.idx[r], L.idx[l]), vv);
+          s = fma(vv, L.e[l], s);
+        }
+        L.tv[j] = s;
+      }
+      ssync();
+      for (int i = lane; i < d; i += 64) {
+        double s = 0.0;
+        for (int j = 0; j < pm; ++j) s = fma(Ft[i + L.idx[j] * d], L.tv[j], s);
+        L.gs[i] = s;
+      }
+      ssync();
+      for (int i = lane; i < d; i += 64) {     // yv <- dc^2 * (uc^T gs)
+        double s = 0.0;
+        for (int l = 0; l < d; ++l) s = fma(M17(L.uc, l, i), L.gs[l], s);
+        L.yv[i] = L.dc[i] * L.dc[i] * s;
+      }
+      ssync();
+      for (int i = lane; i < d; i += 64) {
+        double s = L.a[i];
+        for (int l = 0; l < d; ++l) s = fma(M17(L.uc, i, l), L.yv[l], s);
+        L.m[i] = s;
+      }
+    }
+    ssync();
+    double* o = out + (size_t)(t + 1) * srec;
+    for (int i = lane; i < d; i += 64) { o[i] = L.m[i]; o[d + i] = L.dc[i]; }
+    for (int k = lane; k < dd; k += 64) o[2 * d + k] = M17(L.uc, k % d, k / d);
+  }
+  bool bad = false;
+  for (int i = lane; i < d; i += 64) bad |= !isfinite(L.m[i]) || !isfinite(L.dc[i]);
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+// canonical factor: columns of U (d x d, LDS ld SL) and entries of s reordered so that the
+// ordering key is descending, then each column's largest-|.| entry made positive.
+__device__ void canon_factor(int lane, int d, double* U, double* s, const double* key, double* Utmp, double* stmp) {
+  if (lane < d) {
+    int rank = 0;
+    for (int k = 0; k < d; ++k) rank += (key[k] > key[lane]) || (key[k] == key[lane] && k < lane);
+    stmp[rank] = s[lane];
+    // sign: first index attaining the maximum |.| (with the oracle's 1e-12 relative tie margin)
+    int arg = 0; double best = -1.0;
+    for (int i = 0; i < d; ++i) { const double v = fabs(M17(U, i, lane)); if (v > best * (1.0 + 1e-12)) { best = v; arg = i; } }
+    const double sg = M17(U, arg, lane) < 0.0 ? -1.0 : 1.0;
+    for (int i = 0; i < d; ++i) M17(Utmp, i, rank) = sg * M17(U, i, lane);
+  }
+  ssync();
+  for (int k = lane; k < d * d; k += 64) M17(U, k % d, k / d) = M17(Utmp, k % d, k / d);
+  if (lane < d) s[lane] = stmp[lane];
+  ssync();
+}
+
+// ---------------------------------------------------------------------------------------
+// SVD backward sampler + Gibbs statistics (SvdSampler.scala:15-60)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __restrict__ rec_in) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = 2 * d + dd;
+  SvdLds L = carve(sm);
+  double* stack = L.stack;
+  double* th = L.e;      // theta_{t+1}
+  double* zv = L.yv;     // normals
+  double* ssv = L.dr;    // per-state sum of squares (diag statistics)
+  double* outer = L.ur;  // outer-product statistics
+  double* ssy = L.gs; double* nob = L.gs + 16;
+  const double* W = a.W + (size_t)n * a.w_stride;
+  const double* rin = rec_in + (size_t)n * (T + 1) * srec;
+  const double* y = a.y ? a.y + (size_t)n * T * p : nullptr;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * d : nullptr;
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  const bool want_outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  int st = 0;
+
+  // ps.w of SvdSampler.ffbs: sqrtSvd(W) literally (Q9), sqrtInvSvd(W) for the consistent form
+  if (sqrt_svd(lane, d, W, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  for (int i = lane; i < d; i += 64) ssv[i] = 0.0;
+  for (int k = lane; k < dd; k += 64) M17(outer, k % d, k / d) = 0.0;
+  for (int i = lane; i < 32; i += 64) ssy[i] = 0.0;
+  ssync();
+
+  // initialise (SvdSampler.scala:38-45): theta_T = m_T + uc_T diag(dc_T) z, canonical factor order
+  {
+    const double* r = rin + (size_t)T * srec;
+    for (int i = lane; i < d; i += 64) {
+      L.m[i] = r[i]; L.dc[i] = r[d + i]; L.sig[i] = 1.0 / r[d + i];   // key: sigma = 1/dc, descending
+      zv[i] = zin ? zin[(size_t)T * d + i] : philox_normal(a.seed, series, (unsigned)T, (unsigned)i);
+    }
+    for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = r[2 * d + k];
+    ssync();
+    canon_factor(lane, d, L.uc, L.dc, L.sig, L.tmp, L.tv);
+    for (int i = lane; i < d; i += 64) {
+      double s = L.m[i];
+      for (int k = 0; k < d; ++k) s = fma(M17(L.uc, i, k) * L.dc[k], zv[k], s);
+      th[i] = s;
+      if (thout) thout[(size_t)T * d + i] = s;
+    }
+    ssync();
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
+    const double* Ft = a.F + (size_t)t * a.f_stride;
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    const double* r = rin + (size_t)t * srec;
+    if (a.stats && y) {   // observation residuals of theta_{t+1} (Gibbs.scala:29-39)
+      for (int j = lane; j < p; j += 64) {
+        const double yj = y[(size_t)t * p + j];
+        if (yj == yj) {
+          double f = 0.0;
+          for (int k = 0; k < d; ++k) f = fma(Ft[k + j * d], th[k], f);
+          ssy[j] += (yj - f) * (yj - f); nob[j] += 1.0;
+        }
+      }
+    }
+    for (int i = lane; i < d; i += 64) {
+      L.m[i] = r[i]; L.dc[i] = r[d + i];
+      zv[i] = zin ? zin[(size_t)t * d + i] : philox_normal(a.seed, series, (unsigned)t, (unsigned)i);
+    }
+    for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = r[2 * d + k];
+    ssync();
+    // a_{t+1} = G m_t ; tmp = sqrtWb G
+    for (int i = lane; i < d; i += 64) {
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) s = fma(Gt[i + k * d], L.m[k], s);
+      L.a[i] = s;
+    }
+    for (int k = lane; k < dd; k += 64) {
+      const int i = k % d, j = k / d;
+      double s = 0.0;
+      for (int l = 0; l < d; ++l) s = fma(M17(L.sWb, i, l), Gt[l + j * d], s);
+      M17(L.tmp, i, j) = s;
+    }
+    ssync();
+    // stack (2d x d) = [sqrtWb G uc ; diag(1/dc)]
+    for (int k = lane; k < dd; k += 64) {
+      const int i = k % d, j = k / d;
+      double s = 0.0;
+      for (int l = 0; l < d; ++l) s = fma(M17(L.tmp, i, l), M17(L.uc, l, j), s);
+      STK(i, j) = s;
+      STK(d + i, j) = (i == j) ? 1.0 / L.dc[i] : 0.0;
+    }
+    ssync();
+    if (jacobi_svd(lane, 2 * d, d, stack, STL, L.V, L.sig)) st |= DLM_ST_NOCONV;
+    // uh = uc V -> Wadv buffer ; dh = 1/sigma -> tv
+    for (int k = lane; k < dd; k += 64) {
+      const int i = k % d, j = k / d;
+      double s = 0.0;
+      for (int l = 0; l < d; ++l) s = fma(M17(L.uc, i, l), M17(L.V, l, j), s);
+      M17(L.Wadv, i, j) = s;
+    }
+    for (int i = lane; i < d; i += 64) L.tv[i] = 1.0 / L.sig[i];
+    ssync();
+    canon_factor(lane, d, L.Wadv, L.tv, L.sig, L.V, L.dc);   // V, dc are free scratch now
+    double* uh = L.Wadv; double* dh = L.tv;
+    // h = m + uh dh^2 uh^T G^T sqrtWb^T sqrtWb (theta_{t+1} - a_{t+1})
+    double* u = L.sig;   // d-vectors: reuse sig, dc as scratch
+    double* v1 = L.dc;
+    for (int i = lane; i < d; i += 64) u[i] = th[i] - L.a[i];
+    ssync();
+    for (int i = lane; i < d; i += 64) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(M17(L.sWb, i, k), u[k], s); v1[i] = s; }
+    ssync();
+    for (int i = lane; i < d; i += 64) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(M17(L.sWb, k, i), v1[k], s); u[i] = s; }
+    ssync();
+    for (int i = lane; i < d; i += 64) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Gt[k + i * d], u[k], s); v1[i] = s; }
+    ssync();
+    for (int i = lane; i < d; i += 64) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(M17(uh, k, i), v1[k], s); u[i] = dh[i] * dh[i] * s; }
+    ssync();
+    for (int i = lane; i < d; i += 64) {
+      double h = L.m[i];
+      for (int k = 0; k < d; ++k) h = fma(M17(uh, i, k), u[k], h);
+      double s = h;
+      for (int k = 0; k < d; ++k) s = fma(M17(uh, i, k) * dh[k], zv[k], s);
+      v1[i] = s;   // theta_t
+    }
+    ssync();
+    if (a.stats) {
+      for (int i = lane; i < d; i += 64) {
+        double s = th[i];
+        for (int k = 0; k < d; ++k) s = fma(-Gt[i + k * d], v1[k], s);
+        u[i] = s;   // theta_{t+1} - G theta_t
+      }
+      ssync();
+      const double dts = (dt == 0.0) ? 1.0 : dt;
+      if (want_outer) for (int k = lane; k < dd; k += 64) M17(outer, k % d, k / d) += u[k % d] * u[k / d] / dts;
+      for (int i = lane; i < d; i += 64) ssv[i] += u[i] * u[i] / dts;
+    }
+    ssync();
+    for (int i = lane; i < d; i += 64) { th[i] = v1[i]; if (thout) thout[(size_t)t * d + i] = v1[i]; }
+    ssync();
+  }
+  bool bad = false;
+  for (int i = lane; i < d; i += 64) bad |= !isfinite(th[i]);
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.stats) {
+    const int Ls = stats_len(d, p, a.flags);
+    double* so = a.stats + (size_t)n * Ls;
+    for (int j = lane; j < p; j += 64) { so[j] = ssy[j]; so[p + j] = nob[j]; }
+    if (want_outer) for (int k = lane; k < dd; k += 64) so[2 * p + k] = M17(outer, k % d, k / d);
+    else for (int i = lane; i < d; i += 64) so[2 * p + i] = ssv[i];
+    if (lane == 0) so[Ls - 1] = (double)T;
+  }
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s) {
+  if (a.d > 16 || a.p > 16) return hipErrorNotSupported;
+  hipLaunchKernelGGL(k_svd_filter, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec);
+  return hipGetLastError();
+}
+
+hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s) {
+  if (a.d > 16 || a.p > 16) return hipErrorNotSupported;
+  hipLaunchKernelGGL(k_svd_sampler, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec);
+  return hipGetLastError();
+}
+
+}  // namespace dlm

@@ -654,6 +654,9 @@ void oracle_svd_filter(int d, int p, int T, const double *F, long f_stride, cons
 /* SVD backward sampler: SvdSampler.scala:15-60, rnorm :94-102.          */
 /* Inputs: SVD filter records (m, dc, uc, a); sqrtW = sqrtSvd(W).         */
 /* Draw = h + uh diag(dh) z.  h_out optional.                             */
+/* Canonical factor (LAPACK leaves order and sign open): singular values  */
+/* descending, and the largest-|component| of each column of the FINAL    */
+/* factor (uc_T for the first draw, uh afterwards) positive.              */
 /* Quirk Q9: the reference hands sqrt(W) (ps.w, SvdSampler.scala:71-73)    */
 /* to a step whose algebra needs sqrt(W)^-1 (information form             */
 /* H = (C^-1 + G^T W^-1 G)^-1); with W = I, as in the reference's test,     */
@@ -675,7 +678,10 @@ void oracle_svd_backward_sample(int d, int T, const double *G, const int *g_inde
   double *v1 = malloc(sizeof(double) * d), *v2 = malloc(sizeof(double) * d);
   /* initialise: SvdSampler.scala:38-45 -> rnorm(m_T, dc_T, uc_T) */
   {
-    const double *mT = m + (size_t)T * d, *dT = dc + (size_t)T * d, *uT = uc + (size_t)T * dd;
+    const double *mT = m + (size_t)T * d, *dT = dc + (size_t)T * d;
+    double *uT = t1;
+    memcpy(uT, uc + (size_t)T * dd, sizeof(double) * dd);
+    canon_cols(d, d, uT, d);
     for (int i = 0; i < d; ++i) {
       double s = mT[i];
       for (int k = 0; k < d; ++k) s += uT[IDX(i, k, d)] * dT[k] * z[(size_t)T * d + k];
@@ -699,6 +705,7 @@ void oracle_svd_backward_sample(int d, int T, const double *G, const int *g_inde
       }
     svd_right(2 * d, d, stack, sig, Vt);
     mm(d, d, d, uct, d, 0, Vt, d, 1, uh, d);
+    canon_cols(d, d, uh, d);
     for (int i = 0; i < d; ++i) dh[i] = 1.0 / sig[i];
     /* h = m + (du^T du) g^T sqrtW^T sqrtW (theta1 - a1), du = diag(dh) uh^T */
     for (int i = 0; i < d; ++i) u[i] = thn[i] - a1[i];

@@ -330,3 +330,91 @@ def test_device_pointer_mode_matches_host_mode(eng):
     dev = eng.filter_smooth(mat, p, torch.as_tensor(y, device="cuda:0"))
     np.testing.assert_array_equal(dev["filt"].cpu().numpy(), host["filt"])
     np.testing.assert_array_equal(dev["smooth"].cpu().numpy(), host["smooth"])
+
+
+# ------------------------------------------------------------------------------------------
+# SVD (square-root) filter and sampler: config C5
+# ------------------------------------------------------------------------------------------
+def _svd_cov(rec, d):
+    """[T+1, 2d+d*d] SVD records -> (m [T+1, d], C [T+1, d, d]) with C = uc diag(dc^2) uc^T"""
+    m, dc = rec[:, :d], rec[:, d:2 * d]
+    uc = rec[:, 2 * d:].reshape(-1, d, d).transpose(0, 2, 1)
+    return m, np.einsum("tij,tj,tkj->tik", uc, dc ** 2, uc)
+
+
+def test_svd_filter_reference_fixture(eng, golden_dir):
+    """core/src/test/scala/SvdFilter.scala:102-158: SVD filter == Kalman filter on the bivariate fixture."""
+    g = json.load(open(os.path.join(golden_dir, "kalman_filter_test.json")))
+    mod = Dlm.polynomial(1) * Dlm.polynomial(1)
+    p = DlmParameters(np.diag(g["v"]), np.diag(g["w"]), np.array(g["m0"]), np.diag(g["c0"]))
+    y = np.array([[np.nan if v is None else v for v in row] for row in g["obs"]]).reshape(1, 6, 2)
+    mat = materialise(mod, g["times"])
+    kf = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[0])
+    for flags in (0, _lib.OPT_SVD_RAW_W_Q2):     # W = I: Q2 is invisible, exactly as in the reference test
+        out = eng.svd_filter(mat, p, y, flags=flags)
+        assert int(out["status"][0]) == 0
+        m, C = _svd_cov(out["svd"][0], 2)
+        np.testing.assert_allclose(m, kf["m"], atol=1e-9)
+        for t in range(7):
+            np.testing.assert_allclose(C[t], oracle.from_cm(kf["C"][t], 2, 2), atol=1e-9)
+
+
+@pytest.mark.parametrize("literal_q2", [False, True])
+def test_svd_filter_d13_vs_oracle(eng, literal_q2):
+    mod, mat, p = seasonal_model(T=60)
+    y = simulate(mat, p, 3, seed=21, missing=0.1)
+    out = eng.svd_filter(mat, p, y, flags=_lib.OPT_SVD_RAW_W_Q2 if literal_q2 else 0)
+    assert eng.last_variant == "svd-jacobi" and np.all(out["status"] == 0)
+    om = omodel(mat)
+    for n in range(3):
+        o = oracle.svd_filter(om, p.v, p.w, p.m0, p.c0, y[n], raw_w_q2=literal_q2)
+        m, C = _svd_cov(out["svd"][n], 13)
+        om_, oC = _svd_cov(np.concatenate([o["m"], o["dc"], o["uc"]], axis=1), 13)
+        # tolerance 1e-7: two Jacobi SVDs per step, factors compared through U D^2 U^T
+        np.testing.assert_allclose(m, om_, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(C, oC, rtol=1e-7, atol=1e-8)
+    if not literal_q2:  # the consistent form is the Kalman filter (stability check vs. the standard filter)
+        kf = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y[0])
+        m, C = _svd_cov(out["svd"][0], 13)
+        np.testing.assert_allclose(m, kf["m"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(C.transpose(0, 2, 1).reshape(61, 169), kf["C"], rtol=1e-6, atol=1e-7)
+
+
+def test_svd_filter_ill_conditioned_stays_psd(eng):
+    """Stability check: tiny observation noise and a wide prior; U D^2 U^T is PSD by construction."""
+    mod = Dlm.polynomial(3)
+    mat = materialise(mod, np.arange(1, 201, dtype=np.float64))
+    p = DlmParameters([[1e-10]], np.diag([1e-8, 1e-8, 1e-8]), np.zeros(3), np.eye(3) * 1e8)
+    y = simulate(mat, DlmParameters([[1e-2]], np.diag([1e-4] * 3), np.zeros(3), np.eye(3)), 4, seed=2)
+    out = eng.svd_filter(mat, p, y)
+    for n in range(4):
+        m, C = _svd_cov(out["svd"][n], 3)
+        assert np.all(np.isfinite(C))
+        assert min(np.linalg.eigvalsh((c + c.T) / 2).min() for c in C) >= -1e-18
+
+
+@pytest.mark.parametrize("literal", [False, True])
+def test_svd_ffbs_draws_and_stats(eng, literal):
+    mod, mat, p = seasonal_model(T=40)
+    # C0 = I makes the record-0 factor fully degenerate (any orthogonal basis is an SVD), which
+    # leaves the draw theta_0 = h + U D z undefined; use distinct prior variances instead
+    p = DlmParameters(p.v, p.w, p.m0, np.diag(np.linspace(0.5, 2.0, 13)))
+    N = 2
+    y = simulate(mat, p, N, seed=31, missing=0.1)
+    flags = (_lib.OPT_SVD_RAW_W_Q2 | _lib.OPT_SVD_SAMPLER_Q9) if literal else 0
+    out = eng.svd_ffbs(mat, p, y, seed=77, series_offset=3, flags=flags)
+    assert np.all(out["status"] == 0)
+    om = omodel(mat)
+    for n in range(N):
+        sf = oracle.svd_filter(om, p.v, p.w, p.m0, p.c0, y[n], raw_w_q2=literal)
+        z = oracle.normals(77, 3 + n, 41, 13)
+        o = oracle.svd_backward_sample(om, p.w, sf, z, literal_q9=literal)
+        np.testing.assert_allclose(out["theta"][n], o["theta"], rtol=1e-6, atol=1e-7)
+        st = oracle.gibbs_stats(om, y[n], o["theta"])
+        np.testing.assert_allclose(out["stats"][n, 0], st["ssy"][0], rtol=1e-6)
+        np.testing.assert_allclose(out["stats"][n, 2:15], st["ss"], rtol=1e-6)
+    if not literal:  # zero noise => the SVD sampler reproduces the RTS mean
+        z0 = np.zeros((N, 41, 13))
+        o0 = eng.svd_ffbs(mat, p, y, z=z0)
+        f, s = oracle_filter_smooth(mat, p, y[0])
+        np.testing.assert_allclose(o0["theta"][0], s["s"], rtol=1e-6, atol=1e-7)
