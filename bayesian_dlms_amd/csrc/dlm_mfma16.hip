@@ -132,12 +132,13 @@ __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restri
     double* o = out + (size_t)(t + 1) * rec;
     if (yt == yt) {
       // updateState, Joseph form expanded for p = 1
+      // Joseph form for p = 1, factored: R - (RF_i/Q) RF_j (2 - Q (1/Q))
       const double e = yt - f, rq = 1.0 / Q;
-      const double Kc = rfc * rq;
+      const double gam = rfc * (2.0 - Q * rq);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double Kr = rfr[r] * rq;
-        cc[r] = fma(Q * Kr, Kc, fma(-rfr[r], Kc, fma(-Kr, rfc, R[r])));
+        cc[r] = fma(-Kr, gam, R[r]);
         mrow[r] = fma(Kr, e, rp[r]);                  // meaningful in column-15 lanes
       }
       if (sd && lane == 0) { sd[2 * (t + 1)] = e * rq; sd[2 * (t + 1) + 1] = rq; }

@@ -131,6 +131,21 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, char* base, 
 #endif
 }
 
+// Diagnostic build only (-DDLM_STAMP): s_memtime stamps around the phases of the backward step;
+// the sums of series 0 are written into status[1..] (never in the shipped build).
+#ifdef DLM_STAMP
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define STAMP(k) { const unsigned long long _t = stamp(); seg[k] += _t - tlast; tlast = _t; }
+#else
+#define STAMP(k)
+#endif
+
 // Z = T X T^T for symmetric X (std layout), T given by the per-column-lane tables idx/val.
 template <int K>
 __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB, const int (&idx)[K],
@@ -249,13 +264,13 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_filter_sp16(KArgs a, cons
     const double Q = row_sum(Fc * rfc) + V;
 
     if (yt == yt) {
+      // Joseph form for p = 1 with K = RF / Q:  R - K RF^T - RF K^T + Q K K^T
+      //   = R - (RF_i / Q) * RF_j * (2 - Q * (1/Q))   -- the same expression, factored
       const double e = yt - f, rq = 1.0 / Q;
       const double Kc = rfc * rq;
+      const double gam = rfc * (2.0 - Q * rq);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double Kr = rfr[r] * rq;
-        cc[r] = fma(Q * Kr, Kc, fma(-rfr[r], Kc, fma(-Kr, rfc, R[r])));
-      }
+      for (int r = 0; r < 4; ++r) cc[r] = fma(-(rfr[r] * rq), gam, R[r]);
       mcol = fma(Kc, e, acol);
       if (sd && lane == 0) { sd[2 * (t + 1)] = e * rq; sd[2 * (t + 1) + 1] = rq; }
     } else {
@@ -340,7 +355,11 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
   double scol = 0.0;
   const double m15 = col15 ? 1.0 : 0.0;
 
+#ifdef DLM_STAMP
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp();
+#endif
   for (int t = T; t >= 0; --t) {
+    STAMP(7)
     const d4 cc = ncc;
     const double mcol = nm;
     // the innovations are per-series scalars: keep them in SGPRs so `observed` is a scalar branch
@@ -367,13 +386,19 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
     d4 b1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) b1[r] = fma(kr[r], m15, cc[r]);   // column 15 of C is zero
+    STAMP(0)
     const d4 x1 = mmT(P, b1);                                // [P C | P K]
     d4 b2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) b2[r] = col15 ? qr[r] : x1[r];
     // [C P C | C q]: only the OUTPUT (s_t, S_t) needs it, so it is consumed at the very end of the
     // step and its MFMA latency hides behind the recursion work below
+#ifdef DLM_STAMP
+    asm volatile("" ::"v"(b2[0]), "v"(b2[1]), "v"(b2[2]), "v"(b2[3]));
+#endif
+    STAMP(1)
     const d4 x2 = mmT(cc, b2);
+    STAMP(2)
 
     if (t > 0) {
       // (q_{t-1}, P_{t-1}) from (q_t, P_t).  Column 15 of x1 is P K: park x1 in the idle image
@@ -397,12 +422,20 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       }
       vR[c] = rcol;
       wave_sync();                                           // column-15 reads precede the image rewrite
+#ifdef DLM_STAMP
+      asm volatile("" ::"v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]));
+#endif
+      STAMP(3)
       P = congruence<K>(M, imgA, imgB, idx, val, g, c);      // G^T M G (its first sync covers vR)
       qcol = vR[idx[0]] * val[0];
 #pragma unroll
       for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
       vQ[c] = qcol;                                          // published by the next wave_sync
       wave_sync();                                           // pass-2 reads of imgB precede its reuse
+#ifdef DLM_STAMP
+      asm volatile("" ::"v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]));
+#endif
+      STAMP(4)
     }
 
     // output: s_t = m_t + C_t q_t (column 15 of x2), S_t = C_t - C_t P_t C_t
@@ -414,7 +447,12 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
 #pragma unroll
     for (int r = 0; r < 4; ++r) { Sv[r] = cc[r] - x2[r]; buf_store(rout, bout, offC[r], so, Sv[r]); }
     buf_store(rout, bout, offM, so, scol);
+    STAMP(5)
   }
+#ifdef DLM_STAMP
+  if (n == 0 && lane == 0 && a.status)
+    for (int k = 0; k < 8; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)(T + 1));
+#endif
   // P and q carry any non-finite value down to record 0: test the last output
   bool bad = vc && !isfinite(scol);
 #pragma unroll

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline): FFBS/Gibbs (C3), d=40 multivariate (C4), SVD filter (C5).
+Prints one JSON object per config.  Usage: python tools/secondary_bench.py [c3] [c4] [c5]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import seasonal_c2, simulate
+from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
+from bayesian_dlms_amd.engine import Engine
+
+def timeit(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+def main():
+    which = sys.argv[1:] or ["c3", "c4", "c5"]
+    eng = Engine(0); dev = torch.device("cuda", 0)
+    if "c3" in which:
+        mod, p = seasonal_c2(); N, T = 10000, 1000
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        y = torch.as_tensor(simulate(mat, p, N, seed=1), device=dev)
+        dt = timeit(lambda: eng.ffbs(mat, p, y, seed=3, want_theta=False, want_stats=True))
+        print(json.dumps({"config": "C3 FFBS + suff-stats, d=13, N=10000, T=1000", "variant": eng.last_variant,
+                          "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "c4" in which:
+        mod = Dlm.polynomial(2)
+        for _ in range(19): mod = mod * Dlm.polynomial(2)
+        N, T = 2000, 1000
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        rng = np.random.default_rng(40); A = rng.standard_normal((40, 40))
+        p = DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
+        y = torch.as_tensor(rng.standard_normal((N, T, 20)).cumsum(axis=1), device=dev)
+        dt = timeit(lambda: eng.filter_smooth(mat, p, y), reps=1)
+        print(json.dumps({"config": "C4 filter+smooth, d=40, p=20, N=2000, T=1000", "variant": eng.last_variant,
+                          "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "c5" in which:
+        mod, p = seasonal_c2(); N, T = 10000, 200
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        y = torch.as_tensor(simulate(mat, p, N, seed=1), device=dev)
+        dt = timeit(lambda: eng.svd_filter(mat, p, y), reps=1)
+        print(json.dumps({"config": "C5 SVD filter, d=13, N=10000, T=200", "variant": eng.last_variant,
+                          "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+
+if __name__ == "__main__":
+    main()
