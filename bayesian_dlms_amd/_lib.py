@@ -14,6 +14,7 @@ OPT_SVD_SAMPLER_Q9 = 1 << 2
 OPT_FORCE_GENERIC = 1 << 3
 OPT_STATS_OUTER = 1 << 4
 OPT_ASYNC = 1 << 5
+OPT_FFBS_SIMSMOOTH = 1 << 6
 ST_NONFINITE, ST_NOT_PD, ST_NOCONV = 1, 2, 4
 COMM_ID_BYTES = 128
 

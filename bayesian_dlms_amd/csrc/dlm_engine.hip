@@ -26,6 +26,8 @@ struct dlm_engine {
   int sparse_k = 0;           // 0: G is not structured (dense MFMA path)
   double* side = nullptr;     // forward->backward innovations buffer of the fused fast path
   size_t side_bytes = 0;
+  double* xplus = nullptr;    // simulated states x+ of the simulation smoother [N][T+1][d]
+  size_t xplus_bytes = 0;
   ncclComm_t comm = nullptr;
   bool has_comm = false;
 };
@@ -165,6 +167,16 @@ int ensure_side(dlm_engine* e, const KArgs& k) {
   return DLM_OK;
 }
 
+int ensure_xplus(dlm_engine* e, const KArgs& k) {
+  const size_t need = sizeof(double) * (size_t)k.N * ((size_t)k.T + 1) * (size_t)k.d;
+  if (need > e->xplus_bytes) {
+    if (e->xplus) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->xplus, need));
+    e->xplus_bytes = need;
+  }
+  return DLM_OK;
+}
+
 // want_side: the caller will run the fast backward pass on this filter's output
 int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
   if (use_fast(k) && !k.prior) {
@@ -172,7 +184,7 @@ int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
     double* side = want_side ? e->side : nullptr;
     if (e->sparse_k) {
       e->variant = "sparse16";
-      HIP_TRY(e, dlm::launch_sparse16_filter(k, e->sparse_k, e->sp_dev, side, e->stream));
+      HIP_TRY(e, dlm::launch_sparse16_filter(k, e->sparse_k, e->sp_dev, side, nullptr, e->stream));
     } else {
       e->variant = "mfma16";
       HIP_TRY(e, dlm::launch_mfma16_filter(k, side, e->stream));
@@ -232,6 +244,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->has_comm) ncclCommDestroy(e->comm);
   if (e->arena) (void)hipFree(e->arena);
   if (e->side) (void)hipFree(e->side);
+  if (e->xplus) (void)hipFree(e->xplus);
   if (e->sp_dev) (void)hipFree(e->sp_dev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -346,8 +359,9 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
+  const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
   st.in(&k.y, y, y ? N * T * p : 0);
-  st.in(&k.z, z, z ? N * (T + 1) * d : 0);
+  st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + 1 : d) : 0);
   if (forward) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
   else st.in(&k.filt_in, filt_in, N * (T + 1) * rec);
   st.out(&k.theta, theta, N * (T + 1) * d);
@@ -357,6 +371,16 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if ((rc = st.commit())) return rc;
   if (forward) {
     if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
+    if (simflag && e->sparse_k) {
+      // Durbin-Koopman simulation smoother on the structured fast path
+      if ((rc = ensure_side(e, k)) || (rc = ensure_xplus(e, k))) return rc;
+      e->variant = "sparse16-simsmooth";
+      HIP_TRY(e, dlm::launch_sparse16_filter(k, e->sparse_k, e->sp_dev, e->side, e->xplus, e->stream));
+      k.filt_in = k.filt;
+      HIP_TRY(e, dlm::launch_sparse16_simsmooth(k, e->sparse_k, e->sp_dev, e->side, e->xplus, e->stream));
+      return st.finish(opts->flags & DLM_OPT_ASYNC);
+    }
+    if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need the structured fast path");
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }

@@ -51,7 +51,10 @@ hipError_t launch_mfma16_smoother(const KArgs& a, const double* side, hipStream_
 // ---- structured-G variant of the fast path (<= 4 nonzeros per row/column), dlm_sparse16.hip
 struct SparseT { int K; int pad; int idx[16][4]; double val[16][4]; };
 int sparse16_analyse(const double* G_host, int d, SparseT* rows, SparseT* cols);
-hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev, double* side, hipStream_t s);
+// xplus != nullptr: simulation-smoother forward pass (also writes x+ [N][T+1][d])
+hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev, double* side, double* xplus, hipStream_t s);
+// tabs_dev[0] = rows of G, tabs_dev[1] = columns of G
+hipError_t launch_sparse16_simsmooth(const KArgs& a, int K, const SparseT* tabs_dev, const double* side, const double* xplus, hipStream_t s);
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s);
 
 // ---- SVD filter / sampler (one-sided Jacobi in LDS), dlm_svd.hip ----------------------

@@ -26,7 +26,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 constexpr int LD = 17;                        // leading dimension of an LDS image
 constexpr int IMG = 16 * LD;                  // doubles per image
-constexpr int WAVE_LDS = 2 * IMG + 5 * 16;    // two images + five 16-vectors per wave
+constexpr int WAVE_LDS = 2 * IMG + 8 * 16;    // two images + eight 16-vectors per wave
 
 #ifndef DLM_SM_WAVES
 #define DLM_SM_WAVES 4
@@ -178,10 +178,35 @@ __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB
 // ---------------------------------------------------------------------------------------
 // forward pass (no MFMA at all: O(K d^2) per step)
 // ---------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256, DLM_FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
-                                                     double* __restrict__ side) {
-  __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
+// Wave-cooperative lower Cholesky of the symmetric d x d matrix held row-major in an LDS image
+// (img[i * LD + j]); one-off per series (simulation smoother set-up), so simplicity over speed.
+__device__ void wave_chol(double* img, int d, int g, int c) {
+  for (int k = 0; k < d; ++k) {
+    wave_sync();
+    double akk = img[k * LD + k];
+    akk = akk > 0.0 ? akk : 1e-300;
+    const double lkk = sqrt(akk), inv = 1.0 / lkk;
+    wave_sync();
+    if (g == 0 && c >= k && c < d) img[c * LD + k] = (c == k) ? lkk : img[c * LD + k] * inv;
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * r + g;
+      if (i > k && c > k && c <= i && i < d) img[i * LD + c] = fma(-img[i * LD + k], img[c * LD + k], img[i * LD + c]);
+    }
+  }
+  wave_sync();
+}
+
+// SIM = true turns the forward pass into the first half of the Durbin-Koopman (2002) simulation
+// smoother: it also simulates (x+, y+) from the model, filters y* = y - y+ from a zero prior mean
+// and writes x+ to `xplus` [N][T+1][d].  Normal (record t, component i) of series n is
+// philox_normal(seed, series_offset + n, t, i), i = 0..d-1 for the state noise (the initial state at
+// record 0), i = d for the observation noise; injected normals are z[N][T+1][d+1].
+template <int K, bool SIM>
+__global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
+                                                     double* __restrict__ side, double* __restrict__ xplus) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS + (SIM ? 4 * IMG : 0)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * 4 + wave;
@@ -190,6 +215,9 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_filter_sp16(KArgs a, cons
   double* imgB = imgA + IMG;
   double* vM = imgB + IMG;       // m, column-indexed
   double* vRF = vM + 16;         // R F
+  double* vX = vRF + 16;         // x+ (SIM)
+  double* vZ = vX + 16;          // 64 normals = 4 records x 16 components (SIM)
+  double* imgW = lds + 4 * WAVE_LDS + wave * IMG;   // chol(W), row-major (SIM, dense W only)
   const int d = a.d, T = a.T, rec = d + d * d;
   const int g = lane >> 4, c = lane & 15;
   const bool vc = c < d;
@@ -228,6 +256,37 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_filter_sp16(KArgs a, cons
   }
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
 
+  // ---- simulation-smoother set-up: factors of C0 and W, x+_0, zero prior mean -------------
+  double xcol = 0.0, wsd = 0.0;
+  bool wdiag = true;
+  const double sqV = sqrt(V);
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  const double* zin = (SIM && a.z) ? a.z + (size_t)n * (T + 1) * (d + 1) : nullptr;
+  double* xp = SIM ? xplus + (size_t)n * (T + 1) * d : nullptr;
+  if (SIM) {
+    bool offd = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) offd |= (4 * r + g != c) && (w[r] != 0.0 || cc[r] != 0.0);
+    wdiag = (__ballot(offd) == 0ull);                       // W and C0 both diagonal: no factorisation
+    const double z0 = (c < d) ? (zin ? zin[c] : philox_normal(a.seed, series, 0u, (unsigned)c)) : 0.0;
+    if (wdiag) {
+      wsd = vc ? sqrt(W[c * d + c]) : 0.0;
+      xcol = vc ? fma(sqrt(C0[c * d + c]), z0, m0[c]) : 0.0;
+    } else {
+      vZ[c] = z0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { imgW[(4 * r + g) * LD + c] = w[r]; imgB[(4 * r + g) * LD + c] = cc[r]; }
+      wave_chol(imgW, d, g, c);
+      wave_chol(imgB, d, g, c);
+      double x0 = vc ? m0[c] : 0.0;
+      for (int k = 0; k <= c && k < d; ++k) x0 = fma(imgB[c * LD + k], vZ[k], x0);
+      xcol = vc ? x0 : 0.0;
+      wave_sync();
+    }
+    mcol = 0.0;                                             // y* is filtered from a zero prior mean
+    if (g == 0 && vc) xp[c] = xcol;
+  }
+
 #pragma unroll
   for (int r = 0; r < 4; ++r) buf_store(rout, bout, offC[r], 0, cc[r]);
   buf_store(rout, bout, offM, 0, mcol);
@@ -239,14 +298,37 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_filter_sp16(KArgs a, cons
   double ychunk = 0.0;
   for (int t = 0; t < T; ++t) {
     if ((t & 63) == 0) ychunk = (t + lane < T) ? y[t + lane] : 0.0;
-    const double yt = uniform_from_lane(ychunk, t & 63);
+    double yt = uniform_from_lane(ychunk, t & 63);
 
     // advState: a = G m, R = G C G^T + W
     vM[c] = mcol;
-    d4 R = congruence<K>(cc, imgA, imgB, idx, val, g, c);   // first wave_sync also covers vM
+    if (SIM) {
+      vX[c] = xcol;
+      if ((t & 3) == 0) {   // 64 normals: records t+1 .. t+4, components 0..15 (0..d used)
+        const int tr = t + 1 + g;
+        double zz = 0.0;
+        if (c <= d && tr <= T) zz = zin ? zin[(size_t)tr * (d + 1) + c] : philox_normal(a.seed, series, (unsigned)tr, (unsigned)c);
+        vZ[lane] = zz;
+      }
+    }
+    d4 R = congruence<K>(cc, imgA, imgB, idx, val, g, c);   // first wave_sync also covers vM, vX, vZ
     double acol = vM[idx[0]] * val[0];
 #pragma unroll
     for (int s = 1; s < K; ++s) acol = fma(vM[idx[s]], val[s], acol);
+    if (SIM) {
+      // x+_t = G x+_{t-1} + L_W z ;  y+_t = F^T x+_t + sqrt(V) z_v ;  y*_t = y_t - y+_t
+      double xg = vX[idx[0]] * val[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) xg = fma(vX[idx[s]], val[s], xg);
+      const double* zr = vZ + 16 * (t & 3);
+      double wl;
+      if (wdiag) wl = wsd * zr[c];
+      else { wl = 0.0; for (int k = 0; k <= c && k < d; ++k) wl = fma(imgW[c * LD + k], zr[k], wl); }
+      xcol = vc ? xg + wl : 0.0;
+      const double yplus = fma(sqV, zr[d], row_sum(Fc * xcol));
+      yt = yt - yplus;                                       // NaN (missing) stays NaN
+      if (g == 0 && vc) xp[(size_t)(t + 1) * d + c] = xcol;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) R[r] += w[r];
 
@@ -462,6 +544,144 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
 }
 
 // ---------------------------------------------------------------------------------------
+// second half of the simulation smoother: mean-only backward pass on y*, theta = s* + x+,
+// Gibbs sufficient statistics (Gibbs.scala:23-78, GibbsWishart.scala:16-35) on the fly.
+//   s*_t = m*_t + C_t q_t ,  q_{t-1} = G^T [ q_t + F (e_t/Q_t - K_t^T q_t) ] ,  K_t = C_t F / V
+// No covariance recursion and no MFMA: O(K d + d^2) work per step.
+// ---------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256, DLM_FI_WAVES) void k_simsmooth_sp16(KArgs a, const SparseT* __restrict__ sp,
+                                                        const double* __restrict__ side,
+                                                        const double* __restrict__ xplus) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= a.N) return;
+  double* vQ = lds + wave * 64;   // q_t
+  double* vR = vQ + 16;           // r
+  double* vT = vR + 16;           // theta_t
+  double* vD = vT + 16;           // theta_{t+1} - G theta_t
+  const int d = a.d, T = a.T, rec = d + d * d, recb = rec * 8;
+  const int g = lane >> 4, c = lane & 15;
+  const bool vc = c < d;
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
+
+  const double V = a.V[(size_t)n * a.v_stride];
+  const double rV = 1.0 / V;
+  const char* bin = (const char*)(a.filt_in + (size_t)n * (T + 1) * rec);
+  const __amdgpu_buffer_rsrc_t rin = make_rsrc(bin, (size_t)(T + 1) * rec * 8);
+  const double* sd = side + (size_t)n * (T + 1) * 2;
+  const double* xp = xplus + (size_t)n * (T + 1) * d;
+  const double* y = a.y ? a.y + (size_t)n * T : nullptr;
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+
+  // rows of G (for G theta) and columns of G (for G^T r)
+  int ridx[K], cidx[K];
+  double rval[K], cval[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { ridx[s] = sp[0].idx[c][s]; rval[s] = sp[0].val[c][s]; cidx[s] = sp[1].idx[c][s]; cval[s] = sp[1].val[c][s]; }
+  double Fr[4];
+  int offC[4];
+  const int offMl = vc ? c * 8 : OOB;
+  const double Fc = vc ? a.F[c] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    Fr[r] = i < d ? a.F[i] : 0.0;
+    offC[r] = (i < d && vc) ? (d + i * d + c) * 8 : OOB;
+  }
+  double qcol = 0.0, thn = 0.0, ssy = 0.0, nob = 0.0, ssc = 0.0;
+  d4 so = {0.0, 0.0, 0.0, 0.0};
+  int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+
+  d4 ncc;
+  double nm, nx;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], T * recb);
+  nm = buf_load(rin, bin, offMl, T * recb);
+  nx = vc ? xp[(size_t)T * d + c] : 0.0;
+  double neq = sd[2 * T], niq = sd[2 * T + 1];
+  double ychunk = 0.0;
+
+  for (int t = T; t >= 0; --t) {
+    const d4 cc = ncc;
+    const double mcol = nm, xcol = nx;
+    const double eq = uniform_from_lane(neq, 0), iq = uniform_from_lane(niq, 0);
+    {
+      const int tp = t > 0 ? t - 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], tp * recb);
+      nm = buf_load(rin, bin, offMl, tp * recb);
+      nx = vc ? xp[(size_t)tp * d + c] : 0.0;
+      neq = sd[2 * tp]; niq = sd[2 * tp + 1];
+    }
+    const bool observed = (iq == iq) && t > 0;
+
+    // theta_t = m*_t + C_t q_t + x+_t
+    vQ[c] = qcol;
+    wave_sync();
+    double cq = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cq = fma(cc[r], vQ[4 * r + g], cq);   // C symmetric: column sums
+    const double th = mcol + sum_g(cq) + xcol;
+    if (thout && g == 0 && vc) thout[(size_t)t * d + c] = th;
+
+    if (a.stats) {
+      vT[c] = th;
+      wave_sync();
+      if (t < T) {   // system innovation theta_{t+1} - G theta_t (dt = 1 on the fast path)
+        double gth = vT[ridx[0]] * rval[0];
+#pragma unroll
+        for (int s = 1; s < K; ++s) gth = fma(vT[ridx[s]], rval[s], gth);
+        const double df = vc ? thn - gth : 0.0;
+        ssc = fma(df, df, ssc);
+        if (outer) {
+          vD[c] = df;
+          wave_sync();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) so[r] = fma(vD[4 * r + g], df, so[r]);
+        }
+      }
+      if (t > 0 && y) {   // observation residual of theta_t against y_t
+        const int ti = t - 1;
+        if (t == T || (ti & 63) == 63) ychunk = ((ti & ~63) + lane < T) ? y[(ti & ~63) + lane] : 0.0;
+        const double yv = uniform_from_lane(ychunk, ti & 63);
+        if (yv == yv) { const double res = yv - row_sum(Fc * th); ssy = fma(res, res, ssy); nob += 1.0; }
+      }
+    }
+    thn = th;
+    if (t == 0) break;
+
+    double rcol = qcol;
+    if (observed) {
+      double kc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kc = fma(cc[r], Fr[r], kc);
+      kc = sum_g(kc) * rV;
+      rcol = fma(Fc, eq - row_sum(kc * qcol), qcol);
+    }
+    vR[c] = rcol;
+    wave_sync();
+    qcol = vR[cidx[0]] * cval[0];
+#pragma unroll
+    for (int s = 1; s < K; ++s) qcol = fma(vR[cidx[s]], cval[s], qcol);
+    wave_sync();
+  }
+  if (__ballot(vc && !isfinite(thn)) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.stats) {
+    const int L = stats_len(d, 1, a.flags);
+    double* sout = a.stats + (size_t)n * L;
+    if (lane == 0) { sout[0] = ssy; sout[1] = nob; sout[L - 1] = (double)T; }
+    if (outer) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int i = 4 * r + g; if (i < d && vc) sout[2 + i + c * d] = so[r]; }
+    } else if (g == 0 && vc) sout[2 + c] = ssc;
+  }
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+// ---------------------------------------------------------------------------------------
 // host side: structure detection and launch
 // ---------------------------------------------------------------------------------------
 // Nonzeros of the rows of G (`rows`, forward pass) and of the columns of G (`cols`, backward
@@ -489,8 +709,14 @@ int sparse16_analyse(const double* G /* d x d column-major, host */, int d, Spar
 }
 
 template <int K>
-static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, hipStream_t s) {
-  hipLaunchKernelGGL(k_filter_sp16<K>, dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
+static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, double* xplus, hipStream_t s) {
+  if (xplus) hipLaunchKernelGGL((k_filter_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  else hipLaunchKernelGGL((k_filter_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* side, const double* xplus, hipStream_t s) {
+  hipLaunchKernelGGL(k_simsmooth_sp16<K>, dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
   return hipGetLastError();
 }
 template <int K>
@@ -499,12 +725,24 @@ static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side
   return hipGetLastError();
 }
 
-hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev, double* side, hipStream_t s) {
+hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev, double* side, double* xplus,
+                                  hipStream_t s) {
   switch (K) {
-    case 1: return launch_f<1>(a, rows_dev, side, s);
-    case 2: return launch_f<2>(a, rows_dev, side, s);
-    case 3: return launch_f<3>(a, rows_dev, side, s);
-    case 4: return launch_f<4>(a, rows_dev, side, s);
+    case 1: return launch_f<1>(a, rows_dev, side, xplus, s);
+    case 2: return launch_f<2>(a, rows_dev, side, xplus, s);
+    case 3: return launch_f<3>(a, rows_dev, side, xplus, s);
+    case 4: return launch_f<4>(a, rows_dev, side, xplus, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_sparse16_simsmooth(const KArgs& a, int K, const SparseT* tabs_dev, const double* side,
+                                     const double* xplus, hipStream_t s) {
+  switch (K) {
+    case 1: return launch_ss<1>(a, tabs_dev, side, xplus, s);
+    case 2: return launch_ss<2>(a, tabs_dev, side, xplus, s);
+    case 3: return launch_ss<3>(a, tabs_dev, side, xplus, s);
+    case 4: return launch_ss<4>(a, tabs_dev, side, xplus, s);
   }
   return hipErrorInvalidValue;
 }

@@ -186,7 +186,7 @@ class Engine:
         md, pd, op, keep = self.prepare(mat, params, N, be, flags, seed, series_offset)
         theta = be.empty((N, T + 1, d)) if want_theta else None
         cond = be.empty((N, T + 1, rec)) if want_cond else None
-        L = self.lib.dlm_stats_len(d, p, flags)
+        L = self.lib.dlm_stats_len(d, p, flags & ~_lib.OPT_FFBS_SIMSMOOTH)
         stats = be.empty((N, L)) if want_stats else None
         status = be.empty((N,), np.int32)
         if filt is None:

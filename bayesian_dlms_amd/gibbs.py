@@ -105,31 +105,33 @@ class GibbsSampling:
     def sample(mod: Dlm, prior_v: InverseGamma, prior_w: InverseGamma, init_params, times, y, engine,
                *, n_iter: int, seed: int = 0, pooled: bool = False, series_offset: int = 0,
                allreduce: Optional[Callable[[np.ndarray], np.ndarray]] = None,
-               keep_theta: bool = False, ffbs: Optional[Callable] = None) -> Iterator[GibbsState]:
+               keep_theta: bool = False, ffbs: Optional[Callable] = None,
+               simulation_smoother: bool = False) -> Iterator[GibbsState]:
         """d-Inverse-Gamma Gibbs (GibbsSampling.sample).  `y` is this rank's shard [N][T][p];
         `series_offset` its first global series index (keeps the Philox streams identical to a
         single-GPU run).  Yields one GibbsState per iteration."""
         return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
-                      series_offset, allreduce, keep_theta, ffbs, wishart=False)
+                      series_offset, allreduce, keep_theta, ffbs, wishart=False, simsmooth=simulation_smoother)
 
 
 class GibbsWishart:
     @staticmethod
     def sample(mod: Dlm, prior_v: InverseGamma, prior_w: InverseWishart, init_params, times, y, engine,
                *, n_iter: int, seed: int = 0, pooled: bool = False, series_offset: int = 0,
-               allreduce=None, keep_theta: bool = False, ffbs=None) -> Iterator[GibbsState]:
+               allreduce=None, keep_theta: bool = False, ffbs=None,
+               simulation_smoother: bool = False) -> Iterator[GibbsState]:
         """Inverse-Wishart Gibbs for W (GibbsWishart.sample; order theta, W, V as wishartStep)."""
         return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
-                      series_offset, allreduce, keep_theta, ffbs, wishart=True)
+                      series_offset, allreduce, keep_theta, ffbs, wishart=True, simsmooth=simulation_smoother)
 
 
 def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled, series_offset,
-           allreduce, keep_theta, ffbs, wishart):
+           allreduce, keep_theta, ffbs, wishart, simsmooth=False):
     y = np.asarray(y, dtype=np.float64)
     N = y.shape[0]
     mat = materialise(mod, times)
     d, p = mat.d, mat.p
-    flags = _lib.OPT_STATS_OUTER if wishart else 0
+    flags = (_lib.OPT_STATS_OUTER if wishart else 0) | (_lib.OPT_FFBS_SIMSMOOTH if simsmooth else 0)
     run = ffbs if ffbs is not None else engine.ffbs
     params = init_params
     rng = np.random.default_rng(seed)            # identical on every rank (pooled draws agree)

@@ -50,7 +50,8 @@ enum {
   DLM_OPT_SVD_SAMPLER_Q9 = 1u << 2,     /* literal SvdSampler.step: sqrt(W) for sqrt(W)^-1  */
   DLM_OPT_FORCE_GENERIC = 1u << 3,      /* disable the specialised (MFMA) kernels           */
   DLM_OPT_STATS_OUTER = 1u << 4,        /* Gibbs stats: full outer product (GibbsWishart)   */
-  DLM_OPT_ASYNC = 1u << 5               /* do not synchronise the stream before returning   */
+  DLM_OPT_ASYNC = 1u << 5,              /* do not synchronise the stream before returning   */
+  DLM_OPT_FFBS_SIMSMOOTH = 1u << 6      /* draw with the Durbin-Koopman simulation smoother */
 };
 
 /* per-series status bits */
@@ -142,6 +143,11 @@ int dlm_last_timing(dlm_engine *e, double ms[2]);
  *   stats   [N][L]           L = dlm_stats_len(d, p, flags):
  *                            [ssy(p) | n(p) | ss(d) | T]            (d-Inverse-Gamma)
  *                            [ssy(p) | n(p) | outer(d*d) | T]       (DLM_OPT_STATS_OUTER)
+ * DLM_OPT_FFBS_SIMSMOOTH: draw theta = E[x | y - y+] + x+ with (x+, y+) simulated from the model
+ * (Durbin & Koopman 2002): the same distribution as FFBS without a d x d factorisation per step
+ * (fast path: d <= 15, p = 1, structured G, regular grid; otherwise the flag is ignored).  Normals:
+ * d + 1 per record (state noise, then observation noise), so injected z is [N][T+1][d+1]; `cond` is
+ * not produced.
  * The draw uses the lower Cholesky factor of H_t (theta = h + L z); the reference's eigSym
  * factor has LAPACK-defined signs and an unseedable RNG, so draw-level parity with Breeze is
  * not defined -- see DESIGN.md. */

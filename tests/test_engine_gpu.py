@@ -418,3 +418,71 @@ def test_svd_ffbs_draws_and_stats(eng, literal):
         o0 = eng.svd_ffbs(mat, p, y, z=z0)
         f, s = oracle_filter_smooth(mat, p, y[0])
         np.testing.assert_allclose(o0["theta"][0], s["s"], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------
+# FFBS by the Durbin-Koopman simulation smoother (DLM_OPT_FFBS_SIMSMOOTH)
+# ------------------------------------------------------------------------------------------
+def dk_reference_draw(mat, p, y, z):
+    """theta = E[x | y - y+] + x+ with (x+, y+) simulated from z [T+1][d+1]; smoothing by the oracle."""
+    d, T = mat.d, mat.T
+    G = oracle.from_cm(mat.G[: d * d], d, d); F = mat.F[:d]
+    Lc, Lw = np.linalg.cholesky(p.c0), np.linalg.cholesky(p.w)
+    x = p.m0 + Lc @ z[0, :d]
+    xs, yp = [x], np.empty((T, 1))
+    for t in range(1, T + 1):
+        x = G @ x + Lw @ z[t, :d]
+        xs.append(x)
+        yp[t - 1, 0] = F @ x + np.sqrt(p.v[0, 0]) * z[t, d]
+    om = omodel(mat)
+    f = oracle.kf_filter(om, p.v, p.w, np.zeros(d), p.c0, y - yp)      # zero prior mean
+    s = oracle.smoother(om, f, compat_q1=False)
+    return s["s"] + np.array(xs)
+
+
+@pytest.mark.parametrize("dense_w", [False, True])
+def test_ffbs_simulation_smoother_matches_reference_construction(eng, dense_w):
+    mod, mat, p = seasonal_model(T=90)
+    if dense_w:
+        rng = np.random.default_rng(17)
+        A = rng.standard_normal((13, 13))
+        p = DlmParameters(p.v, A @ A.T / 13 + 0.05 * np.eye(13), rng.standard_normal(13), A.T @ A / 13 + 0.5 * np.eye(13))
+    N = 4
+    y = simulate(mat, p, N, seed=61, missing=0.1)
+    z = np.random.default_rng(9).standard_normal((N, 91, 14))
+    flags = _lib.OPT_FFBS_SIMSMOOTH
+    out = eng.ffbs(mat, p, y, z=z, flags=flags)
+    assert eng.last_variant == "sparse16-simsmooth" and np.all(out["status"] == 0)
+    om = omodel(mat)
+    for n in range(N):
+        ref = dk_reference_draw(mat, p, y[n], z[n])
+        # tolerance 1e-7: a filter and a mean smoother on top of simulated states
+        np.testing.assert_allclose(out["theta"][n], ref, rtol=1e-7, atol=1e-8)
+        st = oracle.gibbs_stats(om, y[n], ref)
+        np.testing.assert_allclose(out["stats"][n, 0], st["ssy"][0], rtol=1e-7)
+        assert out["stats"][n, 1] == st["n"][0] and out["stats"][n, -1] == 90
+        np.testing.assert_allclose(out["stats"][n, 2:15], st["ss"], rtol=1e-7)
+    # outer-product statistics (GibbsWishart) and the Philox stream (same normals as the oracle's)
+    out2 = eng.ffbs(mat, p, y, z=z, flags=flags | _lib.OPT_STATS_OUTER)
+    st = oracle.gibbs_stats(om, y[0], dk_reference_draw(mat, p, y[0], z[0]), want_outer=True)
+    np.testing.assert_allclose(out2["stats"][0, 2:2 + 169], st["outer"], rtol=1e-6, atol=1e-8)
+    out3 = eng.ffbs(mat, p, y, seed=5, series_offset=2, flags=flags)
+    zz = oracle.normals(5, 2 + 1, 91, 14)
+    np.testing.assert_allclose(out3["theta"][1], dk_reference_draw(mat, p, y[1], zz), rtol=1e-7, atol=1e-8)
+
+
+def test_ffbs_simulation_smoother_distribution(eng):
+    """Many draws of one series: mean and covariance of theta_t equal the RTS smoothing moments."""
+    mod = Dlm.polynomial(2)
+    mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
+    p = DlmParameters([[3.0]], np.diag([1.0, 0.3]), [0.5, -0.2], np.eye(2) * 0.5)
+    y1 = simulate(mat, p, 1, seed=4)
+    N = 6000
+    out = eng.ffbs(mat, p, np.repeat(y1, N, axis=0), seed=123, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    assert eng.last_variant == "sparse16-simsmooth"
+    f, s = oracle_filter_smooth(mat, p, y1[0])
+    for t in (0, 12, 30):
+        th = out["theta"][:, t]
+        S = oracle.from_cm(s["S"][t], 2, 2)
+        assert np.all(np.abs(th.mean(axis=0) - s["s"][t]) < 5 * np.sqrt(np.diag(S) / N))
+        np.testing.assert_allclose(np.cov(th.T), S, rtol=0.12, atol=0.02)

@@ -24,9 +24,11 @@ def main():
         mod, p = seasonal_c2(); N, T = 10000, 1000
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
         y = torch.as_tensor(simulate(mat, p, N, seed=1), device=dev)
-        dt = timeit(lambda: eng.ffbs(mat, p, y, seed=3, want_theta=False, want_stats=True))
-        print(json.dumps({"config": "C3 FFBS + suff-stats, d=13, N=10000, T=1000", "variant": eng.last_variant,
-                          "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+        from bayesian_dlms_amd import _lib
+        for name, flags in (("reference-form backward sampling", 0), ("simulation smoother", _lib.OPT_FFBS_SIMSMOOTH)):
+            dt = timeit(lambda: eng.ffbs(mat, p, y, seed=3, want_theta=False, want_stats=True, flags=flags))
+            print(json.dumps({"config": f"C3 FFBS + suff-stats ({name}), d=13, N=10000, T=1000", "variant": eng.last_variant,
+                              "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
     if "c4" in which:
         mod = Dlm.polynomial(2)
         for _ in range(19): mod = mod * Dlm.polynomial(2)
