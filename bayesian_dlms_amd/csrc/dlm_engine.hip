@@ -134,6 +134,7 @@ void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params
 }
 
 bool use_fast(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::mfma16_supported(k); }
+bool use_tiled(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::tiled_supported(k); }
 
 // Inspect G (one table entry, fast path only) and upload its sparse tables when it is
 // structured.  `G_user` is the caller's pointer (host or device according to host_mode).
@@ -189,6 +190,9 @@ int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
       e->variant = "mfma16";
       HIP_TRY(e, dlm::launch_mfma16_filter(k, side, e->stream));
     }
+  } else if (use_tiled(k) && !k.prior) {
+    e->variant = "tiled-mfma";
+    HIP_TRY(e, dlm::launch_tiled_filter(k, e->stream));
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_filter(k, e->stream));
@@ -208,6 +212,9 @@ int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
       e->variant = "mfma16";
       HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->side, e->stream));
     }
+  } else if (have_side && use_tiled(k) && k.y && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1)) {
+    e->variant = "tiled-mfma";   // fused call only: the information-form pass recomputes innovations from y
+    HIP_TRY(e, dlm::launch_tiled_smoother(k, e->stream));
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_smoother(k, e->stream));
@@ -334,7 +341,7 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
-  const bool fused_fast = fast_smoother_ok(k);
+  const bool fused_fast = fast_smoother_ok(k) || use_tiled(k);
   HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
   if ((rc = run_filter(e, k, fused_fast))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));

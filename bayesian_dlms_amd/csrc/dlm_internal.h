@@ -57,6 +57,11 @@ hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev
 hipError_t launch_sparse16_simsmooth(const KArgs& a, int K, const SparseT* tabs_dev, const double* side, const double* xplus, hipStream_t s);
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s);
 
+// ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------
+bool tiled_supported(const KArgs& a);
+hipError_t launch_tiled_filter(const KArgs& a, hipStream_t s);
+hipError_t launch_tiled_smoother(const KArgs& a, hipStream_t s);   // needs a.y (innovations are recomputed)
+
 // ---- SVD filter / sampler (one-sided Jacobi in LDS), dlm_svd.hip ----------------------
 size_t svd_filter_lds_bytes(int d, int p);
 hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s);

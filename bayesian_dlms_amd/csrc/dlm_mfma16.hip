@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256) void k_smoother_mfma16(KArgs a, const double* 
   const double* fin = a.filt_in + (size_t)n * (T + 1) * rec;
   double* out = a.smooth + (size_t)n * (T + 1) * rec;
   const double* sd = side + (size_t)n * (T + 1) * 2;
+  __shared__ double tlds[4 * 16 * 17];
+  double* timg = tlds + (threadIdx.x >> 6) * (16 * 17);   // wave-private transpose scratch
 
   d4 gm;             // std(G)
   double Fr[4];
@@ -276,6 +278,20 @@ __global__ __launch_bounds__(256) void k_smoother_mfma16(KArgs a, const double* 
     } else {
       M = P;
       rrow = qrow;
+    }
+    // Symmetrise M through a wave-private LDS transpose: the rank-2 update above treats P as exactly
+    // symmetric, and an antisymmetric rounding component would escape the contraction and grow
+    // exponentially for unit-root models.
+    if ((t & 7) == 0) {   // both cross terms use P^T K here: the asymmetry only rotates with G between clean-ups
+#pragma unroll
+      for (int r = 0; r < 4; ++r) timg[(4 * r + g) * 17 + c] = M[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int r = 0; r < 4; ++r) M[r] = 0.5 * (M[r] + timg[c * 17 + 4 * r + g]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
     const d4 mg = mmT(M, gm);                         // M G   (M symmetric)
     d4 b3;

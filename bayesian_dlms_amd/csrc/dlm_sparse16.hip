@@ -147,7 +147,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #endif
 
 // Z = T X T^T for symmetric X (std layout), T given by the per-column-lane tables idx/val.
-template <int K>
+// SYM: use (X + X^T)/2 in the first pass.  The backward recursion needs it: its rank-2 update treats P
+// as exactly symmetric, and an antisymmetric rounding component would otherwise escape the contraction
+// (I - F K^T) . (I - K F^T) and grow exponentially for unit-root models.
+template <int K, bool SYM = false>
 __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB, const int (&idx)[K],
                                          const double (&val)[K], int g, int c) {
 #pragma unroll
@@ -156,9 +159,17 @@ __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB
   d4 y;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    double acc = imgA[(4 * r + g) * LD + idx[0]] * val[0];
+    double acc;
+    if (SYM) {
+      acc = (imgA[(4 * r + g) * LD + idx[0]] + imgA[idx[0] * LD + 4 * r + g]) * (0.5 * val[0]);
 #pragma unroll
-    for (int s = 1; s < K; ++s) acc = fma(imgA[(4 * r + g) * LD + idx[s]], val[s], acc);
+      for (int s = 1; s < K; ++s)
+        acc = fma(imgA[(4 * r + g) * LD + idx[s]] + imgA[idx[s] * LD + 4 * r + g], 0.5 * val[s], acc);
+    } else {
+      acc = imgA[(4 * r + g) * LD + idx[0]] * val[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) acc = fma(imgA[(4 * r + g) * LD + idx[s]], val[s], acc);
+    }
     y[r] = acc;
   }
 #pragma unroll
@@ -508,7 +519,11 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       asm volatile("" ::"v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]));
 #endif
       STAMP(3)
-      P = congruence<K>(M, imgA, imgB, idx, val, g, c);      // G^T M G (its first sync covers vR)
+      // In this kernel both cross terms use the same vector (P^T K), so the antisymmetric rounding part of
+      // P is only rotated by G from step to step (polynomial growth at worst for unit-root G), never
+      // amplified by the update: removing it every 8th step keeps it at rounding level.
+      if ((t & 7) == 0) P = congruence<K, true>(M, imgA, imgB, idx, val, g, c);   // G^T sym(M) G
+      else P = congruence<K, false>(M, imgA, imgB, idx, val, g, c);               // (first sync covers vR)
       qcol = vR[idx[0]] * val[0];
 #pragma unroll
       for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);

@@ -45,18 +45,29 @@
 
 /* C(m x n) = op(A) * op(B); op = transpose when ta/tb != 0.
  * A is (ta ? k x m : m x k) with leading dimension lda, likewise B. */
-static void mm(int m, int n, int k, const double *A, int lda, int ta,
-               const double *B, int ldb, int tb, double *C, int ldc) {
-  for (int j = 0; j < n; ++j)
-    for (int i = 0; i < m; ++i) {
-      double s = 0.0;
+static void mm(int m, int n, int k, const double *restrict A, int lda, int ta,
+               const double *restrict B, int ldb, int tb, double *restrict C, int ldc) {
+  /* column-major: accumulate C[:, j] += op(A)[:, l] * op(B)[l, j] so that the inner loop runs
+   * down a contiguous column whenever A is not transposed (the common case on this path) */
+  for (int j = 0; j < n; ++j) {
+    double *restrict c = C + (size_t)j * ldc;
+    for (int i = 0; i < m; ++i) c[i] = 0.0;
+    if (!ta) {
       for (int l = 0; l < k; ++l) {
-        double a = ta ? A[IDX(l, i, lda)] : A[IDX(i, l, lda)];
-        double b = tb ? B[IDX(j, l, ldb)] : B[IDX(l, j, ldb)];
-        s += a * b;
+        const double b = tb ? B[IDX(j, l, ldb)] : B[IDX(l, j, ldb)];
+        const double *restrict a = A + (size_t)l * lda;
+        for (int i = 0; i < m; ++i) c[i] += a[i] * b;
       }
-      C[IDX(i, j, ldc)] = s;
+    } else {
+      for (int i = 0; i < m; ++i) {
+        const double *restrict a = A + (size_t)i * lda;
+        double s = 0.0;
+        if (!tb) { const double *restrict b = B + (size_t)j * ldb; for (int l = 0; l < k; ++l) s += a[l] * b[l]; }
+        else for (int l = 0; l < k; ++l) s += a[l] * B[IDX(j, l, ldb)];
+        c[i] = s;
+      }
     }
+  }
 }
 
 /* Solve A X = B in place (B <- X); A n x n is destroyed.  LU with partial

@@ -486,3 +486,101 @@ def test_ffbs_simulation_smoother_distribution(eng):
         S = oracle.from_cm(s["S"][t], 2, 2)
         assert np.all(np.abs(th.mean(axis=0) - s["s"][t]) < 5 * np.sqrt(np.diag(S) / N))
         np.testing.assert_allclose(np.cov(th.T), S, rtol=0.12, atol=0.02)
+
+
+# ------------------------------------------------------------------------------------------
+# multivariate tiled-MFMA path (16 <= d <= 48, p <= 32): config C4 and friends
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["c4", "d17_p3_irregular", "d24_p5_timevarying_f"])
+def test_tiled_mfma_path(eng, case):
+    rng = np.random.default_rng({"c4": 40, "d17_p3_irregular": 17, "d24_p5_timevarying_f": 24}[case])
+    if case == "c4":
+        mod = Dlm.polynomial(2)
+        for _ in range(19):
+            mod = mod * Dlm.polynomial(2)
+        times = np.arange(1, 41, dtype=np.float64)
+        d, p_ = 40, 20
+        V = np.eye(20)
+    elif case == "d17_p3_irregular":
+        d, p_ = 17, 3
+        A = rng.standard_normal((d, d)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((d, p_))
+        mod = Dlm(lambda t: F, lambda dt: np.linalg.matrix_power(G1, int(dt)) if dt > 0 else np.eye(d))
+        times = np.cumsum(np.array([1, 1, 2, 1, 3, 1, 1, 2] * 4, dtype=np.float64))
+        B = rng.standard_normal((p_, p_)); V = B @ B.T / p_ + 0.5 * np.eye(p_)   # correlated observation noise
+    else:
+        d, p_ = 24, 5
+        G1 = 0.8 * np.eye(d) + 0.1 * np.eye(d, k=1)
+        Fs = rng.standard_normal((30, d, p_))
+        mod = Dlm(lambda t: Fs[int(t) - 1], lambda dt: G1)
+        times = np.arange(1, 31, dtype=np.float64)
+        V = np.diag(rng.uniform(0.5, 2.0, p_))
+    mat = materialise(mod, times)
+    assert mat.d == d and mat.p == p_
+    A = rng.standard_normal((d, d))
+    p = DlmParameters(V, A @ A.T / d + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d) * 1.5)
+    N = 3
+    y = rng.standard_normal((N, mat.T, p_)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.2] = np.nan
+    y[:, 5, :] = np.nan                                  # a fully missing record
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "tiled-mfma" and np.all(out["status"] == 0)
+    fq = eng.filter(mat, p, y, want_fq=True)
+    assert eng.last_variant == "tiled-mfma"
+    for n in range(N):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], d); sm, S = split(out["smooth"][n], d)
+        # tolerance: 1e-8 (filter) / 1e-7 (smoother): 40-dimensional products, p x p inverses
+        np.testing.assert_allclose(m, f["m"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(fq["fq"][n][1:, :p_], f["f"][1:], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(fq["fq"][n][1:, p_:], f["Q"][1:], rtol=1e-8, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------
+# unit-root models: the information-form backward pass must not amplify rounding asymmetry
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["sparse16_poly2_blocks", "mfma16_dense_unit_root", "tiled_poly2_blocks", "sparse16_poly3"])
+def test_unit_root_models_long_series(eng, kind):
+    """polynomial trends have G with unit eigenvalues; with a dense W an expanded P update that assumes
+    exact symmetry blows up within ~100 steps (found in round 1).  T = 400 here."""
+    rng = np.random.default_rng({"sparse16_poly2_blocks": 1, "mfma16_dense_unit_root": 2, "tiled_poly2_blocks": 3,
+                                 "sparse16_poly3": 4}[kind])
+    T = 400
+    if kind == "sparse16_poly2_blocks":
+        mod = Dlm.polynomial(2)
+        for _ in range(5):
+            mod = mod + Dlm.polynomial(2)             # d = 12, p = 1, block bidiagonal G
+        expect = "sparse16"
+    elif kind == "sparse16_poly3":
+        mod = Dlm.polynomial(3) + Dlm.seasonal(12, 2)  # d = 7
+        expect = "sparse16"
+    elif kind == "mfma16_dense_unit_root":
+        Q_, _ = np.linalg.qr(rng.standard_normal((10, 10)))
+        Gd = Q_ @ np.kron(np.eye(5), np.array([[1.0, 1.0], [0.0, 1.0]])) @ Q_.T   # dense, five unit-root Jordan blocks
+        Fd = Q_ @ np.tile([1.0, 0.0], 5)
+        mod = Dlm(lambda t: Fd.reshape(-1, 1), lambda dt: Gd)
+        expect = "mfma16"
+    else:
+        mod = Dlm.polynomial(2)
+        for _ in range(9):
+            mod = mod * Dlm.polynomial(2)              # d = 20, p = 10
+        expect = "tiled-mfma"
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    d, q = mat.d, mat.p
+    A = rng.standard_normal((d, d))
+    p = DlmParameters(np.eye(q) * 1.3, A @ A.T / d + 0.1 * np.eye(d), np.zeros(d), np.eye(d))
+    y = rng.standard_normal((2, T, q)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.05] = np.nan
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == expect and np.all(out["status"] == 0)
+    for n in range(2):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], d); sm, S = split(out["smooth"][n], d)
+        scale = max(1.0, np.abs(f["C"]).max())
+        np.testing.assert_allclose(m, f["m"], rtol=1e-7, atol=1e-8 * scale)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-7, atol=1e-8 * scale)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-6, atol=1e-7 * scale)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-6, atol=1e-7 * scale)
