@@ -32,27 +32,45 @@ constexpr int BIG = 48 * DL;    // doubles in a 48 x d-wide matrix
 constexpr int MID = 48 * PL;    // doubles in a 48 x p-wide matrix
 constexpr int SML = 32 * PL;    // doubles in a 32 x p-wide matrix
 
-// C (mt x nt tiles) = D -/+ op(A) op(B), all row-major in LDS.  MODE 0: C = acc, 1: C = D + acc,
+// C (mt x nt tiles, mt * nt <= 12) = D -/+ op(A) op(B), all row-major in LDS.  MODE 0: C = acc, 1: C = D + acc,
 // 2: C = D - acc (D may alias C).  kb = number of 4-deep k-blocks.
 template <bool TA, bool TB, int MODE>
 __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const double* A, int lda, const double* B,
                                        int ldb, double* C, int ldc, const double* D = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
-  for (int tile = wave; tile < mt * nt; tile += 4) {
+  const int ntiles = mt * nt;   // <= 9 on this path: every wave owns tiles wave, wave + 4, wave + 8
+  // The (up to) three tiles of a wave accumulate in three independent MFMA chains, so the dependent-
+  // accumulator latency of one chain (~3x the issue interval) is covered by the other two.
+  int ao[3], bo[3];
+  bool on[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int tile = wave + 4 * q;
+    on[q] = tile < ntiles;
+    const int i0 = on[q] ? (tile / nt) * 16 : 0, j0 = on[q] ? (tile % nt) * 16 : 0;
+    ao[q] = TA ? g * lda + i0 + c : (i0 + c) * lda + g;      // op(A)[i0 + c][g]     (+ 4 kk along k)
+    bo[q] = TB ? (j0 + c) * ldb + g : g * ldb + j0 + c;      // op(B)[g][j0 + c]
+  }
+  const int as = TA ? 4 * lda : 4, bs = TB ? 4 : 4 * ldb;    // stride of one k-block
+  d4 acc[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  for (int kk = 0; kk < kb; ++kk) {
+    double av[3], bv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { av[q] = A[ao[q] + kk * as]; bv[q] = B[bo[q] + kk * bs]; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (!on[q]) continue;
+    const int tile = wave + 4 * q;
     const int i0 = (tile / nt) * 16, j0 = (tile % nt) * 16;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int kk = 0; kk < kb; ++kk) {
-      const int k = 4 * kk + g;
-      const double av = TA ? A[k * lda + i0 + c] : A[(i0 + c) * lda + k];
-      const double bv = TB ? B[(j0 + c) * ldb + k] : B[k * ldb + j0 + c];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = (i0 + 4 * r + g) * ldc + j0 + c;
-      if (MODE == 0) C[o] = acc[r];
-      else if (MODE == 1) C[o] = D[o] + acc[r];
-      else C[o] = D[o] - acc[r];
+      if (MODE == 0) C[o] = acc[q][r];
+      else if (MODE == 1) C[o] = D[o] + acc[q][r];
+      else C[o] = D[o] - acc[q][r];
     }
   }
 }

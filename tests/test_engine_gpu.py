@@ -584,3 +584,105 @@ def test_unit_root_models_long_series(eng, kind):
         np.testing.assert_allclose(C, f["C"], rtol=1e-7, atol=1e-8 * scale)
         np.testing.assert_allclose(sm, s["s"], rtol=1e-6, atol=1e-7 * scale)
         np.testing.assert_allclose(S, s["S"], rtol=1e-6, atol=1e-7 * scale)
+
+
+# ------------------------------------------------------------------------------------------
+# Gibbs samplers end to end on the engine (GibbsSampling.sample / GibbsWishart.sample)
+# ------------------------------------------------------------------------------------------
+def test_gibbs_dinvgamma_recovers_variances(eng):
+    """Pooled d-Inverse-Gamma Gibbs on 200 simulated local-linear-trend series: posterior means of V and
+    W land near the truth (a statistical end-to-end check of FFBS + statistics + conjugate draws)."""
+    from bayesian_dlms_amd.gibbs import GibbsSampling, InverseGamma
+    mod = Dlm.polynomial(2)
+    times = np.arange(1, 151, dtype=np.float64)
+    mat = materialise(mod, times)
+    truth = DlmParameters([[2.0]], np.diag([0.5, 0.05]), [0.0, 0.0], np.eye(2))
+    y = simulate(mat, truth, 200, seed=101)
+    init = DlmParameters([[1.0]], np.diag([1.0, 1.0]), [0.0, 0.0], np.eye(2) * 10)
+    for sim in (False, True):
+        chain = list(GibbsSampling.sample(mod, InverseGamma(3.0, 3.0), InverseGamma(3.0, 1.0), init, times, y, eng,
+                                          n_iter=60, seed=5, pooled=True, simulation_smoother=sim))
+        v = np.mean([s.p.v[0, 0] for s in chain[20:]]); w = np.mean([np.diag(s.p.w) for s in chain[20:]], axis=0)
+        assert abs(v - 2.0) < 0.15 and abs(w[0] - 0.5) < 0.08 and abs(w[1] - 0.05) < 0.02, (sim, v, w)
+
+
+def test_gibbs_per_series_engine_matches_oracle_ffbs(eng):
+    """Per-series Gibbs through the engine equals the same chain driven by the oracle's FFBS."""
+    from bayesian_dlms_amd.gibbs import GibbsSampling, InverseGamma
+    from test_host_logic import oracle_ffbs
+    mod = Dlm.polynomial(2)
+    times = np.arange(1, 41, dtype=np.float64)
+    mat = materialise(mod, times)
+    p0 = DlmParameters([[2.0]], np.diag([0.5, 0.2]), [0.0, 0.0], np.eye(2) * 10)
+    y = simulate(mat, p0, 5, seed=3, missing=0.1)
+    a = list(GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p0, times, y, eng, n_iter=3, seed=9))
+    b = list(GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p0, times, y, None, n_iter=3, seed=9,
+                                  ffbs=oracle_ffbs))
+    for sa, sb in zip(a, b):
+        for k in range(5):
+            np.testing.assert_allclose(sa.p[k].v, sb.p[k].v, rtol=1e-6)
+            np.testing.assert_allclose(sa.p[k].w, sb.p[k].w, rtol=1e-6)
+
+
+def test_gibbs_wishart_engine(eng):
+    from bayesian_dlms_amd.gibbs import GibbsWishart, InverseGamma, InverseWishart
+    mod = Dlm.polynomial(1) * Dlm.polynomial(1)
+    times = np.arange(1, 101, dtype=np.float64)
+    mat = materialise(mod, times)
+    Wt = np.array([[0.5, 0.3], [0.3, 0.4]])
+    truth = DlmParameters(np.eye(2), Wt, [0.0, 0.0], np.eye(2))
+    y = simulate(mat, truth, 100, seed=7)
+    init = DlmParameters(np.eye(2), np.eye(2), [0.0, 0.0], np.eye(2) * 10)
+    chain = list(GibbsWishart.sample(mod, InverseGamma(3.0, 3.0), InverseWishart(4.0, np.eye(2)), init, times, y, eng,
+                                     n_iter=50, seed=2, pooled=True))
+    W = np.mean([s.p.w for s in chain[15:]], axis=0)
+    np.testing.assert_allclose(W, Wt, atol=0.08)
+
+
+def test_rccl_allreduce_single_rank_and_stats_pool(eng):
+    """The C-ABI RCCL wrapper on a 1-rank communicator (the multi-rank path is the same call)."""
+    import torch
+    from bayesian_dlms_amd.engine import Engine
+    e2 = Engine(0)
+    e2.comm_init_rank(1, 0, e2.comm_unique_id())
+    t = torch.arange(16, dtype=torch.float64, device="cuda:0")
+    e2.allreduce_stats(t)
+    np.testing.assert_array_equal(t.cpu().numpy(), np.arange(16.0))
+    e2.close()
+
+
+# ------------------------------------------------------------------------------------------
+# edge cases
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags", VARIANTS)
+def test_edge_shapes(eng, flags):
+    """T = 1, N = 1, d = 1; every observation missing; a series that starts with missing data."""
+    p = DlmParameters([[2.0]], [[3.0]], [1.0], [[10.0]])
+    mat = materialise(Dlm.polynomial(1), [5.0])
+    out = eng.filter_smooth(mat, p, np.array([[[4.0]]]), flags=flags)
+    f, s = oracle_filter_smooth(mat, p, np.array([[4.0]]))
+    np.testing.assert_allclose(out["filt"][0], np.concatenate([f["m"], f["C"]], axis=1), rtol=1e-13)
+    np.testing.assert_allclose(out["smooth"][0], np.concatenate([s["s"], s["S"]], axis=1), rtol=1e-12)
+    mat = materialise(Dlm.polynomial(1), np.arange(1, 9, dtype=np.float64))
+    y = np.full((2, 8, 1), np.nan); y[1, 3:, 0] = [1.0, 2.0, np.nan, 2.5, 3.0]
+    out = eng.filter_smooth(mat, p, y, flags=flags)
+    assert np.all(out["status"] == 0)
+    for n in range(2):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        np.testing.assert_allclose(out["filt"][n], np.concatenate([f["m"], f["C"]], axis=1), rtol=1e-12)
+        np.testing.assert_allclose(out["smooth"][n], np.concatenate([s["s"], s["S"]], axis=1), rtol=1e-11)
+    np.testing.assert_allclose(out["filt"][0][:, 1], 10.0 + 3.0 * np.arange(9))   # nothing observed: C_t = C0 + t W
+
+
+def test_status_flags_nonfinite_and_not_pd(eng):
+    mod, mat, p = seasonal_model(T=20)
+    y = simulate(mat, p, 3, seed=1)
+    y[1, 5, 0] = np.inf                               # a non-finite observation poisons only its own series
+    out = eng.filter_smooth(mat, p, y)
+    st = out["status"]
+    assert st[0] == 0 and st[2] == 0 and (st[1] & _lib.ST_NONFINITE)
+    bad = DlmParameters([[0.0]], p.w, p.m0, p.c0)     # V = 0: the information-form backward pass needs V > 0
+    out = eng.filter_smooth(mat, bad, y[:1])
+    assert out["status"][0] & _lib.ST_NOT_PD
+    ok = eng.filter_smooth(mat, bad, y[:1], flags=_lib.OPT_FORCE_GENERIC)   # the generic RTS path handles V = 0
+    assert ok["status"][0] == 0 and np.all(np.isfinite(ok["smooth"]))

@@ -38,8 +38,9 @@ def main():
         p = DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
         y = torch.as_tensor(rng.standard_normal((N, T, 20)).cumsum(axis=1), device=dev)
         dt = timeit(lambda: eng.filter_smooth(mat, p, y), reps=1)
+        fwd, bwd = eng.last_timing()
         print(json.dumps({"config": "C4 filter+smooth, d=40, p=20, N=2000, T=1000", "variant": eng.last_variant,
-                          "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+                          "ms": dt * 1e3, "forward_ms": fwd, "backward_ms": bwd, "series_steps_per_s": N * T / dt}))
     if "c5" in which:
         mod, p = seasonal_c2(); N, T = 10000, 200
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
