@@ -1,6 +1,6 @@
 // Multivariate path: 16 <= d <= 48, p <= 32 (config C4: d = 40, p = 20).
 //
-// One 256-thread workgroup (4 wavefronts) per series.  Every matrix of the recursion lives in the
+// One 512-thread workgroup (8 wavefronts, two per SIMD) per series.  Every matrix of the recursion lives in the
 // workgroup's LDS, zero-padded to multiples of 16 with a leading dimension of 49 (d-wide) or 33
 // (p-wide) doubles -- odd, so that the strided A-operand reads are bank-conflict free -- and every
 // O(d^3) / O(d^2 p) product is an MFMA GEMM: the 16 x 16 output tiles are dealt round-robin to the
@@ -22,10 +22,14 @@
 #include "dlm_internal.h"
 #include "../../include/dlm_engine.h"
 
+#include <type_traits>
+
 namespace dlm {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+constexpr int NT = 512;         // threads per workgroup: 8 waves, two per SIMD (latency hiding, 1 workgroup per CU)
+constexpr int NW = NT / 64;
 constexpr int DL = 49;          // leading dimension of d-wide matrices (up to 48 columns)
 constexpr int PL = 33;          // leading dimension of p-wide matrices (up to 32 columns)
 constexpr int BIG = 48 * DL;    // doubles in a 48 x d-wide matrix
@@ -38,32 +42,36 @@ template <bool TA, bool TB, int MODE>
 __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const double* A, int lda, const double* B,
                                        int ldb, double* C, int ldc, const double* D = nullptr) {
   const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
-  const int ntiles = mt * nt;   // <= 9 on this path: every wave owns tiles wave, wave + 4, wave + 8
-  // The (up to) three tiles of a wave accumulate in three independent MFMA chains, so the dependent-
-  // accumulator latency of one chain (~3x the issue interval) is covered by the other two.
-  int ao[3], bo[3];
-  bool on[3];
+  const int ntiles = mt * nt;   // <= 9 on this path: wave w owns tiles w and w + 8
+  if (wave >= ntiles) return;
+  // two independent MFMA accumulation chains per wave (and two waves per SIMD) cover the
+  // dependent-accumulator latency of a chain
+  int ao[2], bo[2];
+  bool on[2];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int tile = wave + 4 * q;
+  for (int q = 0; q < 2; ++q) {
+    const int tile = wave + NW * q;
     on[q] = tile < ntiles;
     const int i0 = on[q] ? (tile / nt) * 16 : 0, j0 = on[q] ? (tile % nt) * 16 : 0;
     ao[q] = TA ? g * lda + i0 + c : (i0 + c) * lda + g;      // op(A)[i0 + c][g]     (+ 4 kk along k)
     bo[q] = TB ? (j0 + c) * ldb + g : g * ldb + j0 + c;      // op(B)[g][j0 + c]
   }
   const int as = TA ? 4 * lda : 4, bs = TB ? 4 : 4 * ldb;    // stride of one k-block
-  d4 acc[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-  for (int kk = 0; kk < kb; ++kk) {
-    double av[3], bv[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { av[q] = A[ao[q] + kk * as]; bv[q] = B[bo[q] + kk * bs]; }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[q], 0, 0, 0);
+  d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  if (on[1]) {
+    for (int kk = 0; kk < kb; ++kk) {
+      const double a0 = A[ao[0] + kk * as], b0 = B[bo[0] + kk * bs], a1 = A[ao[1] + kk * as], b1 = B[bo[1] + kk * bs];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1], 0, 0, 0);
+    }
+  } else {
+    for (int kk = 0; kk < kb; ++kk)
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ao[0] + kk * as], B[bo[0] + kk * bs], acc[0], 0, 0, 0);
   }
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < 2; ++q) {
     if (!on[q]) continue;
-    const int tile = wave + 4 * q;
+    const int tile = wave + NW * q;
     const int i0 = (tile / nt) * 16, j0 = (tile % nt) * 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -75,52 +83,143 @@ __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const do
   }
 }
 
-// In-place inverse of the SPD n x n (n <= 32) LDS matrix A (ld PL) via Cholesky; Li is scratch.
-// Returns true if a non-positive pivot was met.  All 256 threads must call.
-__device__ bool spd_inverse(int tid, int n, double* A, double* Li) {
-  bool bad = false;
-  for (int k = 0; k < n; ++k) {
-    __syncthreads();
-    double akk = A[k * PL + k];
-    if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
-    const double lkk = sqrt(akk), inv = 1.0 / lkk;
-    __syncthreads();
-    if (tid >= k && tid < n) A[tid * PL + k] = (tid == k) ? lkk : A[tid * PL + k] * inv;
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += 256) {
-      const int i = idx / n, j = idx % n;
-      if (j > k && i >= j) A[i * PL + j] = fma(-A[i * PL + k], A[j * PL + k], A[i * PL + j]);
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 32 * PL; idx += 256) Li[idx] = 0.0;
-  __syncthreads();
-  if (tid < n) {   // column tid of L^-1 by forward substitution
-    const int j = tid;
-    Li[j * PL + j] = 1.0 / A[j * PL + j];
-    for (int i = j + 1; i < n; ++i) {
-      double s = 0.0;
-      for (int l = j; l < i; ++l) s = fma(A[i * PL + l], Li[l * PL + j], s);
-      Li[i * PL + j] = -s / A[i * PL + i];
-    }
-  }
-  __syncthreads();
-  const int nt = (n + 15) / 16, kb = (n + 3) / 4;
-  gemm_t<true, false, 0>(tid, nt, nt, kb, Li, PL, Li, PL, A, PL);   // A^-1 = L^-T L^-1
-  __syncthreads();
-  return bad;
+__device__ __forceinline__ void wsync() {   // LDS hand-off inside ONE wavefront (in-order LDS queue)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void zero_lds(int tid, double* p, int n) { for (int i = tid; i < n; i += 256) p[i] = 0.0; }
+__device__ __forceinline__ double bcast_lane(double v, int src) {   // lane `src` -> SGPR pair (uniform)
+  const int lo = __builtin_amdgcn_readlane((int)__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane((int)__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// In-place inverse of the SPD n x n (n <= 32) LDS matrix A (ld PL); Li is scratch.
+// Register-resident on wave 0: lane i holds row i (32 doubles); the Cholesky pivot quantities and the
+// entries of L needed by every lane are broadcast with v_readlane into SGPRs, so the n sequential
+// pivots cost no LDS round trip and no barrier (the LDS version spent 64k of 89k cycles per step
+// here).  Then X = L^-1 by forward substitution (lane = column of X) and A^-1 = X^T X by MFMA.
+// Every thread must call; ends with one workgroup barrier.  Returns whether a pivot was non-positive.
+// compile-time loop: the register arrays below must only ever be indexed by constants
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+__device__ __forceinline__ bool spd_inverse(int tid, int n_, double* A, double* Li, int* bad_flag) {
+  const int n = __builtin_amdgcn_readfirstlane(n_);   // uniform: the guards below must be scalar branches
+  __syncthreads();
+  if (tid < 64) {
+    const int lane = tid;
+    double a[32], x[32];
+    static_for<0, 32>([&](auto J) { constexpr int j = J; a[j] = (lane < n && j < n) ? A[lane * PL + j] : ((lane == j) ? 1.0 : 0.0); });
+    bool bad = false;
+    static_for<0, 32>([&](auto Kc) {
+      constexpr int k = Kc;
+      if (k < n) {
+        double akk = bcast_lane(a[k], k);
+        if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
+        const double lkk = sqrt(akk), inv = 1.0 / lkk;
+        a[k] = (lane == k) ? lkk : a[k] * inv;               // column k of L (rows >= k are meaningful)
+        static_for<k + 1, 32>([&](auto J) {
+          constexpr int j = J;
+          if (j < n) a[j] = fma(-a[k], bcast_lane(a[k], j), a[j]);   // A[i][j] -= L[i][k] L[j][k]
+        });
+      }
+    });
+    // X = L^-1, lane c = column c:  x[i] = ((i == c) - sum_{l<i} L[i][l] x[l]) / L[i][i]
+    double dinv = 1.0;
+    static_for<0, 32>([&](auto Kc) { constexpr int k = Kc; dinv = (lane == k) ? 1.0 / a[k] : dinv; });   // 1 / L[lane][lane]
+    static_for<0, 32>([&](auto Ic) {
+      constexpr int i = Ic;
+      x[i] = 0.0;
+      if (i < n) {
+        double acc = (lane == i) ? 1.0 : 0.0;
+        static_for<0, i>([&](auto Lc) { constexpr int l = Lc; acc = fma(-bcast_lane(a[l], i), x[l], acc); });
+        x[i] = acc * bcast_lane(dinv, i);
+      }
+    });
+    for (int idx = lane; idx < 32 * PL; idx += 64) Li[idx] = 0.0;
+    wsync();
+    if (lane < n) static_for<0, 32>([&](auto Ic) { constexpr int i = Ic; if (i < n) Li[i * PL + lane] = x[i]; });
+    wsync();
+    // A^-1 = X^T X : up to 2 x 2 tiles, all on this wave
+    const int nt = (n + 15) / 16, kb = (n + 3) / 4, g = lane >> 4, c = lane & 15;
+    for (int tile = 0; tile < nt * nt; ++tile) {
+      const int i0 = (tile / nt) * 16, j0 = (tile % nt) * 16;
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < kb; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(4 * kk + g) * PL + i0 + c], Li[(4 * kk + g) * PL + j0 + c], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) A[(i0 + 4 * r + g) * PL + j0 + c] = acc[r];
+    }
+    if (lane == 0) *bad_flag = bad ? 1 : 0;
+  }
+  __syncthreads();
+  return *bad_flag != 0;
+}
+
+__device__ __forceinline__ void zero_lds(int tid, double* p, int n) { for (int i = tid; i < n; i += NT) p[i] = 0.0; }
+
+// element loop over a rows x cols column-major block without integer division: wave -> column, lane -> row
+#define FOR_CM(rows, cols, i, j) for (int j = tid >> 6; j < (cols); j += NW) for (int i = tid & 63; i < (rows); i += 64)
 
 // column-major global d x d (or d x p) -> zero-padded row-major LDS
 __device__ __forceinline__ void load_cm(int tid, const double* src, int rows, int cols, double* dst, int ld) {
-  for (int idx = tid; idx < rows * cols; idx += 256) { const int i = idx % rows, j = idx / rows; dst[i * ld + j] = src[idx]; }
+  FOR_CM(rows, cols, i, j) dst[i * ld + j] = src[i + j * rows];
 }
+
+// Inverse of the SPD n x n matrix Q (LDS, ld PL) by Newton-Schulz refinement of a warm start:
+//   E = I - Q X ,  X <- X + X E        (||E|| squares every iteration)
+// X holds the inverse of the previous time step's Q on entry (Q_t changes slowly: one or two iterations
+// at steady state) and the verified inverse on exit.  If the
+// warm start is too far off (first step, missingness pattern changed: n max|E| >= 0.5) or it has not
+// converged (max|E| <= 2e-10) in 6 iterations, the direct register Cholesky takes over.  E and Tn are p x p scratch.
+// Every thread must call.  Returns whether the direct path met a non-positive pivot.
+__device__ __forceinline__ bool spd_inverse_warm(int tid, int n, const double* Q, double* X, double* E, double* Tn,
+                                                 double* Li, int* flag, bool have_warm, int* dbg = nullptr) {
+  const int nt = (n + 15) / 16, kb = (n + 3) / 4;
+  const double tol = 2e-10;   // the fp64 floor of max|I - Q X| is ~n cond(Q) eps (1e-11 here, no better for the direct inverse)
+  bool done = false;
+  if (have_warm) {
+    for (int it = 0; it < 6 && !done; ++it) {
+      __syncthreads();
+      gemm_t<false, false, 0>(tid, nt, nt, kb, Q, PL, X, PL, E, PL);            // Q X
+      __syncthreads();
+      bool big = false, far = false;
+      FOR_CM(n, n, i, j) {
+        const double e = ((i == j) ? 1.0 : 0.0) - E[i * PL + j];
+        E[i * PL + j] = e;
+        big |= !(fabs(e) <= tol);
+        far |= !(fabs(e) * n < 0.5);
+      }
+      const int any_far = __syncthreads_or(far);
+      const int any_big = __syncthreads_or(big);
+      if (dbg && tid == 0) { dbg[0] += 1; if (any_far) dbg[2] += 1; }
+      if (any_far && any_big) break;                                             // not contractive enough: go direct
+      if (!any_big) done = true;   // ||E|| <= 2e-10: the update below squares it, i.e. lands on the fp64 floor
+      gemm_t<false, false, 1>(tid, nt, nt, kb, X, PL, E, PL, Tn, PL, X);         // X + X E
+      __syncthreads();
+      FOR_CM(n, n, i, j) X[i * PL + j] = 0.5 * (Tn[i * PL + j] + Tn[j * PL + i]);  // keep it symmetric
+    }
+    __syncthreads();
+  }
+  if (done) return false;
+  if (dbg && tid == 0) dbg[1] += 1;
+  FOR_CM(n, n, i, j) X[i * PL + j] = Q[i * PL + j];
+  return spd_inverse(tid, n, X, Li, flag);
+}
+
+#ifdef DLM_STAMP
+#define TSTAMP(k) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); seg[k] += _t - tlast; tlast = _t; }
+#else
+#define TSTAMP(k)
+#endif
 
 bool tiled_supported(const KArgs& a) { return a.d >= 16 && a.d <= 48 && a.p <= 32; }
 
-constexpr int FILT_DOUBLES = 4 * BIG + 3 * MID + 3 * SML + 8 * 48;    // 141.7 KB
+constexpr int FILT_DOUBLES = 4 * BIG + 3 * MID + 2 * SML + 8 * 48;    // 133 KB (inverse scratch aliases Tm / Kg)
 constexpr int SMTH_DOUBLES = 4 * BIG + 3 * MID + 4 * SML + 10 * 48;   // 150.9 KB
 size_t tiled_filter_lds_bytes() { return sizeof(double) * FILT_DOUBLES + 16; }
 size_t tiled_smoother_lds_bytes() { return sizeof(double) * SMTH_DOUBLES + 16; }
@@ -128,16 +227,19 @@ size_t tiled_smoother_lds_bytes() { return sizeof(double) * SMTH_DOUBLES + 16; }
 // ---------------------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_filter_tiled(KArgs a) {
+__global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, frec = p + p * p;
   const int dt16 = (d + 15) / 16, pt16 = (p + 15) / 16, kd = (d + 3) / 4, kp = (p + 3) / 4;
   double* C = sm;            double* R = C + BIG;     double* Tm = R + BIG;    double* Gm = Tm + BIG;
   double* Fm = Gm + BIG;     double* RF = Fm + MID;   double* Kg = RF + MID;
-  double* Q = Kg + MID;      double* Qi = Q + SML;    double* Li = Qi + SML;
-  double* mv = Li + SML;     double* av = mv + 48;    double* ev = av + 48;    double* fv = ev + 48;
+  double* Q = Kg + MID;      double* Qi = Q + SML;    // Qi persists: warm start of the next step's inverse
+  double* mv = Qi + SML;     double* av = mv + 48;    double* ev = av + 48;    double* fv = ev + 48;
   double* ob = fv + 48;      // observed flags (1.0 / 0.0)
+  // scratch of the inverse, aliasing buffers that are idle between the forecast and the gain
+  double* Qm = Tm;           double* Es = Tm + SML;   double* Tn = Kg;         double* Li = Es;
+  bool warm = false;
   const double* V = a.V + (size_t)n * a.v_stride;
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* y = a.y + (size_t)n * T * p;
@@ -153,11 +255,17 @@ __global__ __launch_bounds__(256) void k_filter_tiled(KArgs a) {
   load_cm(tid, a.G + (size_t)gcur * dd, d, d, Gm, DL);
   if (tid < d) mv[tid] = (a.m0 + (size_t)n * a.m0_stride)[tid];
   __syncthreads();
-  for (int idx = tid; idx < dd; idx += 256) out[d + idx] = C[(idx % d) * DL + idx / d];
+  FOR_CM(d, d, i, j) out[d + i + j * d] = C[i * DL + j];
   if (tid < d) out[tid] = mv[tid];
-  if (fq) for (int i = tid; i < frec; i += 256) fq[i] = __builtin_nan("");
+  if (fq) for (int i = tid; i < frec; i += NT) fq[i] = __builtin_nan("");
 
+#ifdef DLM_STAMP
+  int dbgc[3] = {0, 0, 0};
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
   for (int t = 0; t < T; ++t) {
+    TSTAMP(7)
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) { __syncthreads(); load_cm(tid, a.G + (size_t)gi * dd, d, d, Gm, DL); gcur = gi; }
@@ -165,7 +273,7 @@ __global__ __launch_bounds__(256) void k_filter_tiled(KArgs a) {
     __syncthreads();
     // advState: a = G m, R = G C G^T + W dt   (dt == 0: a = m, R = C)
     if (dt == 0.0) {
-      for (int idx = tid; idx < 48 * DL; idx += 256) R[idx] = C[idx];
+      for (int idx = tid; idx < 48 * DL; idx += NT) R[idx] = C[idx];
       if (tid < d) av[tid] = mv[tid];
     } else {
       gemm_t<false, false, 0>(tid, dt16, dt16, kd, Gm, DL, C, DL, Tm, DL);
@@ -173,16 +281,17 @@ __global__ __launch_bounds__(256) void k_filter_tiled(KArgs a) {
       __syncthreads();
       gemm_t<false, true, 0>(tid, dt16, dt16, kd, Tm, DL, Gm, DL, R, DL);
       __syncthreads();
-      for (int idx = tid; idx < dd; idx += 256) { const int i = idx % d, j = idx / d; R[i * DL + j] = fma(W[idx], dt, R[i * DL + j]); }
+      FOR_CM(d, d, i, j) R[i * DL + j] = fma(W[i + j * d], dt, R[i * DL + j]);
     }
     __syncthreads();
+    TSTAMP(0)
     // forecast: f = F^T a, RF = R F, Q = F^T R F + V
     gemm_t<false, false, 0>(tid, dt16, pt16, kd, R, DL, Fm, PL, RF, PL);
     if (tid < p) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Fm[k * PL + tid], av[k], s); fv[tid] = s; }
     __syncthreads();
     gemm_t<true, false, 0>(tid, pt16, pt16, kd, Fm, PL, RF, PL, Q, PL);
     __syncthreads();
-    for (int idx = tid; idx < p * p; idx += 256) { const int i = idx % p, j = idx / p; Q[i * PL + j] += V[idx]; }
+    FOR_CM(p, p, i, j) Q[i * PL + j] += V[i + j * p];
     if (tid < p) {
       const double yv = y[(size_t)t * p + tid];
       ob[tid] = (yv == yv) ? 1.0 : 0.0;
@@ -192,40 +301,50 @@ __global__ __launch_bounds__(256) void k_filter_tiled(KArgs a) {
     if (fq) {
       double* fr = fq + (size_t)(t + 1) * frec;
       if (tid < p) fr[tid] = fv[tid];
-      for (int idx = tid; idx < p * p; idx += 256) fr[p + idx] = Q[(idx % p) * PL + idx / p];
+      FOR_CM(p, p, i, j) fr[p + i + j * p] = Q[i * PL + j];
     }
     bool any = false;
     for (int j = 0; j < p; ++j) any |= ob[j] != 0.0;
+    TSTAMP(1)
     if (!any) {   // updateState :74-75
       __syncthreads();
-      for (int idx = tid; idx < 48 * DL; idx += 256) C[idx] = R[idx];
+      for (int idx = tid; idx < 48 * DL; idx += NT) C[idx] = R[idx];
       if (tid < d) mv[tid] = av[tid];
     } else {
       // Qm: missing rows/columns -> identity; inverse; back to zero
       __syncthreads();
-      for (int idx = tid; idx < p * p; idx += 256) {
-        const int i = idx / p, j = idx % p;
-        Qi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? Q[i * PL + j] : (i == j ? 1.0 : 0.0);
-      }
-      if (spd_inverse(tid, p, Qi, Li)) st |= DLM_ST_NOT_PD;
-      for (int idx = tid; idx < p * p; idx += 256) {
-        const int i = idx / p, j = idx % p;
-        if (!(ob[i] != 0.0 && ob[j] != 0.0)) Qi[i * PL + j] = 0.0;
-      }
+      zero_lds(tid, Tm, 2 * SML);
+      zero_lds(tid, Kg, SML);
       __syncthreads();
+      FOR_CM(p, p, i, j) Qm[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? Q[i * PL + j] : (i == j ? 1.0 : 0.0);
+      if (tid < p && ob[tid] == 0.0) Qi[tid * PL + tid] = 1.0;   // warm start: identity on the missing block
+#ifdef DLM_STAMP
+      if (spd_inverse_warm(tid, p, Qm, Qi, Es, Tn, Li, (int*)(ob + 40), warm, (n == 0) ? dbgc : nullptr)) st |= DLM_ST_NOT_PD;
+#else
+      if (spd_inverse_warm(tid, p, Qm, Qi, Es, Tn, Li, (int*)(ob + 40), warm)) st |= DLM_ST_NOT_PD;
+#endif
+      warm = true;
+      FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Qi[i * PL + j] = 0.0;
+      __syncthreads();
+      TSTAMP(2)
       gemm_t<false, false, 0>(tid, dt16, pt16, kp, RF, PL, Qi, PL, Kg, PL);          // K = R F Qm^-1
       __syncthreads();
       if (tid < d) { double s = av[tid]; for (int j = 0; j < p; ++j) s = fma(Kg[tid * PL + j], ev[j], s); mv[tid] = s; }
       gemm_t<false, true, 2>(tid, dt16, dt16, kp, Kg, PL, RF, PL, C, DL, R);          // C = R - K (R F)^T
     }
     __syncthreads();
+    TSTAMP(3)
     double* o = out + (size_t)(t + 1) * rec;
     if (tid < d) o[tid] = mv[tid];
-    for (int idx = tid; idx < dd; idx += 256) o[d + idx] = C[(idx % d) * DL + idx / d];
+    FOR_CM(d, d, i, j) o[d + i + j * d] = C[i * DL + j];
+    TSTAMP(4)
   }
+#ifdef DLM_STAMP
+  if (n == 0 && tid == 0 && a.status) { for (int k = 0; k < 8; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)T); a.status[6] = dbgc[0]; a.status[7] = dbgc[1]; a.status[9] = dbgc[2]; }
+#endif
   __syncthreads();
   bool bad = false;
-  for (int idx = tid; idx < dd; idx += 256) bad |= !isfinite(C[(idx % d) * DL + idx / d]);
+  FOR_CM(d, d, i, j) bad |= !isfinite(C[i * DL + j]);
   if (tid < d) bad |= !isfinite(mv[tid]);
   if (__syncthreads_or(bad)) st |= DLM_ST_NONFINITE;
   if (a.status && tid == 0 && st) atomicOr(&a.status[n], st);
@@ -234,7 +353,7 @@ __global__ __launch_bounds__(256) void k_filter_tiled(KArgs a) {
 // ---------------------------------------------------------------------------------------
 // backward pass (information form, general p)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_smoother_tiled(KArgs a) {
+__global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd;
@@ -258,11 +377,28 @@ __global__ __launch_bounds__(256) void k_smoother_tiled(KArgs a) {
   if (tid < p) obp[tid] = -1.0;   // mask of the cached Vm^-1 (none yet)
   __syncthreads();
 
+  // register prefetch of the record stream: C_t one step ahead, the means two steps ahead (the
+  // innovation of step t needs m_{t-1})
+  double pre[6], mcur = 0.0, mnext = 0.0;
+  {
+    const double* r = fin + (size_t)T * rec;
+    int q = 0;
+    for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
+    if (tid < d) { mcur = r[tid]; mnext = (T > 0) ? (r - rec)[tid] : 0.0; }
+  }
   for (int t = T; t >= 0; --t) {
-    const double* r = fin + (size_t)t * rec;
     __syncthreads();
-    load_cm(tid, r + d, d, d, C, DL);
-    if (tid < d) { mv[tid] = r[tid]; mp[tid] = (t > 0) ? (r - rec)[tid] : 0.0; }
+    {
+      int q = 0;
+      for (int j = tid >> 6; j < d; j += NW, ++q) if ((tid & 63) < d) C[(tid & 63) * DL + j] = pre[q];
+      if (tid < d) { mv[tid] = mcur; mp[tid] = mnext; mcur = mnext; }
+      if (t > 0) {
+        const double* r = fin + (size_t)(t - 1) * rec;
+        q = 0;
+        for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
+        if (tid < d) mnext = (t > 1) ? (r - rec)[tid] : 0.0;
+      }
+    }
     if (a.f_stride && t > 0) load_cm(tid, a.F + (size_t)(t - 1) * a.f_stride, d, p, Fm, PL);
     if (tid < p) { const double yv = (t > 0) ? y[(size_t)(t - 1) * p + tid] : __builtin_nan(""); ob[tid] = (yv == yv) ? 1.0 : 0.0; tv[tid] = yv; }
     __syncthreads();
@@ -274,15 +410,9 @@ __global__ __launch_bounds__(256) void k_smoother_tiled(KArgs a) {
     if (any) {
       if (!same) {   // Vm^-1 for this missingness pattern (cached while the pattern repeats)
         __syncthreads();
-        for (int idx = tid; idx < p * p; idx += 256) {
-          const int i = idx / p, j = idx % p;
-          Vi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0);
-        }
-        if (spd_inverse(tid, p, Vi, Li)) st |= DLM_ST_NOT_PD;
-        for (int idx = tid; idx < p * p; idx += 256) {
-          const int i = idx / p, j = idx % p;
-          if (!(ob[i] != 0.0 && ob[j] != 0.0)) Vi[i * PL + j] = 0.0;
-        }
+        FOR_CM(p, p, i, j) Vi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0);
+        if (spd_inverse(tid, p, Vi, Li, (int*)(cq + 40))) st |= DLM_ST_NOT_PD;
+        FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Vi[i * PL + j] = 0.0;
         if (tid < p) obp[tid] = ob[tid];
         __syncthreads();
       }
@@ -314,7 +444,7 @@ __global__ __launch_bounds__(256) void k_smoother_tiled(KArgs a) {
     __syncthreads();
     double* o = out + (size_t)t * rec;
     if (tid < d) o[tid] = mv[tid] + cq[tid];                                          // s_t = m_t + C_t q_t
-    for (int idx = tid; idx < dd; idx += 256) { const int i = idx % d, j = idx / d; o[d + idx] = C[i * DL + j] - T2[i * DL + j]; }  // S_t
+    FOR_CM(d, d, i, j) o[d + i + j * d] = C[i * DL + j] - T2[i * DL + j];                       // S_t
     if (t == 0) break;
 
     // (q_{t-1}, P_{t-1})
@@ -335,10 +465,7 @@ __global__ __launch_bounds__(256) void k_smoother_tiled(KArgs a) {
       // The expanded update treats P as exactly symmetric (it uses (P K)^T for K^T P).  Without this
       // symmetrisation the antisymmetric rounding component is NOT contracted by (I - F K^T) and grows
       // exponentially for unit-root models (polynomial trends with dense W): see DESIGN.md 4.3.
-      for (int idx = tid; idx < dd; idx += 256) {
-        const int i = idx / d, j = idx % d;
-        if (i < j) { const double v = 0.5 * (P[i * DL + j] + P[j * DL + i]); P[i * DL + j] = v; P[j * DL + i] = v; }
-      }
+      FOR_CM(d, d, i, j) if (i < j) { const double v = 0.5 * (P[i * DL + j] + P[j * DL + i]); P[i * DL + j] = v; P[j * DL + i] = v; }
     } else if (tid < d) rv[tid] = qv[tid];
     __syncthreads();
     if (dtt == 0.0) {
@@ -356,7 +483,7 @@ __global__ __launch_bounds__(256) void k_smoother_tiled(KArgs a) {
   }
   __syncthreads();
   bool bad = false;
-  for (int idx = tid; idx < dd; idx += 256) bad |= !isfinite(T2[(idx % d) * DL + idx / d]) || !isfinite(C[(idx % d) * DL + idx / d]);
+  FOR_CM(d, d, i, j) bad |= !isfinite(T2[i * DL + j]) || !isfinite(C[i * DL + j]);
   if (__syncthreads_or(bad)) st |= DLM_ST_NONFINITE;
   if (a.status && tid == 0 && st) atomicOr(&a.status[n], st);
 }
@@ -369,7 +496,7 @@ hipError_t launch_tiled_filter(const KArgs& a, hipStream_t s) {
   const size_t lds = tiled_filter_lds_bytes();
   hipError_t e = set_lds((const void*)k_filter_tiled, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_filter_tiled, dim3(a.N), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k_filter_tiled, dim3(a.N), dim3(NT), lds, s, a);
   return hipGetLastError();
 }
 
@@ -377,7 +504,7 @@ hipError_t launch_tiled_smoother(const KArgs& a, hipStream_t s) {
   const size_t lds = tiled_smoother_lds_bytes();
   hipError_t e = set_lds((const void*)k_smoother_tiled, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_smoother_tiled, dim3(a.N), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k_smoother_tiled, dim3(a.N), dim3(NT), lds, s, a);
   return hipGetLastError();
 }
 
