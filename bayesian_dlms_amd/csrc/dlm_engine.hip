@@ -28,6 +28,8 @@ struct dlm_engine {
   size_t side_bytes = 0;
   double* xplus = nullptr;    // simulated states x+ of the simulation smoother [N][T+1][d]
   size_t xplus_bytes = 0;
+  double* ystar = nullptr;    // y - y+ of the simulation smoother (multivariate path) [N][T][p]
+  size_t ystar_bytes = 0;
   ncclComm_t comm = nullptr;
   bool has_comm = false;
 };
@@ -178,6 +180,16 @@ int ensure_xplus(dlm_engine* e, const KArgs& k) {
   return DLM_OK;
 }
 
+int ensure_ystar(dlm_engine* e, const KArgs& k) {
+  const size_t need = sizeof(double) * (size_t)k.N * (size_t)k.T * (size_t)k.p;
+  if (need > e->ystar_bytes) {
+    if (e->ystar) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->ystar)); e->ystar = nullptr; e->ystar_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->ystar, need));
+    e->ystar_bytes = need;
+  }
+  return DLM_OK;
+}
+
 // want_side: the caller will run the fast backward pass on this filter's output
 int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
   if (use_fast(k) && !k.prior) {
@@ -252,6 +264,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->arena) (void)hipFree(e->arena);
   if (e->side) (void)hipFree(e->side);
   if (e->xplus) (void)hipFree(e->xplus);
+  if (e->ystar) (void)hipFree(e->ystar);
   if (e->sp_dev) (void)hipFree(e->sp_dev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -368,7 +381,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   stage_model(st, k, model, params, opts);
   const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
   st.in(&k.y, y, y ? N * T * p : 0);
-  st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + 1 : d) : 0);
+  st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + p : d) : 0);
   if (forward) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
   else st.in(&k.filt_in, filt_in, N * (T + 1) * rec);
   st.out(&k.theta, theta, N * (T + 1) * d);
@@ -387,7 +400,13 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       HIP_TRY(e, dlm::launch_sparse16_simsmooth(k, e->sparse_k, e->sp_dev, e->side, e->xplus, e->stream));
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
-    if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need the structured fast path");
+    if (simflag && use_tiled(k)) {
+      if ((rc = ensure_xplus(e, k)) || (rc = ensure_ystar(e, k))) return rc;
+      e->variant = "tiled-simsmooth";
+      HIP_TRY(e, dlm::launch_tiled_simsmooth(k, e->xplus, e->ystar, e->stream));
+      return st.finish(opts->flags & DLM_OPT_ASYNC);
+    }
+    if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need a fast path (structured d <= 15 or 16 <= d <= 48)");
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }

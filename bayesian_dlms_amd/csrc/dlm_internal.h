@@ -61,6 +61,8 @@ hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_d
 bool tiled_supported(const KArgs& a);
 hipError_t launch_tiled_filter(const KArgs& a, hipStream_t s);
 hipError_t launch_tiled_smoother(const KArgs& a, hipStream_t s);   // needs a.y (innovations are recomputed)
+// simulation-smoother FFBS (forward SIM pass + mean-only backward pass); xplus [N][T+1][d], ystar [N][T][p]
+hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s);
 
 // ---- SVD filter / sampler (one-sided Jacobi in LDS), dlm_svd.hip ----------------------
 size_t svd_filter_lds_bytes(int d, int p);

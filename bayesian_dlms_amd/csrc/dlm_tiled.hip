@@ -170,6 +170,28 @@ __device__ __forceinline__ void load_cm(int tid, const double* src, int rows, in
   FOR_CM(rows, cols, i, j) dst[i * ld + j] = src[i + j * rows];
 }
 
+// In-place lower Cholesky of the n x n LDS matrix A (row-major, leading dimension ld); one-off per series
+// (simulation-smoother set-up), so a plain right-looking factorisation with workgroup barriers.
+__device__ bool chol_block(int tid, int n, double* A, int ld) {
+  bool bad = false;
+  for (int k = 0; k < n; ++k) {
+    __syncthreads();
+    double akk = A[k * ld + k];
+    if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
+    const double lkk = sqrt(akk), inv = 1.0 / lkk;
+    __syncthreads();
+    if (tid >= k && tid < n) A[tid * ld + k] = (tid == k) ? lkk : A[tid * ld + k] * inv;
+    __syncthreads();
+    for (int j = (tid >> 6) + k + 1; j < n; j += NW)
+      for (int i = (tid & 63); i < n; i += 64)
+        if (i >= j) A[i * ld + j] = fma(-A[i * ld + k], A[j * ld + k], A[i * ld + j]);
+  }
+  __syncthreads();
+  for (int j = (tid >> 6); j < n; j += NW) for (int i = (tid & 63); i < n; i += 64) if (i < j) A[i * ld + j] = 0.0;
+  __syncthreads();
+  return bad;
+}
+
 // Inverse of the SPD n x n matrix Q (LDS, ld PL) by Newton-Schulz refinement of a warm start:
 //   E = I - Q X ,  X <- X + X E        (||E|| squares every iteration)
 // X holds the inverse of the previous time step's Q on entry (Q_t changes slowly: one or two iterations
@@ -220,6 +242,8 @@ __device__ __forceinline__ bool spd_inverse_warm(int tid, int n, const double* Q
 bool tiled_supported(const KArgs& a) { return a.d >= 16 && a.d <= 48 && a.p <= 32; }
 
 constexpr int FILT_DOUBLES = 4 * BIG + 3 * MID + 2 * SML + 8 * 48;    // 133 KB (inverse scratch aliases Tm / Kg)
+constexpr int FILT_SIM_DOUBLES = FILT_DOUBLES + BIG + SML + 3 * 48;   // + chol(W), chol(V), x+ (48), normals (96): 158 KB
+constexpr int SIMS_DOUBLES = 2 * BIG + 3 * MID + 4 * SML + 16 * 48;   // mean-only backward pass: 115 KB
 constexpr int SMTH_DOUBLES = 4 * BIG + 3 * MID + 4 * SML + 10 * 48;   // 150.9 KB
 size_t tiled_filter_lds_bytes() { return sizeof(double) * FILT_DOUBLES + 16; }
 size_t tiled_smoother_lds_bytes() { return sizeof(double) * SMTH_DOUBLES + 16; }
@@ -227,7 +251,11 @@ size_t tiled_smoother_lds_bytes() { return sizeof(double) * SMTH_DOUBLES + 16; }
 // ---------------------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a) {
+// SIM: first half of the Durbin-Koopman simulation smoother (see dlm_sparse16.hip): simulate (x+, y+),
+// filter y* = y - y+ from a zero prior mean, write x+ [N][T+1][d] and y* [N][T][p].  Normals of record t:
+// components 0..d-1 state noise (record 0: the initial state), d..d+p-1 observation noise.
+template <bool SIM>
+__global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict__ xplus, double* __restrict__ ystar) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, frec = p + p * p;
@@ -240,6 +268,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a) {
   // scratch of the inverse, aliasing buffers that are idle between the forecast and the gain
   double* Qm = Tm;           double* Es = Tm + SML;   double* Tn = Kg;         double* Li = Es;
   bool warm = false;
+  double* Lw = sm + FILT_DOUBLES;  double* Lv = Lw + BIG;   double* xv = Lv + SML;   double* zv = xv + 48;   // SIM only
   const double* V = a.V + (size_t)n * a.v_stride;
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* y = a.y + (size_t)n * T * p;
@@ -247,7 +276,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a) {
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * frec : nullptr;
   int st = 0;
 
-  zero_lds(tid, sm, FILT_DOUBLES);
+  zero_lds(tid, sm, SIM ? FILT_SIM_DOUBLES : FILT_DOUBLES);
   __syncthreads();
   load_cm(tid, a.C0 + (size_t)n * a.c0_stride, d, d, C, DL);
   load_cm(tid, a.F, d, p, Fm, PL);
@@ -255,6 +284,23 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a) {
   load_cm(tid, a.G + (size_t)gcur * dd, d, d, Gm, DL);
   if (tid < d) mv[tid] = (a.m0 + (size_t)n * a.m0_stride)[tid];
   __syncthreads();
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  const double* zin = (SIM && a.z) ? a.z + (size_t)n * (T + 1) * (d + p) : nullptr;
+  double* xp = SIM ? xplus + (size_t)n * (T + 1) * d : nullptr;
+  double* ys = SIM ? ystar + (size_t)n * T * p : nullptr;
+  if (SIM) {
+    // factors chol(W), chol(V), and x+_0 = m0 + chol(C0) z_0 (chol(C0) in R, which is idle here)
+    load_cm(tid, W, d, d, Lw, DL);
+    load_cm(tid, V, p, p, Lv, PL);
+    for (int idx = tid; idx < 48 * DL; idx += NT) R[idx] = C[idx];
+    if (tid < d) zv[tid] = zin ? zin[tid] : philox_normal(a.seed, series, 0u, (unsigned)tid);
+    const bool b1 = chol_block(tid, d, Lw, DL), b2 = chol_block(tid, p, Lv, PL), b3 = chol_block(tid, d, R, DL);
+    if (b1 || b2 || b3) st |= DLM_ST_NOT_PD;
+    if (tid < d) { double sx = mv[tid]; for (int k = 0; k <= tid; ++k) sx = fma(R[tid * DL + k], zv[k], sx); xv[tid] = sx; }
+    __syncthreads();
+    if (tid < d) { xp[tid] = xv[tid]; mv[tid] = 0.0; }     // y* is filtered from a zero prior mean
+    __syncthreads();
+  }
   FOR_CM(d, d, i, j) out[d + i + j * d] = C[i * DL + j];
   if (tid < d) out[tid] = mv[tid];
   if (fq) for (int i = tid; i < frec; i += NT) fq[i] = __builtin_nan("");
@@ -292,8 +338,32 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a) {
     gemm_t<true, false, 0>(tid, pt16, pt16, kd, Fm, PL, RF, PL, Q, PL);
     __syncthreads();
     FOR_CM(p, p, i, j) Q[i * PL + j] += V[i + j * p];
+    if (SIM) {
+      // x+_t = G x+_{t-1} + L_W z_x ;  y+_t = F^T x+_t + L_V z_y   (tv = new x+, then copied back)
+      if (tid < d + p) zv[tid] = zin ? zin[(size_t)(t + 1) * (d + p) + tid] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)tid);
+      __syncthreads();
+      double xn = 0.0;
+      if (tid < d) {
+        if (dt == 0.0) xn = xv[tid];
+        else {
+          const double sdt = sqrt(dt);
+          for (int k = 0; k < d; ++k) xn = fma(Gm[tid * DL + k], xv[k], xn);
+          for (int k = 0; k <= tid; ++k) xn = fma(Lw[tid * DL + k] * sdt, zv[k], xn);
+        }
+      }
+      __syncthreads();
+      if (tid < d) { xv[tid] = xn; xp[(size_t)(t + 1) * d + tid] = xn; }
+      __syncthreads();
+    }
     if (tid < p) {
-      const double yv = y[(size_t)t * p + tid];
+      double yv = y[(size_t)t * p + tid];
+      if (SIM) {
+        double yp = 0.0;
+        for (int k = 0; k < d; ++k) yp = fma(Fm[k * PL + tid], xv[k], yp);
+        for (int k = 0; k <= tid; ++k) yp = fma(Lv[tid * PL + k], zv[d + k], yp);
+        yv = yv - yp;                                  // NaN (missing) stays NaN
+        ys[(size_t)t * p + tid] = yv;
+      }
       ob[tid] = (yv == yv) ? 1.0 : 0.0;
       ev[tid] = (yv == yv) ? yv - fv[tid] : 0.0;
     }
@@ -488,15 +558,182 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a) {
   if (a.status && tid == 0 && st) atomicOr(&a.status[n], st);
 }
 
+// ---------------------------------------------------------------------------------------
+// second half of the simulation smoother for general p: mean-only backward pass on y*, theta = s* + x+,
+// Gibbs statistics (Gibbs.scala:23-78, GibbsWishart.scala:16-35) on the fly.  No covariance recursion:
+//   q_{t-1} = G^T [ q + F (Qm^-1 e - K^T q) ],  K = C F Vm^-1,  Qm^-1 = Vm^-1 - Vm^-1 F^T K
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* __restrict__ xplus,
+                                                        const double* __restrict__ ystar) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd;
+  const int dt16 = (d + 15) / 16, pt16 = (p + 15) / 16, kd = (d + 3) / 4, kp = (p + 3) / 4;
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
+  double* C = sm;            double* OUT = C + BIG;
+  double* Fm = OUT + BIG;    double* CF = Fm + MID;   double* Kg = CF + MID;
+  double* Vi = Kg + MID;     double* Qi = Vi + SML;   double* X = Qi + SML;    double* Li = X + SML;
+  double* mv = Li + SML;     double* mp = mv + 48;    double* qv = mp + 48;    double* rv = qv + 48;
+  double* ev = rv + 48;      double* uv = ev + 48;    double* ob = uv + 48;    double* obp = ob + 48;
+  double* tv = obp + 48;     double* thn = tv + 48;   double* thc = thn + 48;  double* dfv = thc + 48;
+  double* ssy = dfv + 48;    double* nob = ssy + 48;  double* ssd = nob + 48;  double* flagv = ssd + 48;
+  const double* V = a.V + (size_t)n * a.v_stride;
+  const double* y = a.y ? a.y + (size_t)n * T * p : nullptr;
+  const double* ys = ystar + (size_t)n * T * p;
+  const double* xp = xplus + (size_t)n * (T + 1) * d;
+  const double* fin = a.filt_in + (size_t)n * (T + 1) * rec;
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  int st = 0;
+
+  zero_lds(tid, sm, SIMS_DOUBLES);
+  __syncthreads();
+  load_cm(tid, a.F, d, p, Fm, PL);
+  if (tid < p) obp[tid] = -1.0;
+  double pre[6], mcur = 0.0, mnext = 0.0;
+  {
+    const double* r = fin + (size_t)T * rec;
+    int q = 0;
+    for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
+    if (tid < d) { mcur = r[tid]; mnext = (T > 0) ? (r - rec)[tid] : 0.0; }
+  }
+  for (int t = T; t >= 0; --t) {
+    __syncthreads();
+    {
+      int q = 0;
+      for (int j = tid >> 6; j < d; j += NW, ++q) if ((tid & 63) < d) C[(tid & 63) * DL + j] = pre[q];
+      if (tid < d) { mv[tid] = mcur; mp[tid] = mnext; mcur = mnext; }
+      if (t > 0) {
+        const double* r = fin + (size_t)(t - 1) * rec;
+        q = 0;
+        for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
+        if (tid < d) mnext = (t > 1) ? (r - rec)[tid] : 0.0;
+      }
+    }
+    if (a.f_stride && t > 0) load_cm(tid, a.F + (size_t)(t - 1) * a.f_stride, d, p, Fm, PL);
+    if (tid < p) { const double yv = (t > 0) ? ys[(size_t)(t - 1) * p + tid] : __builtin_nan(""); ob[tid] = (yv == yv) ? 1.0 : 0.0; tv[tid] = yv; }
+    const double xcur = (tid < d) ? xp[(size_t)t * d + tid] : 0.0;
+    __syncthreads();
+    bool any = false, same = true;
+    for (int j = 0; j < p; ++j) { any |= ob[j] != 0.0; same &= ob[j] == obp[j]; }
+    const double* Gt = a.G + (size_t)((a.g_index && t > 0) ? a.g_index[t - 1] : 0) * dd;   // G of the step INTO record t
+    const double dtt = (a.dt && t > 0) ? a.dt[t - 1] : 1.0;
+
+    // theta_t = m*_t + C_t q_t + x+_t
+    if (tid < d) {
+      double s = mv[tid] + xcur;
+      for (int k = 0; k < d; ++k) s = fma(C[tid * DL + k], qv[k], s);
+      thc[tid] = s;
+      if (thout) thout[(size_t)t * d + tid] = s;
+    }
+    __syncthreads();
+    if (a.stats) {
+      if (t < T) {   // system innovation theta_{t+1} - G_{t+1} theta_t
+        const double* Gn = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
+        const double dtn = a.dt ? a.dt[t] : 1.0;
+        if (tid < d) {
+          double s = thn[tid];
+          if (dtn == 0.0) s -= thc[tid];
+          else for (int k = 0; k < d; ++k) s = fma(-Gn[tid + k * d], thc[k], s);
+          const double dts = (dtn == 0.0) ? 1.0 : dtn;
+          dfv[tid] = s / sqrt(dts);
+          ssd[tid] = fma(s, s / dts, ssd[tid]);
+        }
+        __syncthreads();
+        if (outer) FOR_CM(d, d, i, j) OUT[i * DL + j] = fma(dfv[i], dfv[j], OUT[i * DL + j]);
+      }
+      if (t > 0 && y && tid < p) {   // observation residual of theta_t against the ORIGINAL y_t
+        const double yv = y[(size_t)(t - 1) * p + tid];
+        if (yv == yv) {
+          double f = 0.0;
+          for (int k = 0; k < d; ++k) f = fma(Fm[k * PL + tid], thc[k], f);
+          ssy[tid] = fma(yv - f, yv - f, ssy[tid]); nob[tid] += 1.0;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < d) thn[tid] = thc[tid];
+    if (t == 0) break;
+
+    if (any) {
+      if (!same) {
+        __syncthreads();
+        FOR_CM(p, p, i, j) Vi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0);
+        if (spd_inverse(tid, p, Vi, Li, (int*)flagv)) st |= DLM_ST_NOT_PD;
+        FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Vi[i * PL + j] = 0.0;
+        if (tid < p) obp[tid] = ob[tid];
+        __syncthreads();
+      }
+      gemm_t<false, false, 0>(tid, dt16, pt16, kd, C, DL, Fm, PL, CF, PL);            // C F
+      if (tid < d) {
+        double s = 0.0;
+        if (dtt == 0.0) s = mp[tid];
+        else for (int k = 0; k < d; ++k) s = fma(Gt[tid + k * d], mp[k], s);
+        rv[tid] = s;   // a*_t
+      }
+      __syncthreads();
+      gemm_t<false, false, 0>(tid, dt16, pt16, kp, CF, PL, Vi, PL, Kg, PL);           // K = C F Vm^-1
+      if (tid < p) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Fm[k * PL + tid], rv[k], s); ev[tid] = (ob[tid] != 0.0) ? tv[tid] - s : 0.0; }
+      __syncthreads();
+      gemm_t<true, false, 0>(tid, pt16, pt16, kd, Fm, PL, Kg, PL, X, PL);             // F^T K
+      __syncthreads();
+      gemm_t<false, false, 2>(tid, pt16, pt16, kp, Vi, PL, X, PL, Qi, PL, Vi);        // Qm^-1
+      __syncthreads();
+      if (tid < p) {
+        double s = 0.0;
+        for (int j = 0; j < p; ++j) s = fma(Qi[tid * PL + j], ev[j], s);              // u = Qm^-1 e
+        for (int k = 0; k < d; ++k) s = fma(-Kg[k * PL + tid], qv[k], s);             // - K^T q
+        uv[tid] = s;
+      }
+      __syncthreads();
+      if (tid < d) { double s = qv[tid]; for (int j = 0; j < p; ++j) s = fma(Fm[tid * PL + j], uv[j], s); rv[tid] = s; }
+    } else if (tid < d) rv[tid] = qv[tid];
+    __syncthreads();
+    if (tid < d) {
+      double s = 0.0;
+      if (dtt == 0.0) s = rv[tid];
+      else for (int k = 0; k < d; ++k) s = fma(Gt[k + tid * d], rv[k], s);             // q = G^T r
+      qv[tid] = s;
+    }
+  }
+  __syncthreads();
+  bool bad = (tid < d) && !isfinite(thn[tid]);
+  if (__syncthreads_or(bad)) st |= DLM_ST_NONFINITE;
+  if (a.stats) {
+    const int L = stats_len(d, p, a.flags);
+    double* so = a.stats + (size_t)n * L;
+    if (tid < p) { so[tid] = ssy[tid]; so[p + tid] = nob[tid]; }
+    if (outer) FOR_CM(d, d, i, j) so[2 * p + i + j * d] = OUT[i * DL + j];
+    else if (tid < d) so[2 * p + tid] = ssd[tid];
+    if (tid == 0) so[L - 1] = (double)T;
+  }
+  if (a.status && tid == 0 && st) atomicOr(&a.status[n], st);
+}
+
 static hipError_t set_lds(const void* fn, size_t bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 hipError_t launch_tiled_filter(const KArgs& a, hipStream_t s) {
   const size_t lds = tiled_filter_lds_bytes();
-  hipError_t e = set_lds((const void*)k_filter_tiled, lds);
+  hipError_t e = set_lds((const void*)k_filter_tiled<false>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_filter_tiled, dim3(a.N), dim3(NT), lds, s, a);
+  hipLaunchKernelGGL(k_filter_tiled<false>, dim3(a.N), dim3(NT), lds, s, a, (double*)nullptr, (double*)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s) {
+  size_t lds = sizeof(double) * FILT_SIM_DOUBLES + 16;
+  hipError_t e = set_lds((const void*)k_filter_tiled<true>, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_filter_tiled<true>, dim3(a.N), dim3(NT), lds, s, a, xplus, ystar);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  KArgs b = a;
+  b.filt_in = a.filt;
+  lds = sizeof(double) * SIMS_DOUBLES + 16;
+  e = set_lds((const void*)k_simsmooth_tiled, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_simsmooth_tiled, dim3(a.N), dim3(NT), lds, s, b, (const double*)xplus, (const double*)ystar);
   return hipGetLastError();
 }
 

@@ -145,9 +145,9 @@ int dlm_last_timing(dlm_engine *e, double ms[2]);
  *                            [ssy(p) | n(p) | outer(d*d) | T]       (DLM_OPT_STATS_OUTER)
  * DLM_OPT_FFBS_SIMSMOOTH: draw theta = E[x | y - y+] + x+ with (x+, y+) simulated from the model
  * (Durbin & Koopman 2002): the same distribution as FFBS without a d x d factorisation per step
- * (fast path: d <= 15, p = 1, structured G, regular grid; otherwise the flag is ignored).  Normals:
- * d + 1 per record (state noise, then observation noise), so injected z is [N][T+1][d+1]; `cond` is
- * not produced.
+ * (fast paths: d <= 15, p = 1, structured G, regular grid; or 16 <= d <= 48, p <= 32; otherwise the
+ * flag is ignored).  Normals: d + p per record (state noise, then observation noise), so injected z is
+ * [N][T+1][d+p]; `cond` is not produced.
  * The draw uses the lower Cholesky factor of H_t (theta = h + L z); the reference's eigSym
  * factor has LAPACK-defined signs and an unseedable RNG, so draw-level parity with Breeze is
  * not defined -- see DESIGN.md. */

@@ -686,3 +686,52 @@ def test_status_flags_nonfinite_and_not_pd(eng):
     assert out["status"][0] & _lib.ST_NOT_PD
     ok = eng.filter_smooth(mat, bad, y[:1], flags=_lib.OPT_FORCE_GENERIC)   # the generic RTS path handles V = 0
     assert ok["status"][0] == 0 and np.all(np.isfinite(ok["smooth"]))
+
+
+def dk_reference_draw_mv(mat, p, y, z):
+    """Multivariate version of dk_reference_draw: z [T+1][d+p] (state noise, then observation noise)."""
+    d, q, T = mat.d, mat.p, mat.T
+    G = oracle.from_cm(mat.G[: d * d], d, d); F = oracle.from_cm(mat.F[: d * q], d, q)
+    Lc, Lw, Lv = np.linalg.cholesky(p.c0), np.linalg.cholesky(p.w), np.linalg.cholesky(p.v)
+    x = p.m0 + Lc @ z[0, :d]
+    xs, yp = [x], np.empty((T, q))
+    for t in range(1, T + 1):
+        x = G @ x + Lw @ z[t, :d]
+        xs.append(x)
+        yp[t - 1] = F.T @ x + Lv @ z[t, d:]
+    om = omodel(mat)
+    f = oracle.kf_filter(om, p.v, p.w, np.zeros(d), p.c0, y - yp)
+    s = oracle.smoother(om, f, compat_q1=False)
+    return s["s"] + np.array(xs)
+
+
+def test_ffbs_simulation_smoother_multivariate(eng):
+    """DLM_OPT_FFBS_SIMSMOOTH on the tiled path (d = 20, p = 10, dense W, correlated V, missing data)."""
+    rng = np.random.default_rng(77)
+    mod = Dlm.polynomial(2)
+    for _ in range(9):
+        mod = mod * Dlm.polynomial(2)
+    T, N, d, q = 60, 3, 20, 10
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    A = rng.standard_normal((d, d)); B = rng.standard_normal((q, q))
+    p = DlmParameters(B @ B.T / q + 0.5 * np.eye(q), A @ A.T / d + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d) * 2.0)
+    y = rng.standard_normal((N, T, q)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    z = rng.standard_normal((N, T + 1, d + q))
+    om = omodel(mat)
+    for flags in (_lib.OPT_FFBS_SIMSMOOTH, _lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_STATS_OUTER):
+        out = eng.ffbs(mat, p, y, z=z, flags=flags)
+        assert eng.last_variant == "tiled-simsmooth" and np.all(out["status"] == 0)
+        for n in range(N):
+            ref = dk_reference_draw_mv(mat, p, y[n], z[n])
+            np.testing.assert_allclose(out["theta"][n], ref, rtol=1e-6, atol=1e-7)
+            st = oracle.gibbs_stats(om, y[n], ref, want_outer=bool(flags & _lib.OPT_STATS_OUTER))
+            np.testing.assert_allclose(out["stats"][n, :q], st["ssy"], rtol=1e-6)
+            np.testing.assert_array_equal(out["stats"][n, q:2 * q], st["n"])
+            if flags & _lib.OPT_STATS_OUTER:
+                np.testing.assert_allclose(out["stats"][n, 2 * q:2 * q + d * d], st["outer"], rtol=1e-5, atol=1e-6)
+            else:
+                np.testing.assert_allclose(out["stats"][n, 2 * q:2 * q + d], st["ss"], rtol=1e-6)
+    out = eng.ffbs(mat, p, y, seed=11, series_offset=4, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    zz = oracle.normals(11, 4 + 2, T + 1, d + q)
+    np.testing.assert_allclose(out["theta"][2], dk_reference_draw_mv(mat, p, y[2], zz), rtol=1e-6, atol=1e-7)

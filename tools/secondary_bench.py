@@ -41,6 +41,19 @@ def main():
         fwd, bwd = eng.last_timing()
         print(json.dumps({"config": "C4 filter+smooth, d=40, p=20, N=2000, T=1000", "variant": eng.last_variant,
                           "ms": dt * 1e3, "forward_ms": fwd, "backward_ms": bwd, "series_steps_per_s": N * T / dt}))
+    if "c4ffbs" in which:
+        from bayesian_dlms_amd import _lib
+        mod = Dlm.polynomial(2)
+        for _ in range(19): mod = mod * Dlm.polynomial(2)
+        N, T = 256, 200
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        rng = np.random.default_rng(40); A = rng.standard_normal((40, 40))
+        p = DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
+        y = torch.as_tensor(rng.standard_normal((N, T, 20)).cumsum(axis=1), device=dev)
+        for name, fl in (("reference-form", 0), ("simulation smoother", _lib.OPT_FFBS_SIMSMOOTH)):
+            dt = timeit(lambda: eng.ffbs(mat, p, y, seed=1, want_theta=False, flags=_lib.OPT_STATS_OUTER | fl), reps=1)
+            print(json.dumps({"config": f"C4 FFBS + outer-product stats ({name}), d=40, p=20, N=256, T=200", "variant": eng.last_variant,
+                              "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
     if "c5" in which:
         mod, p = seasonal_c2(); N, T = 10000, 200
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
