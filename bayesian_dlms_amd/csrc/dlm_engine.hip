@@ -22,8 +22,9 @@ struct dlm_engine {
   size_t arena_bytes = 0;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around the forward and backward kernels
   bool timed = false;
-  dlm::SparseT* sp_dev = nullptr;  // [2]: row table, column table of G (structured fast path)
-  int sparse_k = 0;           // 0: G is not structured (dense MFMA path)
+  dlm::SparseT* sp_dev = nullptr;  // [2 n_g]: row table, column table of every G (structured fast path)
+  size_t sp_count = 0;
+  int sparse_k = 0;           // 0: some G is not structured (dense MFMA path, regular grids only)
   double* side = nullptr;     // forward->backward innovations buffer of the fused fast path
   size_t side_bytes = 0;
   double* xplus = nullptr;    // simulated states x+ of the simulation smoother [N][T+1][d]
@@ -121,7 +122,7 @@ int check_common(dlm_engine* e, const dlm_model_desc* m, const dlm_params_desc* 
 // model + params -> staged KArgs fields
 void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params_desc* p, const dlm_options* o) {
   const size_t d = m->d, pp = m->p, T = m->T, N = m->N;
-  k.d = m->d; k.p = m->p; k.T = m->T; k.N = m->N;
+  k.d = m->d; k.p = m->p; k.T = m->T; k.N = m->N; k.n_g = m->n_g;
   k.f_stride = m->f_stride; k.v_stride = p->v_stride; k.w_stride = p->w_stride;
   k.m0_stride = p->m0_stride; k.c0_stride = p->c0_stride;
   k.flags = o->flags; k.seed = o->seed; k.series_offset = o->series_offset;
@@ -135,27 +136,37 @@ void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params
   st.in(&k.C0, p->C0, p->c0_stride ? (N - 1) * (size_t)p->c0_stride + d * d : d * d);
 }
 
-bool use_fast(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::mfma16_supported(k); }
+bool fast_shape_ok(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::fast_shape(k); }
+// d <= 15, p = 1 fast path: the structured kernels take any time grid, the dense-G MFMA kernels a regular one
+bool use_fast(const dlm_engine* e, const KArgs& k) { return fast_shape_ok(k) && (e->sparse_k > 0 || dlm::mfma16_supported(k)); }
 bool use_tiled(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::tiled_supported(k); }
 
-// Inspect G (one table entry, fast path only) and upload its sparse tables when it is
+// Inspect every G of the table (fast-path shapes only) and upload the sparse tables when all of them are
 // structured.  `G_user` is the caller's pointer (host or device according to host_mode).
 int analyse_g(dlm_engine* e, const KArgs& k, const double* G_user, bool host_mode) {
   e->sparse_k = 0;
-  if (!use_fast(k)) return DLM_OK;
-  const size_t dd = (size_t)k.d * k.d;
-  std::vector<double> g(dd);
-  if (host_mode) memcpy(g.data(), G_user, dd * sizeof(double));
+  if (!fast_shape_ok(k)) return DLM_OK;
+  const size_t dd = (size_t)k.d * k.d, ng = (size_t)k.n_g;
+  std::vector<double> g(dd * ng);
+  if (host_mode) memcpy(g.data(), G_user, g.size() * sizeof(double));
   else {
-    HIP_TRY(e, hipMemcpyAsync(g.data(), G_user, dd * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(g.data(), G_user, g.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
-  dlm::SparseT tabs[2];
-  const int K = dlm::sparse16_analyse(g.data(), k.d, &tabs[0], &tabs[1]);
-  if (K > 4) return DLM_OK;
-  if (!e->sp_dev) HIP_TRY(e, hipMalloc((void**)&e->sp_dev, sizeof(tabs)));
-  HIP_TRY(e, hipMemcpyAsync(e->sp_dev, tabs, sizeof(tabs), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));  // tabs is on this stack frame
+  std::vector<dlm::SparseT> tabs(2 * ng);
+  int K = 1;
+  for (size_t q = 0; q < ng; ++q) {
+    const int kq = dlm::sparse16_analyse(g.data() + q * dd, k.d, &tabs[2 * q], &tabs[2 * q + 1]);
+    if (kq > 4) return DLM_OK;
+    K = kq > K ? kq : K;
+  }
+  if (tabs.size() > e->sp_count) {
+    if (e->sp_dev) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->sp_dev)); e->sp_dev = nullptr; }
+    HIP_TRY(e, hipMalloc((void**)&e->sp_dev, tabs.size() * sizeof(dlm::SparseT)));
+    e->sp_count = tabs.size();
+  }
+  HIP_TRY(e, hipMemcpyAsync(e->sp_dev, tabs.data(), tabs.size() * sizeof(dlm::SparseT), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));  // tabs lives on this stack frame
   e->sparse_k = K;
   return DLM_OK;
 }
@@ -192,7 +203,7 @@ int ensure_ystar(dlm_engine* e, const KArgs& k) {
 
 // want_side: the caller will run the fast backward pass on this filter's output
 int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
-  if (use_fast(k) && !k.prior) {
+  if (use_fast(e, k) && !k.prior) {
     if (want_side) { int rc = ensure_side(e, k); if (rc) return rc; }
     double* side = want_side ? e->side : nullptr;
     if (e->sparse_k) {
@@ -212,14 +223,14 @@ int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
   return DLM_OK;
 }
 
-bool fast_smoother_ok(const KArgs& k) { return use_fast(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1); }
+bool fast_smoother_ok(const dlm_engine* e, const KArgs& k) { return use_fast(e, k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1); }
 
 // have_side: the preceding run_filter(.., want_side = true) of THIS call filled e->side
 int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
-  if (have_side && fast_smoother_ok(k)) {
+  if (have_side && fast_smoother_ok(e, k)) {
     if (e->sparse_k) {
       e->variant = "sparse16";
-      HIP_TRY(e, dlm::launch_sparse16_smoother(k, e->sparse_k, e->sp_dev + 1, e->side, e->stream));
+      HIP_TRY(e, dlm::launch_sparse16_smoother(k, e->sparse_k, e->sp_dev, e->side, e->stream));
     } else {
       e->variant = "mfma16";
       HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->side, e->stream));
@@ -354,7 +365,7 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
-  const bool fused_fast = fast_smoother_ok(k) || use_tiled(k);
+  const bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
   HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
   if ((rc = run_filter(e, k, fused_fast))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));

@@ -9,7 +9,7 @@ namespace dlm {
 struct KArgs {
   int d, p, T, N;
   const double* F; long long f_stride;
-  const double* G; const int* g_index; const double* dt;
+  const double* G; int n_g; const int* g_index; const double* dt;
   const double* V; long long v_stride;
   const double* W; long long w_stride;
   const double* m0; long long m0_stride;
@@ -43,7 +43,8 @@ hipError_t launch_generic_sampler(const KArgs& a, hipStream_t s);
 hipError_t launch_stats_pool(const double* stats, int N, int L, double* pooled, hipStream_t s);
 
 // ---- specialised d <= 16, p == 1 kernels on the fp64 MFMA layout, dlm_mfma16.hip ------
-bool mfma16_supported(const KArgs& a);
+bool mfma16_supported(const KArgs& a);   // dense-G kernels: regular grid only
+bool fast_shape(const KArgs& a);         // d <= 15, p == 1, time-invariant F
 // `side` [N][T+1][2] carries (e_t/Q_t, 1/Q_t) from the forward to the backward pass (NaN = no update)
 hipError_t launch_mfma16_filter(const KArgs& a, double* side, hipStream_t s);
 hipError_t launch_mfma16_smoother(const KArgs& a, const double* side, hipStream_t s);
@@ -51,6 +52,7 @@ hipError_t launch_mfma16_smoother(const KArgs& a, const double* side, hipStream_
 // ---- structured-G variant of the fast path (<= 4 nonzeros per row/column), dlm_sparse16.hip
 struct SparseT { int K; int pad; int idx[16][4]; double val[16][4]; };
 int sparse16_analyse(const double* G_host, int d, SparseT* rows, SparseT* cols);
+// sparse16 kernels take tabs[2 * gi + 0] = rows of G_gi, tabs[2 * gi + 1] = columns of G_gi; K = max count
 // xplus != nullptr: simulation-smoother forward pass (also writes x+ [N][T+1][d])
 hipError_t launch_sparse16_filter(const KArgs& a, int K, const SparseT* rows_dev, double* side, double* xplus, hipStream_t s);
 // tabs_dev[0] = rows of G, tabs_dev[1] = columns of G

@@ -1,5 +1,5 @@
-// Fast path for structured system matrices: d <= 15, p == 1, one G, regular grid, and at
-// most K <= 4 nonzeros in every row AND every column of G.  Every model the reference can
+// Fast path for structured system matrices: d <= 15, p == 1, any time grid (several G(dt) tables,
+// W dt, dt == 0), and at most K <= 4 nonzeros in every row AND every column of every G.  Every model the reference can
 // build satisfies this (polynomial: bidiagonal, seasonal: 2x2 rotation blocks, regression:
 // identity, autoregressive: diagonal; Dlm.scala:139-243), and |+| / |*| keep it
 // (block-diagonal composition, Dlm.scala:107-122, :197-208).  Dense G uses dlm_mfma16.hip.
@@ -147,29 +147,30 @@ __device__ __forceinline__ unsigned long long stamp() {
 #endif
 
 // Z = T X T^T for symmetric X (std layout), T given by the per-column-lane tables idx/val.
-// SYM: use (X + X^T)/2 in the first pass.  The backward recursion needs it: its rank-2 update treats P
-// as exactly symmetric, and an antisymmetric rounding component would otherwise escape the contraction
-// (I - F K^T) . (I - K F^T) and grow exponentially for unit-root models.
-template <int K, bool SYM = false>
+// sym (wave-uniform): replace X by (X + X^T)/2 first.  The backward recursion needs it now and then: its
+// rank-2 update treats P as exactly symmetric, and an antisymmetric rounding component would otherwise
+// escape the contraction (I - F K^T) . (I - K F^T).
+template <int K>
 __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB, const int (&idx)[K],
-                                         const double (&val)[K], int g, int c) {
+                                         const double (&val)[K], int g, int c, bool sym = false) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + c] = x[r];
   wave_sync();
+  if (sym) {
+    d4 xt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt[r] = imgA[c * LD + 4 * r + g];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + c] = 0.5 * (x[r] + xt[r]);
+    wave_sync();
+  }
   d4 y;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    double acc;
-    if (SYM) {
-      acc = (imgA[(4 * r + g) * LD + idx[0]] + imgA[idx[0] * LD + 4 * r + g]) * (0.5 * val[0]);
+    double acc = imgA[(4 * r + g) * LD + idx[0]] * val[0];
 #pragma unroll
-      for (int s = 1; s < K; ++s)
-        acc = fma(imgA[(4 * r + g) * LD + idx[s]] + imgA[idx[s] * LD + 4 * r + g], 0.5 * val[s], acc);
-    } else {
-      acc = imgA[(4 * r + g) * LD + idx[0]] * val[0];
-#pragma unroll
-      for (int s = 1; s < K; ++s) acc = fma(imgA[(4 * r + g) * LD + idx[s]], val[s], acc);
-    }
+    for (int s = 1; s < K; ++s) acc = fma(imgA[(4 * r + g) * LD + idx[s]], val[s], acc);
     y[r] = acc;
   }
 #pragma unroll
@@ -214,7 +215,8 @@ __device__ void wave_chol(double* img, int d, int g, int c) {
 // and writes x+ to `xplus` [N][T+1][d].  Normal (record t, component i) of series n is
 // philox_normal(seed, series_offset + n, t, i), i = 0..d-1 for the state noise (the initial state at
 // record 0), i = d for the observation noise; injected normals are z[N][T+1][d+1].
-template <int K, bool SIM>
+// IRR: irregular time grid (several G tables, W dt, dt == 0); the regular instantiation keeps none of that.
+template <int K, bool SIM, bool IRR>
 __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                      double* __restrict__ side, double* __restrict__ xplus) {
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS + (SIM ? 4 * IMG : 0)];
@@ -245,8 +247,9 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
 
   int idx[K];
   double val[K];
+  int gcur = 0;    // table currently held in idx/val (rows of G_gcur); irregular grids switch per step
 #pragma unroll
-  for (int s = 0; s < K; ++s) { idx[s] = sp->idx[c][s]; val[s] = sp->val[c][s]; }
+  for (int s = 0; s < K; ++s) { idx[s] = sp[0].idx[c][s]; val[s] = sp[0].val[c][s]; }
   d4 w, cc;
   double Fr[4];
   bool vr[4];
@@ -310,8 +313,15 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
   for (int t = 0; t < T; ++t) {
     if ((t & 63) == 0) ychunk = (t + lane < T) ? y[t + lane] : 0.0;
     double yt = uniform_from_lane(ychunk, t & 63);
+    const int gi = (IRR && a.g_index) ? a.g_index[t] : 0;   // uniform: scalar loads
+    const double dt = (IRR && a.dt) ? a.dt[t] : 1.0;
+    if (IRR && gi != gcur) {
+#pragma unroll
+      for (int s = 0; s < K; ++s) { idx[s] = sp[2 * gi].idx[c][s]; val[s] = sp[2 * gi].val[c][s]; }
+      gcur = gi;
+    }
 
-    // advState: a = G m, R = G C G^T + W
+    // advState: a = G m, R = G C G^T + W dt   (dt == 0: a = m, R = C, KalmanFilter.scala:279-280)
     vM[c] = mcol;
     if (SIM) {
       vX[c] = xcol;
@@ -322,26 +332,38 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
         vZ[lane] = zz;
       }
     }
-    d4 R = congruence<K>(cc, imgA, imgB, idx, val, g, c);   // first wave_sync also covers vM, vX, vZ
-    double acol = vM[idx[0]] * val[0];
+    d4 R;
+    double acol;
+    if (dt == 0.0) {
+      wave_sync();
+      R = cc;
+      acol = mcol;
+    } else {
+      R = congruence<K>(cc, imgA, imgB, idx, val, g, c);    // first wave_sync also covers vM, vX, vZ
+      acol = vM[idx[0]] * val[0];
 #pragma unroll
-    for (int s = 1; s < K; ++s) acol = fma(vM[idx[s]], val[s], acol);
+      for (int s = 1; s < K; ++s) acol = fma(vM[idx[s]], val[s], acol);
+    }
     if (SIM) {
       // x+_t = G x+_{t-1} + L_W z ;  y+_t = F^T x+_t + sqrt(V) z_v ;  y*_t = y_t - y+_t
-      double xg = vX[idx[0]] * val[0];
-#pragma unroll
-      for (int s = 1; s < K; ++s) xg = fma(vX[idx[s]], val[s], xg);
       const double* zr = vZ + 16 * (t & 3);
-      double wl;
-      if (wdiag) wl = wsd * zr[c];
-      else { wl = 0.0; for (int k = 0; k <= c && k < d; ++k) wl = fma(imgW[c * LD + k], zr[k], wl); }
-      xcol = vc ? xg + wl : 0.0;
+      if (dt != 0.0) {
+        double xg = vX[idx[0]] * val[0];
+#pragma unroll
+        for (int s = 1; s < K; ++s) xg = fma(vX[idx[s]], val[s], xg);
+        double wl;
+        if (wdiag) wl = wsd * zr[c];
+        else { wl = 0.0; for (int k = 0; k <= c && k < d; ++k) wl = fma(imgW[c * LD + k], zr[k], wl); }
+        xcol = vc ? fma(wl, sqrt(dt), xg) : 0.0;
+      }
       const double yplus = fma(sqV, zr[d], row_sum(Fc * xcol));
       yt = yt - yplus;                                       // NaN (missing) stays NaN
       if (g == 0 && vc) xp[(size_t)(t + 1) * d + c] = xcol;
     }
+    if (dt != 0.0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) R[r] += w[r];
+      for (int r = 0; r < 4; ++r) R[r] = fma(w[r], dt, R[r]);
+    }
 
     // f = F^T a ; RF ; Q = F^T R F + V
     const double f = row_sum(Fc * acol);
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
 // ---------------------------------------------------------------------------------------
 // backward pass: MFMA for P C and C (P C); gathers for G^T M G
 // ---------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool IRR>
 __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                        const double* __restrict__ side) {
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
@@ -418,8 +440,9 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
 
   int idx[K];
   double val[K];
+  int gcur = 0;    // idx/val hold the COLUMNS of G_gcur (the transition into the current record)
 #pragma unroll
-  for (int s = 0; s < K; ++s) { idx[s] = sp->idx[c][s]; val[s] = sp->val[c][s]; }
+  for (int s = 0; s < K; ++s) { idx[s] = sp[1].idx[c][s]; val[s] = sp[1].val[c][s]; }
   double Fr[4];
   bool vr[4];
   int offC[4];
@@ -496,6 +519,12 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
     if (t > 0) {
       // (q_{t-1}, P_{t-1}) from (q_t, P_t).  Column 15 of x1 is P K: park x1 in the idle image
       // and read that column back in both indexings.
+      const int gi = (IRR && a.g_index) ? a.g_index[t - 1] : 0;   // G of the step into record t
+      if (IRR && gi != gcur) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) { idx[s] = sp[2 * gi + 1].idx[c][s]; val[s] = sp[2 * gi + 1].val[c][s]; }
+        gcur = gi;
+      }
       d4 M = P;
       double rcol = qcol;
       if (observed) {
@@ -522,8 +551,9 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       // In this kernel both cross terms use the same vector (P^T K), so the antisymmetric rounding part of
       // P is only rotated by G from step to step (polynomial growth at worst for unit-root G), never
       // amplified by the update: removing it every 8th step keeps it at rounding level.
-      if ((t & 7) == 0) P = congruence<K, true>(M, imgA, imgB, idx, val, g, c);   // G^T sym(M) G
-      else P = congruence<K, false>(M, imgA, imgB, idx, val, g, c);               // (first sync covers vR)
+      // Like Smoothing.smoothStep (Smoothing.scala:41) this always uses the table entry g(dt), also for
+      // dt == 0 where the filter made an identity advance; only polynomial-type g ignore dt, see DESIGN.md.
+      P = congruence<K>(M, imgA, imgB, idx, val, g, c, (t & 7) == 0);              // G^T M G (first sync covers vR)
       qcol = vR[idx[0]] * val[0];
 #pragma unroll
       for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
@@ -564,7 +594,7 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
 //   s*_t = m*_t + C_t q_t ,  q_{t-1} = G^T [ q_t + F (e_t/Q_t - K_t^T q_t) ] ,  K_t = C_t F / V
 // No covariance recursion and no MFMA: O(K d + d^2) work per step.
 // ---------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool IRR>
 __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_simsmooth_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                         const double* __restrict__ side,
                                                         const double* __restrict__ xplus) {
@@ -594,6 +624,7 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_simsmooth_sp16(KArgs a, c
   // rows of G (for G theta) and columns of G (for G^T r)
   int ridx[K], cidx[K];
   double rval[K], cval[K];
+  int grow = 0, gcol = 0;     // tables held: rows of G_grow (step t -> t+1), columns of G_gcol (step t-1 -> t)
 #pragma unroll
   for (int s = 0; s < K; ++s) { ridx[s] = sp[0].idx[c][s]; rval[s] = sp[0].val[c][s]; cidx[s] = sp[1].idx[c][s]; cval[s] = sp[1].val[c][s]; }
   double Fr[4];
@@ -645,11 +676,21 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_simsmooth_sp16(KArgs a, c
     if (a.stats) {
       vT[c] = th;
       wave_sync();
-      if (t < T) {   // system innovation theta_{t+1} - G theta_t (dt = 1 on the fast path)
-        double gth = vT[ridx[0]] * rval[0];
+      if (t < T) {   // system innovation (theta_{t+1} - G_{t+1} theta_t) / sqrt(dt_{t+1})
+        const int gn = (IRR && a.g_index) ? a.g_index[t] : 0;
+        const double dtn = (IRR && a.dt) ? a.dt[t] : 1.0;
+        if (IRR && gn != grow) {
 #pragma unroll
-        for (int s = 1; s < K; ++s) gth = fma(vT[ridx[s]], rval[s], gth);
-        const double df = vc ? thn - gth : 0.0;
+          for (int s = 0; s < K; ++s) { ridx[s] = sp[2 * gn].idx[c][s]; rval[s] = sp[2 * gn].val[c][s]; }
+          grow = gn;
+        }
+        double gth = th;
+        if (dtn != 0.0) {
+          gth = vT[ridx[0]] * rval[0];
+#pragma unroll
+          for (int s = 1; s < K; ++s) gth = fma(vT[ridx[s]], rval[s], gth);
+        }
+        const double df = vc ? (thn - gth) / sqrt(dtn == 0.0 ? 1.0 : dtn) : 0.0;
         ssc = fma(df, df, ssc);
         if (outer) {
           vD[c] = df;
@@ -676,11 +717,21 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_simsmooth_sp16(KArgs a, c
       kc = sum_g(kc) * rV;
       rcol = fma(Fc, eq - row_sum(kc * qcol), qcol);
     }
+    const int gi = (IRR && a.g_index) ? a.g_index[t - 1] : 0;   // G of the step into record t
+    const double dtt = (IRR && a.dt) ? a.dt[t - 1] : 1.0;
+    if (IRR && gi != gcol) {
+#pragma unroll
+      for (int s = 0; s < K; ++s) { cidx[s] = sp[2 * gi + 1].idx[c][s]; cval[s] = sp[2 * gi + 1].val[c][s]; }
+      gcol = gi;
+    }
     vR[c] = rcol;
     wave_sync();
-    qcol = vR[cidx[0]] * cval[0];
+    if (dtt == 0.0) qcol = rcol;
+    else {
+      qcol = vR[cidx[0]] * cval[0];
 #pragma unroll
-    for (int s = 1; s < K; ++s) qcol = fma(vR[cidx[s]], cval[s], qcol);
+      for (int s = 1; s < K; ++s) qcol = fma(vR[cidx[s]], cval[s], qcol);
+    }
     wave_sync();
   }
   if (__ballot(vc && !isfinite(thn)) != 0ull) st |= DLM_ST_NONFINITE;
@@ -725,18 +776,24 @@ int sparse16_analyse(const double* G /* d x d column-major, host */, int d, Spar
 
 template <int K>
 static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, double* xplus, hipStream_t s) {
-  if (xplus) hipLaunchKernelGGL((k_filter_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
-  else hipLaunchKernelGGL((k_filter_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  const bool irr = a.g_index || a.dt;
+  const dim3 grid((a.N + 3) / 4), blk(256);
+  if (xplus && irr) hipLaunchKernelGGL((k_filter_sp16<K, true, true>), grid, blk, 0, s, a, sp, side, xplus);
+  else if (xplus) hipLaunchKernelGGL((k_filter_sp16<K, true, false>), grid, blk, 0, s, a, sp, side, xplus);
+  else if (irr) hipLaunchKernelGGL((k_filter_sp16<K, false, true>), grid, blk, 0, s, a, sp, side, xplus);
+  else hipLaunchKernelGGL((k_filter_sp16<K, false, false>), grid, blk, 0, s, a, sp, side, xplus);
   return hipGetLastError();
 }
 template <int K>
 static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* side, const double* xplus, hipStream_t s) {
-  hipLaunchKernelGGL(k_simsmooth_sp16<K>, dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  if (a.g_index || a.dt) hipLaunchKernelGGL((k_simsmooth_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  else hipLaunchKernelGGL((k_simsmooth_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
   return hipGetLastError();
 }
 template <int K>
 static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
-  hipLaunchKernelGGL(k_smoother_sp16<K>, dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
+  if (a.g_index || a.dt) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
+  else hipLaunchKernelGGL((k_smoother_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
   return hipGetLastError();
 }
 

@@ -538,9 +538,7 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a) {
       FOR_CM(d, d, i, j) if (i < j) { const double v = 0.5 * (P[i * DL + j] + P[j * DL + i]); P[i * DL + j] = v; P[j * DL + i] = v; }
     } else if (tid < d) rv[tid] = qv[tid];
     __syncthreads();
-    if (dtt == 0.0) {
-      if (tid < d) qv[tid] = rv[tid];                                                  // identity advance: P = M, q = r
-    } else {
+    {   // like Smoothing.smoothStep (Smoothing.scala:41): always the table entry g(dt), also for dt == 0
       zero_lds(tid, T2, BIG);                                                          // keep the zero padding exact
       __syncthreads();
       load_cm(tid, Gt, d, d, T2, DL);                                                  // G -> T2

@@ -735,3 +735,64 @@ def test_ffbs_simulation_smoother_multivariate(eng):
     out = eng.ffbs(mat, p, y, seed=11, series_offset=4, flags=_lib.OPT_FFBS_SIMSMOOTH)
     zz = oracle.normals(11, 4 + 2, T + 1, d + q)
     np.testing.assert_allclose(out["theta"][2], dk_reference_draw_mv(mat, p, y[2], zz), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------
+# irregular time grids on the structured fast path (several G(dt) tables, W dt, dt == 0)
+# ------------------------------------------------------------------------------------------
+def test_irregular_grid_structured_fast_path(eng):
+    mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+    gaps = np.array([1, 1, 2, 1, 5, 1, 1, 3, 1, 1, 24, 1, 2, 1, 1] * 8, dtype=np.float64)
+    times = np.cumsum(gaps)
+    mat = materialise(mod, times)
+    assert mat.n_g > 2 and mat.dt is not None and mat.g_index is not None
+    w = np.diag([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4])
+    p = DlmParameters([[1.0]], w, np.zeros(13), np.eye(13))
+    rng = np.random.default_rng(31)
+    y = rng.standard_normal((4, mat.T, 1)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "sparse16" and np.all(out["status"] == 0)
+    for n in range(4):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], 13); sm, S = split(out["smooth"][n], 13)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+    # the simulation smoother on the same grid
+    z = rng.standard_normal((4, mat.T + 1, 14))
+    o2 = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    assert eng.last_variant == "sparse16-simsmooth"
+    om = omodel(mat)
+    G_by_step = [oracle.from_cm(mat.G[gi * 169:(gi + 1) * 169], 13, 13) for gi in mat.g_index]
+    for n in range(2):
+        x = p.m0 + np.linalg.cholesky(p.c0) @ z[n, 0, :13]
+        xs, yp = [x], np.empty((mat.T, 1))
+        for t in range(1, mat.T + 1):
+            x = G_by_step[t - 1] @ x + np.sqrt(np.diag(w) * mat.dt[t - 1]) * z[n, t, :13]
+            xs.append(x); yp[t - 1, 0] = mat.F[:13] @ x + z[n, t, 13]
+        f = oracle.kf_filter(om, p.v, p.w, np.zeros(13), p.c0, y[n] - yp)
+        ref = oracle.smoother(om, f)["s"] + np.array(xs)
+        np.testing.assert_allclose(o2["theta"][n], ref, rtol=1e-7, atol=1e-8)
+        st = oracle.gibbs_stats(om, y[n], ref)
+        np.testing.assert_allclose(o2["stats"][n, 2:15], st["ss"], rtol=1e-7)
+
+
+def test_zero_time_increment(eng):
+    """Two observations at the same time: dt == 0 means no advance (KalmanFilter.scala:279-280)."""
+    for mod, d in ((Dlm.polynomial(2), 2), (Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
+                                             * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2), 16)):
+        times = np.array([1.0, 2.0, 2.0, 3.0, 5.0, 5.0, 6.0])
+        mat = materialise(mod, times)
+        q = mat.p
+        rng = np.random.default_rng(d)
+        p = DlmParameters(np.eye(q) * 0.7, np.eye(d) * 0.3, np.zeros(d), np.eye(d) * 2)
+        y = rng.standard_normal((2, 7, q))
+        for flags in (0, _lib.OPT_FORCE_GENERIC):
+            out = eng.filter_smooth(mat, p, y, flags=flags)
+            for n in range(2):
+                f, s = oracle_filter_smooth(mat, p, y[n])
+                np.testing.assert_allclose(split(out["filt"][n], d)[1], f["C"], rtol=1e-10, atol=1e-11)
+                np.testing.assert_allclose(split(out["smooth"][n], d)[0], s["s"], rtol=1e-9, atol=1e-10)
+                np.testing.assert_allclose(split(out["smooth"][n], d)[1], s["S"], rtol=1e-9, atol=1e-10)
