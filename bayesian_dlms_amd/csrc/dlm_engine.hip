@@ -203,7 +203,7 @@ int ensure_ystar(dlm_engine* e, const KArgs& k) {
 
 // want_side: the caller will run the fast backward pass on this filter's output
 int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
-  if (use_fast(e, k) && !k.prior) {
+  if (use_fast(e, k) && (!k.prior || e->sparse_k)) {   // the dense-G MFMA kernel does not write (a, R) records
     if (want_side) { int rc = ensure_side(e, k); if (rc) return rc; }
     double* side = want_side ? e->side : nullptr;
     if (e->sparse_k) {
@@ -213,7 +213,7 @@ int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
       e->variant = "mfma16";
       HIP_TRY(e, dlm::launch_mfma16_filter(k, side, e->stream));
     }
-  } else if (use_tiled(k) && !k.prior) {
+  } else if (use_tiled(k)) {
     e->variant = "tiled-mfma";
     HIP_TRY(e, dlm::launch_tiled_filter(k, e->stream));
   } else {

@@ -244,6 +244,8 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
   double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
+  char* bpri = a.prior ? (char*)(a.prior + (size_t)n * (T + 1) * rec) : nullptr;   // optional (a_t, R_t) records
+  const __amdgpu_buffer_rsrc_t rpri = make_rsrc(bpri ? bpri : bout, (size_t)(T + 1) * rec * 8);
 
   int idx[K];
   double val[K];
@@ -304,6 +306,11 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
 #pragma unroll
   for (int r = 0; r < 4; ++r) buf_store(rout, bout, offC[r], 0, cc[r]);
   buf_store(rout, bout, offM, 0, mcol);
+  if (bpri) {   // record 0: a = m0, R = C0 (KalmanFilter.scala:117)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf_store(rpri, bpri, offC[r], 0, cc[r]);
+    buf_store(rpri, bpri, offM, 0, SIM ? 0.0 : mcol);
+  }
   if (lane == 0) {
     if (fq) { fq[0] = __builtin_nan(""); fq[1] = __builtin_nan(""); }
     if (sd) { sd[0] = __builtin_nan(""); sd[1] = __builtin_nan(""); }
@@ -365,6 +372,11 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
       for (int r = 0; r < 4; ++r) R[r] = fma(w[r], dt, R[r]);
     }
 
+    if (bpri) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) buf_store(rpri, bpri, offC[r], (t + 1) * recb, R[r]);
+      buf_store(rpri, bpri, offM, (t + 1) * recb, acol);
+    }
     // f = F^T a ; RF ; Q = F^T R F + V
     const double f = row_sum(Fc * acol);
     double rfc = 0.0;

@@ -274,6 +274,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
   const double* y = a.y + (size_t)n * T * p;
   double* out = a.filt + (size_t)n * (T + 1) * rec;
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * frec : nullptr;
+  double* pri = a.prior ? a.prior + (size_t)n * (T + 1) * rec : nullptr;   // optional (a_t, R_t) records
   int st = 0;
 
   zero_lds(tid, sm, SIM ? FILT_SIM_DOUBLES : FILT_DOUBLES);
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
   }
   FOR_CM(d, d, i, j) out[d + i + j * d] = C[i * DL + j];
   if (tid < d) out[tid] = mv[tid];
+  if (pri) { FOR_CM(d, d, i, j) pri[d + i + j * d] = C[i * DL + j]; if (tid < d) pri[tid] = mv[tid]; }
   if (fq) for (int i = tid; i < frec; i += NT) fq[i] = __builtin_nan("");
 
 #ifdef DLM_STAMP
@@ -331,6 +333,11 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
     }
     __syncthreads();
     TSTAMP(0)
+    if (pri) {
+      double* pr = pri + (size_t)(t + 1) * rec;
+      if (tid < d) pr[tid] = av[tid];
+      FOR_CM(d, d, i, j) pr[d + i + j * d] = R[i * DL + j];
+    }
     // forecast: f = F^T a, RF = R F, Q = F^T R F + V
     gemm_t<false, false, 0>(tid, dt16, pt16, kd, R, DL, Fm, PL, RF, PL);
     if (tid < p) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Fm[k * PL + tid], av[k], s); fv[tid] = s; }

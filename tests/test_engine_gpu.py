@@ -796,3 +796,27 @@ def test_zero_time_increment(eng):
                 np.testing.assert_allclose(split(out["filt"][n], d)[1], f["C"], rtol=1e-10, atol=1e-11)
                 np.testing.assert_allclose(split(out["smooth"][n], d)[0], s["s"], rtol=1e-9, atol=1e-10)
                 np.testing.assert_allclose(split(out["smooth"][n], d)[1], s["S"], rtol=1e-9, atol=1e-10)
+
+
+def test_prior_records_on_fast_paths(eng):
+    """(a_t, R_t) -- KfState.at / rt -- from the structured and the tiled forward kernels."""
+    mod, mat, p = seasonal_model(T=50)
+    y = simulate(mat, p, 2, seed=6, missing=0.1)
+    out = eng.filter(mat, p, y, want_prior=True, want_fq=True)
+    assert eng.last_variant == "sparse16"
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[1])
+    a, R = split(out["prior"][1], 13)
+    np.testing.assert_allclose(a, f["a"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(R, f["R"], rtol=1e-9, atol=1e-10)
+    mod2 = Dlm.polynomial(2)
+    for _ in range(7):
+        mod2 = mod2 * Dlm.polynomial(2)
+    mat2 = materialise(mod2, np.arange(1, 21, dtype=np.float64))
+    p2 = DlmParameters(np.eye(8), np.eye(16) * 0.2, np.zeros(16), np.eye(16))
+    y2 = np.random.default_rng(1).standard_normal((2, 20, 8))
+    out2 = eng.filter(mat2, p2, y2, want_prior=True)
+    assert eng.last_variant == "tiled-mfma"
+    f2 = oracle.kf_filter(omodel(mat2), p2.v, p2.w, p2.m0, p2.c0, y2[0])
+    a2, R2 = split(out2["prior"][0], 16)
+    np.testing.assert_allclose(a2, f2["a"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(R2, f2["R"], rtol=1e-9, atol=1e-10)
