@@ -49,8 +49,8 @@ __device__ __forceinline__ double uniform_from_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-bool fast_shape(const KArgs& a) { return a.d <= 15 && a.p == 1 && a.f_stride == 0; }
-bool mfma16_supported(const KArgs& a) { return fast_shape(a) && a.g_index == nullptr && a.dt == nullptr; }
+bool fast_shape(const KArgs& a) { return a.d <= 15 && a.p == 1; }
+bool mfma16_supported(const KArgs& a) { return fast_shape(a) && a.f_stride == 0 && a.g_index == nullptr && a.dt == nullptr; }
 
 // ---------------------------------------------------------------------------------------
 // forward pass

@@ -215,7 +215,8 @@ __device__ void wave_chol(double* img, int d, int g, int c) {
 // and writes x+ to `xplus` [N][T+1][d].  Normal (record t, component i) of series n is
 // philox_normal(seed, series_offset + n, t, i), i = 0..d-1 for the state noise (the initial state at
 // record 0), i = d for the observation noise; injected normals are z[N][T+1][d+1].
-// IRR: irregular time grid (several G tables, W dt, dt == 0); the regular instantiation keeps none of that.
+// IRR: irregular time grid (several G tables, W dt, dt == 0) and/or time-varying F; the regular
+// instantiation keeps none of that.
 template <int K, bool SIM, bool IRR>
 __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                      double* __restrict__ side, double* __restrict__ xplus) {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
   int offC[4];                                   // byte offset of C[4r+g][c] inside a record
   const int offM = (g == 0 && vc) ? c * 8 : OOB; // byte offset of m[c]
   const int recb = rec * 8;
-  const double Fc = vc ? a.F[c] : 0.0;
+  double Fc = vc ? a.F[c] : 0.0;
   double mcol = vc ? m0[c] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -326,6 +327,12 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
 #pragma unroll
       for (int s = 0; s < K; ++s) { idx[s] = sp[2 * gi].idx[c][s]; val[s] = sp[2 * gi].val[c][s]; }
       gcur = gi;
+    }
+    if (IRR && a.f_stride) {                                 // time-varying F (Dlm.regression): F_t = f(time_t)
+      const double* Ft = a.F + (size_t)t * a.f_stride;
+      Fc = vc ? Ft[c] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Fr[r] = vr[r] ? Ft[4 * r + g] : 0.0;
     }
 
     // advState: a = G m, R = G C G^T + W dt   (dt == 0: a = m, R = C, KalmanFilter.scala:279-280)
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
   int offC[4];
   const int offM = (g == 0 && vc) ? c * 8 : OOB;     // store of s[c]: one row group only
   const int offMl = vc ? c * 8 : OOB;                // load of m[c]: every row group
-  const double Fc = vc ? a.F[c] : 0.0;
+  double Fc = vc ? a.F[c] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * r + g;
@@ -500,6 +507,12 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       neq = sd[2 * tp]; niq = sd[2 * tp + 1];
     }
     const bool observed = (iq == iq) && t > 0;
+    if (IRR && a.f_stride && t > 0) {                        // F of the observation at record t
+      const double* Ft = a.F + (size_t)(t - 1) * a.f_stride;
+      Fc = vc ? Ft[c] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Fr[r] = vr[r] ? Ft[4 * r + g] : 0.0;
+    }
 
     // K_t = C_t F / V
     double kcol = 0.0;
@@ -642,7 +655,7 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_simsmooth_sp16(KArgs a, c
   double Fr[4];
   int offC[4];
   const int offMl = vc ? c * 8 : OOB;
-  const double Fc = vc ? a.F[c] : 0.0;
+  double Fc = vc ? a.F[c] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * r + g;
@@ -675,6 +688,12 @@ __global__ __launch_bounds__(256, DLM_FI_WAVES) void k_simsmooth_sp16(KArgs a, c
       neq = sd[2 * tp]; niq = sd[2 * tp + 1];
     }
     const bool observed = (iq == iq) && t > 0;
+    if (IRR && a.f_stride && t > 0) {                        // F of the observation at record t
+      const double* Ft = a.F + (size_t)(t - 1) * a.f_stride;
+      Fc = vc ? Ft[c] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Fr[r] = (4 * r + g < d) ? Ft[4 * r + g] : 0.0;
+    }
 
     // theta_t = m*_t + C_t q_t + x+_t
     vQ[c] = qcol;
@@ -788,7 +807,7 @@ int sparse16_analyse(const double* G /* d x d column-major, host */, int d, Spar
 
 template <int K>
 static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, double* xplus, hipStream_t s) {
-  const bool irr = a.g_index || a.dt;
+  const bool irr = a.g_index || a.dt || a.f_stride;
   const dim3 grid((a.N + 3) / 4), blk(256);
   if (xplus && irr) hipLaunchKernelGGL((k_filter_sp16<K, true, true>), grid, blk, 0, s, a, sp, side, xplus);
   else if (xplus) hipLaunchKernelGGL((k_filter_sp16<K, true, false>), grid, blk, 0, s, a, sp, side, xplus);
@@ -798,13 +817,13 @@ static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, doub
 }
 template <int K>
 static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* side, const double* xplus, hipStream_t s) {
-  if (a.g_index || a.dt) hipLaunchKernelGGL((k_simsmooth_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  if (a.g_index || a.dt || a.f_stride) hipLaunchKernelGGL((k_simsmooth_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
   else hipLaunchKernelGGL((k_simsmooth_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
   return hipGetLastError();
 }
 template <int K>
 static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
-  if (a.g_index || a.dt) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
+  if (a.g_index || a.dt || a.f_stride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side);
   return hipGetLastError();
 }

@@ -820,3 +820,46 @@ def test_prior_records_on_fast_paths(eng):
     a2, R2 = split(out2["prior"][0], 16)
     np.testing.assert_allclose(a2, f2["a"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(R2, f2["R"], rtol=1e-9, atol=1e-10)
+
+
+def test_time_varying_f_regression_on_fast_path(eng):
+    """Dlm.regression (Dlm.scala:159-169): F_t = [1, x_t], composed with a seasonal block; the structured
+    d <= 15 kernels reload F every step."""
+    T = 60
+    rng = np.random.default_rng(77)
+    x = [np.array([v]) for v in rng.standard_normal(T)]
+    mod = Dlm.regression(x) + Dlm.seasonal(12, 2)
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    d = mat.d
+    assert d == 6 and mat.f_stride == d
+    p = DlmParameters([[0.7]], np.diag(rng.uniform(0.05, 0.3, d)), np.zeros(d), np.eye(d) * 2.0)
+    y = rng.standard_normal((3, T, 1)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "sparse16" and np.all(out["status"] == 0)
+    for n in range(3):
+        f, sm = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], d); s_, S = split(out["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(s_, sm["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, sm["S"], rtol=1e-8, atol=1e-9)
+    # simulation smoother with the same time-varying F
+    z = rng.standard_normal((3, T + 1, d + 1))
+    o2 = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    assert eng.last_variant == "sparse16-simsmooth"
+    om = omodel(mat)
+    G = oracle.from_cm(mat.G[:d * d], d, d)
+    Ft = np.asarray(mat.F).reshape(T, d)
+    for n in range(2):
+        xx = p.m0 + np.linalg.cholesky(p.c0) @ z[n, 0, :d]
+        xs, yp = [xx], np.empty((T, 1))
+        for t in range(1, T + 1):
+            xx = G @ xx + np.sqrt(np.diag(p.w)) * z[n, t, :d]
+            xs.append(xx); yp[t - 1, 0] = Ft[t - 1] @ xx + np.sqrt(0.7) * z[n, t, d]
+        f = oracle.kf_filter(om, p.v, p.w, np.zeros(d), p.c0, y[n] - yp)
+        ref = oracle.smoother(om, f)["s"] + np.array(xs)
+        np.testing.assert_allclose(o2["theta"][n], ref, rtol=1e-7, atol=1e-8)
+        st = oracle.gibbs_stats(om, y[n], ref)
+        np.testing.assert_allclose(o2["stats"][n, 0], st["ssy"][0], rtol=1e-7)
+        np.testing.assert_allclose(o2["stats"][n, 2:2 + d], st["ss"], rtol=1e-7)
