@@ -147,9 +147,6 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, char* base, 
 // assembly on purpose: the compiler's wait-count insertion treats an LDS-DMA it knows about as aliasing
 // every later LDS read and waits vmcnt(0) -- which would also wait for the just-issued record stores.
 // The waits are placed by hand instead (vm_wait<N>); vector-memory operations of a wave retire in order.
-#ifndef DLM_LDS_PREFETCH
-#define DLM_LDS_PREFETCH 1
-#endif
 typedef int i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i4 rsrc_words(const void* p, unsigned bytes) {
   const unsigned long long a = (unsigned long long)p;
@@ -550,12 +547,20 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
 
 // ---------------------------------------------------------------------------------------
 // backward pass: MFMA for P C and C (P C); gathers for G^T M G
+//
+// The record rides in the registers AUGMENTED: lanes c < d of register r hold C[4r+g][c], lanes c == 15
+// hold m[4r+g] (column 15 of a 16 x 16 tile is free for d <= 15).  With -q in column 15 of the second
+// MFMA's B operand,  [C | m] - C [P C | -q] = [C - C P C | m + C q] = [S | s]:  the smoothed mean needs no
+// extraction from the product, and mean and covariance are read and stored by the same 4 instructions.
 // ---------------------------------------------------------------------------------------
 template <int K, bool IRR>
 __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                        const double* __restrict__ side) {
-  constexpr int SM_LDS = 2 * IMG + 5 * 16;   // two images + five 16-vectors per wave
+  constexpr int SM_LDS = 2 * IMG + 3 * 16;   // two images + three 16-vectors per wave
   __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
+  // two-slot ring per wave in dynamic LDS for the LDS-DMA prefetch; a slot is a raw record followed by one
+  // zero double, which the padded lanes read.  Record t lives in slot t & 1 and is requested two steps ahead.
+  extern __shared__ __attribute__((aligned(16))) char ring_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * 4 + wave;
@@ -563,10 +568,8 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
   double* imgA = lds + wave * SM_LDS;
   double* imgB = imgA + IMG;
   double* vK = imgB + IMG;       // K_t
-  double* vQ = vK + 16;          // q_t
-  double* vPK = vQ + 16;         // P K
-  double* vCQ = vPK + 16;        // C q
-  double* vR = vCQ + 16;         // r
+  double* vQ = vK + 16;          // -q_t
+  double* vR = vQ + 16;          // r
   const int d = a.d, T = a.T, rec = d + d * d;
   const int g = lane >> 4, c = lane & 15;
   const bool vc = c < d, col15 = (c == 15);
@@ -575,9 +578,6 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
   const double rV = 1.0 / V;
   const char* bin = (const char*)(a.filt_in + (size_t)n * (T + 1) * rec);
   char* bout = (char*)(a.smooth + (size_t)n * (T + 1) * rec);
-#if !DLM_LDS_PREFETCH
-  const __amdgpu_buffer_rsrc_t rin = make_rsrc(bin, (size_t)(T + 1) * rec * 8);
-#endif
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
   const double* sd = side + (size_t)n * (T + 1) * 2;
   const int recb = rec * 8;
@@ -588,81 +588,58 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
 #pragma unroll
   for (int s = 0; s < K; ++s) { idx[s] = sp[1].idx[c][s]; val[s] = sp[1].val[c][s]; }
   double Fr[4];
-  bool vr[4];
-  int offC[4];
-  const int offM = (g == 0 && vc) ? c * 8 : OOB;     // store of s[c]: one row group only
-  const int offMl = vc ? c * 8 : OOB;                // load of m[c]: every row group
+  bool va[4];      // this lane's register r carries an element of the augmented record
+  int offA[4];     // its byte offset inside a record (OOB otherwise: loads give 0, stores are dropped)
+  int ldsA[4];     // the same inside a ring slot (padded lanes read the slot's zero double)
   double Fc = vc ? a.F[c] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * r + g;
-    vr[r] = i < d;
-    Fr[r] = vr[r] ? a.F[i] : 0.0;
-    offC[r] = (vr[r] && vc) ? (d + i * d + c) * 8 : OOB;
+    Fr[r] = i < d ? a.F[i] : 0.0;
+    va[r] = i < d && (vc || col15);
+    offA[r] = i < d ? (vc ? (d + i * d + c) * 8 : (col15 ? i * 8 : OOB)) : OOB;
+    ldsA[r] = va[r] ? offA[r] : recb;
   }
   d4 P = {0.0, 0.0, 0.0, 0.0};
   double qcol = 0.0;
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
 
-#if DLM_LDS_PREFETCH
-  // two-slot ring per wave in dynamic LDS; a slot is a raw record followed by one zero double, which the
-  // padded lanes read.  Record t lives in slot t & 1 and is requested two steps ahead.
-  extern __shared__ __attribute__((aligned(16))) char ring_all[];
   const int slotb = recb + 16;
   char* ring = ring_all + wave * 2 * slotb;
-  const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+  const unsigned ring_lds = lds_addr_of(ring);
   const i4 rdma = rsrc_words(bin, (unsigned)((size_t)(T + 1) * recb));
   const int n16 = recb / 16;                          // d (d + 1) is even: a record is a whole number of 16 B
-  int ldsC[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ldsC[r] = offC[r] != OOB ? offC[r] : recb;
-  const int ldsM = offMl != OOB ? offMl : recb;
   if (lane < 2) *(double*)(ring + lane * slotb + recb) = 0.0;
   dma_record(rdma, ring_lds + (T & 1) * slotb, T * recb, lane, n16);
   { const int t1 = T > 0 ? T - 1 : 0; dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * recb, lane, n16); }
-#else
-  d4 ncc;
-  double nm;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], T * recb);
-  nm = buf_load(rin, bin, offMl, T * recb);
-#endif
   double neq = sd[2 * T], niq = sd[2 * T + 1];
   vQ[c] = 0.0;
-  d4 Sv = {0.0, 0.0, 0.0, 0.0};
-  double scol = 0.0;
-  const double m15 = col15 ? 1.0 : 0.0;
+  d4 out = {0.0, 0.0, 0.0, 0.0};
 
 #ifdef DLM_STAMP
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp();
 #endif
   for (int t = T; t >= 0; --t) {
     STAMP(7)
-#if DLM_LDS_PREFETCH
-    // Operations issued after the request for record t: the 5 stores of step t+2, the request for t-1
-    // (1 or 2 instructions), the 5 stores of step t+1.  Counting the requests as one instruction only
+    // Operations issued after the request for record t: the 4 stores of step t+2, the request for t-1
+    // (1 or 2 instructions), the 4 stores of step t+1.  Counting the requests as one instruction only
     // over-waits by one long-finished store.  The first two steps have fewer operations behind them.
     if (t == T) vm_wait<1>();
-    else if (t == T - 1) vm_wait<6>();
-    else vm_wait<11>();
+    else if (t == T - 1) vm_wait<5>();
+    else vm_wait<9>();
     d4 cc;
-    const char* slot = ring + (t & 1) * slotb;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cc[r] = *(const double*)(slot + ldsC[r]);
-    const double mcol = *(const double*)(slot + ldsM);
-#else
-    const d4 cc = ncc;
-    const double mcol = nm;
-#endif
+    {
+      const unsigned slot = ring_lds + (t & 1) * slotb;
+      cc[0] = lds_read64<0>(slot + ldsA[0]);
+      cc[1] = lds_read64<0>(slot + ldsA[1]);
+      cc[2] = lds_read64<0>(slot + ldsA[2]);
+      cc[3] = lds_read64<0>(slot + ldsA[3]);
+      lds_fence(cc);
+    }
     // the innovations are per-series scalars: keep them in SGPRs so `observed` is a scalar branch
     const double eq = uniform_from_lane(neq, 0), iq = uniform_from_lane(niq, 0);
     {
       const int tp = t > 0 ? t - 1 : 0;                      // record 0 is re-read harmlessly at the end
-#if !DLM_LDS_PREFETCH
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], tp * recb);
-      nm = buf_load(rin, bin, offMl, tp * recb);
-#endif
       neq = sd[2 * tp]; niq = sd[2 * tp + 1];
     }
     const bool observed = (iq == iq) && t > 0;
@@ -670,39 +647,41 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       const double* Ft = a.F + (size_t)(t - 1) * a.f_stride;
       Fc = vc ? Ft[c] : 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Fr[r] = vr[r] ? Ft[4 * r + g] : 0.0;
+      for (int r = 0; r < 4; ++r) Fr[r] = (4 * r + g < d) ? Ft[4 * r + g] : 0.0;
     }
 
-    // K_t = C_t F / V
+    // K_t = C_t F / V  (column 15 would give F.m: masked)
     double kcol = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) kcol = fma(cc[r], Fr[r], kcol);
-    kcol = observed ? sum_g(kcol) * rV : 0.0;
+    kcol = (observed && vc) ? sum_g(kcol) * rV : 0.0;
     vK[c] = kcol;
     wave_sync();                                             // also publishes vQ of the last step
-#if DLM_LDS_PREFETCH
     // the slot just read is free again: request record t-2 into it (always issued, so that the operation
     // count behind every request is the same; below record 0 it re-reads record 0, which nobody uses)
     { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * recb, lane, n16); }
-#endif
-    double kr[4], qr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { kr[r] = vK[4 * r + g]; qr[r] = vQ[4 * r + g]; }
+    d4 kr, nqr;
+    {
+      const unsigned bk = lds_addr_of(vK + g), bq = lds_addr_of(vQ + g);
+      kr[0] = lds_read64<0>(bk); kr[1] = lds_read64<32>(bk); kr[2] = lds_read64<64>(bk); kr[3] = lds_read64<96>(bk);
+      nqr[0] = lds_read64<0>(bq); nqr[1] = lds_read64<32>(bq); nqr[2] = lds_read64<64>(bq); nqr[3] = lds_read64<96>(bq);
+      lds_fence(kr, nqr);
+    }
     d4 b1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b1[r] = fma(kr[r], m15, cc[r]);   // column 15 of C is zero
+    for (int r = 0; r < 4; ++r) b1[r] = col15 ? kr[r] : cc[r];
     STAMP(0)
     const d4 x1 = mmT(P, b1);                                // [P C | P K]
     d4 b2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b2[r] = col15 ? qr[r] : x1[r];
-    // [C P C | C q]: only the OUTPUT (s_t, S_t) needs it, so it is consumed at the very end of the
+    for (int r = 0; r < 4; ++r) b2[r] = col15 ? nqr[r] : x1[r];
+    // C [P C | -q]: only the OUTPUT (S_t, s_t) needs it, so it is consumed at the very end of the
     // step and its MFMA latency hides behind the recursion work below
 #ifdef DLM_STAMP
     asm volatile("" ::"v"(b2[0]), "v"(b2[1]), "v"(b2[2]), "v"(b2[3]));
 #endif
     STAMP(1)
-    const d4 x2 = mmT(cc, b2);
+    const d4 x2 = mmT(cc, b2);                               // A operand = [C | m]^T: row 15 of the product is never stored
     STAMP(2)
 
     if (t > 0) {
@@ -720,17 +699,22 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + c] = x1[r];
         wave_sync();
-        const double pkc = imgA[c * LD + 15];
-        double pkr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pkr[r] = imgA[(4 * r + g) * LD + 15];
+        d4 pk;                                               // (P K)[4r+g]
+        double pkc;                                          // (P K)[c]
+        {
+          const unsigned br = lds_addr_of(imgA + g * LD + 15), bc = lds_addr_of(imgA + c * LD + 15);
+          pk[0] = lds_read64<0>(br); pk[1] = lds_read64<4 * LD * 8>(br);
+          pk[2] = lds_read64<8 * LD * 8>(br); pk[3] = lds_read64<12 * LD * 8>(br);
+          pkc = lds_read64<0>(bc);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pk), "+v"(pkc)::"memory");
+        }
         const double kk = row_sum(kcol * (g < 2 ? qcol : pkc));   // rows 0-1: K.q, rows 2-3: K.(P K)
         const double kq = uniform_from_lane(kk, 0), kpk = uniform_from_lane(kk, 32);
         const double sc = iq + kpk;
         rcol = fma(Fc, eq - kq, qcol);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          M[r] = fma(-pkr[r], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
+          M[r] = fma(-pk[r], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
       }
       vR[c] = rcol;
       wave_sync();                                           // column-15 reads precede the image rewrite
@@ -747,7 +731,7 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       qcol = vR[idx[0]] * val[0];
 #pragma unroll
       for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
-      vQ[c] = qcol;                                          // published by the next wave_sync
+      vQ[c] = -qcol;                                         // published by the next wave_sync
       wave_sync();                                           // pass-2 reads of imgB precede its reuse
 #ifdef DLM_STAMP
       asm volatile("" ::"v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]));
@@ -755,28 +739,21 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       STAMP(4)
     }
 
-    // output: s_t = m_t + C_t q_t (column 15 of x2), S_t = C_t - C_t P_t C_t
-#pragma unroll
-    for (int r = 0; r < 4; ++r) imgB[(4 * r + g) * LD + c] = x2[r];
-    wave_sync();
-    scol = mcol + imgB[c * LD + 15];
+    // output: [S_t | s_t] = [C_t | m_t] - C_t [P_t C_t | -q_t]
     const int so = t * recb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { Sv[r] = cc[r] - x2[r]; buf_store(rout, bout, offC[r], so, Sv[r]); }
-    buf_store(rout, bout, offM, so, scol);
+    for (int r = 0; r < 4; ++r) { out[r] = cc[r] - x2[r]; buf_store(rout, bout, offA[r], so, out[r]); }
     STAMP(5)
   }
 #ifdef DLM_STAMP
   if (n == 0 && lane == 0 && a.status)
     for (int k = 0; k < 8; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)(T + 1));
 #endif
-#if DLM_LDS_PREFETCH
   vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
-#endif
   // P and q carry any non-finite value down to record 0: test the last output
-  bool bad = vc && !isfinite(scol);
+  bool bad = false;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bad |= vr[r] && vc && !isfinite(Sv[r]);
+  for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(out[r]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
@@ -991,7 +968,7 @@ static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* sid
 }
 template <int K>
 static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
-  const size_t ring = DLM_LDS_PREFETCH ? (size_t)4 * 2 * ((a.d + a.d * a.d) * 8 + 16) : 0;   // dynamic LDS: DMA ring
+  const size_t ring = (size_t)4 * 2 * ((a.d + a.d * a.d) * 8 + 16);   // dynamic LDS: DMA ring, 2 slots per wave
   if (a.g_index || a.dt || a.f_stride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   return hipGetLastError();
