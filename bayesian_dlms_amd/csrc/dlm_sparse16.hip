@@ -207,6 +207,10 @@ __device__ __forceinline__ void lds_fence(d4& a, d4& b) {
 }
 __device__ __forceinline__ void lds_fence(d4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
 
+template <int K>
+__device__ __forceinline__ d4 congruence_pass2(const d4& y, double* imgB, const int (&idx)[K], const double (&val)[K],
+                                               int g, int c, const d4* add);
+
 // Z = T X T^T for symmetric X (std layout), T given by the per-column-lane tables idx/val.
 // sym (wave-uniform): replace X by (X + X^T)/2 first.  The backward recursion needs it now and then: its
 // rank-2 update treats P as exactly symmetric, and an antisymmetric rounding component would otherwise
@@ -260,6 +264,13 @@ __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB
     y[r] = acc;
   }
 #endif
+  return congruence_pass2<K>(y, imgB, idx, val, g, c, add);
+}
+
+// second pass: Z[i][c] = sum_s Y[idx_c[s]][i] val_c[s] (+ *add) = (T Y)^T = T X T^T for symmetric results
+template <int K>
+__device__ __forceinline__ d4 congruence_pass2(const d4& y, double* imgB, const int (&idx)[K], const double (&val)[K],
+                                               int g, int c, const d4* add) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) imgB[(4 * r + g) * LD + c] = y[r];
   wave_sync();
@@ -339,14 +350,13 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
   if (n >= a.N) return;
   double* imgA = lds + wave * WAVE_LDS;
   double* imgB = imgA + IMG;
-  double* vM = imgB + IMG;       // m, column-indexed
-  double* vRF = vM + 16;         // R F
-  double* vX = vRF + 16;         // x+ (SIM)
+  double* vRF = imgB + IMG;      // R F  (one 16-vector is spare)
+  double* vX = vRF + 32;         // x+ (SIM)
   double* vZ = vX + 16;          // 64 normals = 4 records x 16 components (SIM)
   double* imgW = lds + 4 * WAVE_LDS + wave * IMG;   // chol(W), row-major (SIM, dense W only)
   const int d = a.d, T = a.T, rec = d + d * d;
   const int g = lane >> 4, c = lane & 15;
-  const bool vc = c < d;
+  const bool vc = c < d, col15 = (c == 15);
 
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* C0 = a.C0 + (size_t)n * a.c0_stride;
@@ -365,22 +375,30 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
   int gcur = 0;    // table currently held in idx/val (rows of G_gcur); irregular grids switch per step
 #pragma unroll
   for (int s = 0; s < K; ++s) { idx[s] = sp[0].idx[c][s]; val[s] = sp[0].val[c][s]; }
+  // The state rides in the registers as the symmetric augmented tile [[C, m], [m^T, 0]] (row and column 15
+  // are free for d <= 15): with row/column 15 of the transition set to the unit vector, the congruence
+  // advances mean and covariance together, (R F)[15] is the forecast f = F.a, and the Joseph update of
+  // column 15 is the mean update.  A record is stored by the same 4 instructions: lanes c == 15 of register r
+  // carry m[4r+g].  Row 15 (lanes g == 3 of register 3, column-indexed mean) is never stored.
   d4 w, cc;
   double Fr[4];
-  bool vr[4];
-  int offC[4];                                   // byte offset of C[4r+g][c] inside a record
-  const int offM = (g == 0 && vc) ? c * 8 : OOB; // byte offset of m[c]
+  bool vr[4], va[4];
+  int offA[4];                                   // byte offset of this lane's element of register r inside a record
   const int recb = rec * 8;
   double Fc = vc ? a.F[c] : 0.0;
-  double mcol = vc ? m0[c] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * r + g;
     vr[r] = i < d;
     const bool ok = vr[r] && vc;
-    offC[r] = ok ? (d + i * d + c) * 8 : OOB;
+    va[r] = vr[r] && (vc || col15);
+    offA[r] = ok ? (d + i * d + c) * 8 : (vr[r] && col15 ? i * 8 : OOB);
     w[r] = ok ? W[i * d + c] : 0.0;
     cc[r] = ok ? C0[i * d + c] : 0.0;
+    if (!SIM) {                                  // SIM: y* is filtered from a zero prior mean
+      if (vr[r] && col15) cc[r] = m0[i];
+      if (i == 15 && vc) cc[r] = m0[c];
+    }
     Fr[r] = vr[r] ? a.F[i] : 0.0;
   }
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
@@ -412,17 +430,14 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
       xcol = vc ? x0 : 0.0;
       wave_sync();
     }
-    mcol = 0.0;                                             // y* is filtered from a zero prior mean
     if (g == 0 && vc) xp[c] = xcol;
   }
 
 #pragma unroll
-  for (int r = 0; r < 4; ++r) buf_store(rout, bout, offC[r], 0, cc[r]);
-  buf_store(rout, bout, offM, 0, mcol);
+  for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], 0, cc[r]);
   if (bpri) {   // record 0: a = m0, R = C0 (KalmanFilter.scala:117)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) buf_store(rpri, bpri, offC[r], 0, cc[r]);
-    buf_store(rpri, bpri, offM, 0, SIM ? 0.0 : mcol);
+    for (int r = 0; r < 4; ++r) buf_store(rpri, bpri, offA[r], 0, cc[r]);
   }
   if (lane == 0) {
     if (fq) { fq[0] = __builtin_nan(""); fq[1] = __builtin_nan(""); }
@@ -453,7 +468,6 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
     }
 
     // advState: a = G m, R = G C G^T + W dt   (dt == 0: a = m, R = C, KalmanFilter.scala:279-280)
-    vM[c] = mcol;
     if (SIM) {
       vX[c] = xcol;
       if ((t & 3) == 0) {   // 64 normals: records t+1 .. t+4, components 0..15 (0..d used)
@@ -464,21 +478,16 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
       }
     }
     d4 R;
-    double acol;
     if (dt == 0.0) {
       wave_sync();
       R = cc;
-      acol = mcol;
     } else {
       d4 wdt = w;
       if (IRR) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) wdt[r] = w[r] * dt;
       }
-      R = congruence<K>(cc, imgA, imgB, idx, val, g, c, false, &wdt);   // first wave_sync also covers vM, vX, vZ
-      acol = vM[idx[0]] * val[0];
-#pragma unroll
-      for (int s = 1; s < K; ++s) acol = fma(vM[idx[s]], val[s], acol);
+      R = congruence<K>(cc, imgA, imgB, idx, val, g, c, false, &wdt);   // first wave_sync also covers vX, vZ
     }
     if (SIM) {
       // x+_t = G x+_{t-1} + L_W z ;  y+_t = F^T x+_t + sqrt(V) z_v ;  y*_t = y_t - y+_t
@@ -498,10 +507,9 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
     }
     if (bpri) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) buf_store(rpri, bpri, offC[r], (t + 1) * recb, R[r]);
-      buf_store(rpri, bpri, offM, (t + 1) * recb, acol);
+      for (int r = 0; r < 4; ++r) buf_store(rpri, bpri, offA[r], (t + 1) * recb, R[r]);
     }
-    // f = F^T a ; RF ; Q = F^T R F + V
+    // RF (element 15 is the forecast f = F^T a) ; Q = F^T R F + V
     double rfc = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) rfc = fma(R[r], Fr[r], rfc);
@@ -511,36 +519,33 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
     double rfr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) rfr[r] = vRF[4 * r + g];     // (R F)[4r+g]
-    // one row reduction for both inner products: rows 0-1 reduce F.a, rows 2-3 reduce F.(RF)
-    const double fqv = row_sum(Fc * (g < 2 ? acol : rfc));
-    const double f = uniform_from_lane(fqv, 0);
-    const double Q = uniform_from_lane(fqv, 32) + V;
+    const double f = uniform_from_lane(rfc, 15);
+    const double Q = uniform_from_lane(row_sum(Fc * rfc), 0) + V;
 
     if (yt == yt) {
       // Joseph form for p = 1 with K = RF / Q:  R - K RF^T - RF K^T + Q K K^T
       //   = R - RF_i * (RF_j / Q) * (2 - Q * (1/Q))   -- the same expression, factored
-      const double e = yt - f, rq = fast_rcp(Q);
-      const double Kc = rfc * rq;
-      const double ngam = -Kc * fma(-Q, rq, 2.0);
+      //   column 15: a + RF e / Q = m ;  row 15 (lanes g == 3 of register 3): a[c] + K[c] e
+      const double e = yt - f, rq = fast_rcp(Q), erq = e * rq;
+      const double Kc = (col15 ? 0.0 : rfc) * rq;
+      const double ngam = col15 ? erq : -Kc * fma(-Q, rq, 2.0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cc[r] = fma(rfr[r], ngam, R[r]);
-      mcol = fma(Kc, e, acol);
-      if (sd && lane == 0) { sd[2 * (t + 1)] = e * rq; sd[2 * (t + 1) + 1] = rq; }
+      for (int r = 0; r < 3; ++r) cc[r] = fma(rfr[r], ngam, R[r]);
+      cc[3] = (g == 3) ? fma(Kc, e, R[3]) : fma(rfr[3], ngam, R[3]);
+      if (sd && lane == 0) { sd[2 * (t + 1)] = erq; sd[2 * (t + 1) + 1] = rq; }
     } else {
       cc = R;
-      mcol = acol;
       if (sd && lane == 0) { sd[2 * (t + 1)] = __builtin_nan(""); sd[2 * (t + 1) + 1] = __builtin_nan(""); }
     }
     if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
     const int so = (t + 1) * recb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) buf_store(rout, bout, offC[r], so, cc[r]);
-    buf_store(rout, bout, offM, so, mcol);
-    wave_sync();   // vM / images are rewritten at the top of the next step
+    for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], so, cc[r]);
+    wave_sync();   // the images are rewritten at the top of the next step
   }
-  bool bad = vc && !isfinite(mcol);
+  bool bad = false;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bad |= vr[r] && vc && !isfinite(cc[r]);
+  for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(cc[r]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
@@ -946,6 +951,9 @@ int sparse16_analyse(const double* G /* d x d column-major, host */, int d, Spar
       if (cnt > kmax) kmax = cnt;
     }
   }
+  // row / column 15 of the augmented transition [[G, 0], [0, 1]] (the kernels carry the mean there)
+  rows->idx[15][0] = cols->idx[15][0] = 15;
+  rows->val[15][0] = cols->val[15][0] = 1.0;
   rows->K = cols->K = kmax;
   return kmax;
 }

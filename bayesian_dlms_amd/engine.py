@@ -123,8 +123,29 @@ class Engine:
     def prepare(self, mat: MaterialisedModel, params, N: int, be, flags=0, seed=0, series_offset=0):
         """Build the descriptors; returns (model, params, opts, keepalive list)."""
         V, vs, W, ws, m0, m0s, C0, c0s = pack_params(params, N) if not isinstance(params, tuple) else params
-        bufs = dict(F=be.put(mat.F), G=be.put(mat.G), gi=be.put(mat.g_index, np.int32), dt=be.put(mat.dt),
-                    V=be.put(V), W=be.put(W), m0=be.put(m0), C0=be.put(C0))
+        items = dict(F=(mat.F, np.float64), G=(mat.G, np.float64), gi=(mat.g_index, np.int32), dt=(mat.dt, np.float64),
+                     V=(V, np.float64), W=(W, np.float64), m0=(m0, np.float64), C0=(C0, np.float64))
+        if isinstance(be, _Device) and not any(isinstance(a, be.torch.Tensor) for a, _ in items.values()):
+            # device mode with a host-side model: ONE upload for all the small tables instead of eight
+            parts, offs, pos = [], {}, 0
+            for name, (a, dt) in items.items():
+                if a is None:
+                    continue
+                b = np.ascontiguousarray(a, dtype=dt).reshape(-1).view(np.uint8)
+                offs[name] = pos
+                parts.append(b)
+                pad = (-b.size) % 256
+                if pad:
+                    parts.append(np.zeros(pad, dtype=np.uint8))
+                pos += b.size + pad
+            blob = be.torch.as_tensor(np.concatenate(parts), device=be.device)
+            base = blob.data_ptr()
+            bufs = {"blob": blob}
+            P = lambda name: (base + offs[name]) if name in offs else None
+            md = _lib.ModelDesc(mat.d, mat.p, mat.T, N, P("F"), mat.f_stride, P("G"), mat.n_g, P("gi"), P("dt"))
+            pd = _lib.ParamsDesc(P("V"), vs, P("W"), ws, P("m0"), m0s, P("C0"), c0s)
+            return md, pd, _lib.Options(flags, be.mem, seed, series_offset), bufs
+        bufs = {name: be.put(a, dt) for name, (a, dt) in items.items()}
         P = lambda a: (be.ptr(a).value if a is not None else None)
         md = _lib.ModelDesc(mat.d, mat.p, mat.T, N, P(bufs["F"]), mat.f_stride, P(bufs["G"]), mat.n_g,
                             P(bufs["gi"]), P(bufs["dt"]))
