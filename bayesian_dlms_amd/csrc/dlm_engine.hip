@@ -215,7 +215,8 @@ int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
     }
   } else if (use_tiled(k)) {
     e->variant = "tiled-mfma";
-    HIP_TRY(e, dlm::launch_tiled_filter(k, e->stream));
+    if (want_side) { int rc = ensure_ystar(e, k); if (rc) return rc; }
+    HIP_TRY(e, dlm::launch_tiled_filter(k, want_side ? e->ystar : nullptr, e->stream));
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_filter(k, e->stream));
@@ -235,9 +236,9 @@ int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
       e->variant = "mfma16";
       HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->side, e->stream));
     }
-  } else if (have_side && use_tiled(k) && k.y && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1)) {
-    e->variant = "tiled-mfma";   // fused call only: the information-form pass recomputes innovations from y
-    HIP_TRY(e, dlm::launch_tiled_smoother(k, e->stream));
+  } else if (have_side && use_tiled(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1)) {
+    e->variant = "tiled-mfma";   // fused call only: the information-form pass takes the innovations of the forward pass
+    HIP_TRY(e, dlm::launch_tiled_smoother(k, e->ystar, e->stream));
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_smoother(k, e->stream));

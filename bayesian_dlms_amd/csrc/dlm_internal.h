@@ -61,8 +61,9 @@ hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_d
 
 // ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------
 bool tiled_supported(const KArgs& a);
-hipError_t launch_tiled_filter(const KArgs& a, hipStream_t s);
-hipError_t launch_tiled_smoother(const KArgs& a, hipStream_t s);   // needs a.y (innovations are recomputed)
+// innov [N][T][p] (nullable for the filter): innovations y_t - f_t (NaN = missing) handed from the forward to the backward pass
+hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s);
+hipError_t launch_tiled_smoother(const KArgs& a, const double* innov, hipStream_t s);
 // simulation-smoother FFBS (forward SIM pass + mean-only backward pass); xplus [N][T+1][d], ystar [N][T][p]
 hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s);
 

@@ -30,34 +30,60 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int NT = 512;         // threads per workgroup: 8 waves, two per SIMD (latency hiding, 1 workgroup per CU)
 constexpr int NW = NT / 64;
+constexpr int VW = NW - 1;      // the wave that does a step's vector work (it owns at most one tile of any phase)
 constexpr int DL = 49;          // leading dimension of d-wide matrices (up to 48 columns)
 constexpr int PL = 33;          // leading dimension of p-wide matrices (up to 32 columns)
 constexpr int BIG = 48 * DL;    // doubles in a 48 x d-wide matrix
 constexpr int MID = 48 * PL;    // doubles in a 48 x p-wide matrix
 constexpr int SML = 32 * PL;    // doubles in a 32 x p-wide matrix
 
-// C (mt x nt tiles, mt * nt <= 12) = D -/+ op(A) op(B), all row-major in LDS.  MODE 0: C = acc, 1: C = D + acc,
-// 2: C = D - acc (D may alias C).  kb = number of 4-deep k-blocks.
-template <bool TA, bool TB, int MODE>
+// C (mt x nt tiles) = op(A) op(B) combined with D, all row-major in LDS.  kb = number of 4-deep k-blocks.
+//   MODE 0: C = acc      1: C = D + acc      2: C = D - acc      (D in LDS, may alias C)
+//   MODE 3: C = acc + dscale * Dg, Dg a column-major drows x dcols matrix in GLOBAL memory (W dt, V): the
+//           addend is fetched before the MFMA chain, so its latency hides behind the chain and the separate
+//           element-wise pass with its barrier disappears.
+// SYM (mt == nt, symmetric result): only the tiles on and above the diagonal are computed, each written to
+// both places.  The fp64 MFMA issues about once per 110-140 cycles per SIMD whatever the number of independent
+// accumulators (profiles/r01_mfma_f64_microbench.txt), so a phase lasts as long as the MFMAs of its busiest
+// SIMD: 6 tiles instead of 9 is 20 against 30 on it.  Waves w and w + 4 share a SIMD; tile q goes to wave q % 8.
+// `shift` rotates the tile -> wave assignment (tile q on wave (q + shift) % 8) so that two products issued in
+// the same phase load the SIMDs evenly.
+template <bool TA, bool TB, int MODE, bool SYM = false>
 __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const double* A, int lda, const double* B,
-                                       int ldb, double* C, int ldc, const double* D = nullptr) {
-  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
-  const int ntiles = mt * nt;   // <= 9 on this path: wave w owns tiles w and w + 8
+                                       int ldb, double* C, int ldc, const double* D = nullptr, double dscale = 1.0,
+                                       int drows = 0, int dcols = 0, int shift = 0) {
+  const int wave = ((tid >> 6) - shift) & (NW - 1), lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int ntiles = SYM ? mt * (mt + 1) / 2 : mt * nt;   // <= 16: a wave owns tiles w and w + 8
   if (wave >= ntiles) return;
-  // two independent MFMA accumulation chains per wave (and two waves per SIMD) cover the
-  // dependent-accumulator latency of a chain
-  int ao[2], bo[2];
+  int ao[2], bo[2], ti[2], tj[2];
   bool on[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int tile = wave + NW * q;
     on[q] = tile < ntiles;
-    const int i0 = on[q] ? (tile / nt) * 16 : 0, j0 = on[q] ? (tile % nt) * 16 : 0;
+    int i = 0, j = 0;
+    if (on[q]) {
+      if (SYM) { int rem = tile, len = nt; while (rem >= len) { rem -= len; ++i; --len; } j = i + rem; }
+      else { i = tile / nt; j = tile % nt; }
+    }
+    ti[q] = i; tj[q] = j;
+    const int i0 = i * 16, j0 = j * 16;
     ao[q] = TA ? g * lda + i0 + c : (i0 + c) * lda + g;      // op(A)[i0 + c][g]     (+ 4 kk along k)
     bo[q] = TB ? (j0 + c) * ldb + g : g * ldb + j0 + c;      // op(B)[g][j0 + c]
   }
   const int as = TA ? 4 * lda : 4, bs = TB ? 4 : 4 * ldb;    // stride of one k-block
   d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  if (MODE == 3) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!on[q]) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti[q] * 16 + 4 * r + g, j = tj[q] * 16 + c;
+        acc[q][r] = (i < drows && j < dcols) ? dscale * D[i + (size_t)j * drows] : 0.0;
+      }
+    }
+  }
   if (on[1]) {
     for (int kk = 0; kk < kb; ++kk) {
       const double a0 = A[ao[0] + kk * as], b0 = B[bo[0] + kk * bs], a1 = A[ao[1] + kk * as], b1 = B[bo[1] + kk * bs];
@@ -71,16 +97,38 @@ __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const do
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     if (!on[q]) continue;
-    const int tile = wave + NW * q;
-    const int i0 = (tile / nt) * 16, j0 = (tile % nt) * 16;
+    const int i0 = ti[q] * 16, j0 = tj[q] * 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = (i0 + 4 * r + g) * ldc + j0 + c;
-      if (MODE == 0) C[o] = acc[q][r];
-      else if (MODE == 1) C[o] = D[o] + acc[q][r];
-      else C[o] = D[o] - acc[q][r];
+      double v;
+      if (MODE == 0 || MODE == 3) v = acc[q][r];
+      else if (MODE == 1) v = D[o] + acc[q][r];
+      else v = D[o] - acc[q][r];
+      C[o] = v;
+      if (SYM && i0 != j0) C[(j0 + c) * ldc + i0 + 4 * r + g] = v;
     }
   }
+}
+
+// y[i] = sum_k M[i * ld + k] x[k] (TR: M[k * ld + i]) for i < rows, by the lanes of ONE wave (which = wave index):
+// the O(d^2) vector work of a step runs on a wave that has a light share of the phase's tiles, four
+// independent partial sums keep the LDS reads in flight.
+template <bool TR>
+__device__ __forceinline__ double wave_matvec(int tid, int which, int rows, int cols, const double* M, int ld, const double* x) {
+  const int i = tid - which * 64;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (i >= 0 && i < rows) {
+    int k = 0;
+    for (; k + 3 < cols; k += 4) {
+      s0 = fma(TR ? M[k * ld + i] : M[i * ld + k], x[k], s0);
+      s1 = fma(TR ? M[(k + 1) * ld + i] : M[i * ld + k + 1], x[k + 1], s1);
+      s2 = fma(TR ? M[(k + 2) * ld + i] : M[i * ld + k + 2], x[k + 2], s2);
+      s3 = fma(TR ? M[(k + 3) * ld + i] : M[i * ld + k + 3], x[k + 3], s3);
+    }
+    for (; k < cols; ++k) s0 = fma(TR ? M[k * ld + i] : M[i * ld + k], x[k], s0);
+  }
+  return (s0 + s1) + (s2 + s3);
 }
 
 __device__ __forceinline__ void wsync() {   // LDS hand-off inside ONE wavefront (in-order LDS queue)
@@ -88,6 +136,112 @@ __device__ __forceinline__ void wsync() {   // LDS hand-off inside ONE wavefront
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Products with the d x d transition G of the backward pass.  G is kept in LDS as a compact row-major copy (leading
+// dimension gd = d, no padding: both access patterns below run along a row, so any leading dimension is conflict
+// free; there is room for d <= 46) or, for d = 47, 48, read straight from global memory (column-major; the same 18 KB
+// for every workgroup, so it lives in L1/L2).  Either way all k-blocks of the G operand are fetched before the
+// MFMA chain (one latency, not kb) and the padding is made of predicated zeros.
+//   GA = false:  C = A * G      (A row-major in LDS)             B[k][j] = G[k][j]
+//   GA = true :  C = G^T * B    (B row-major in LDS, SYM result)  A[i][k] = G[k][i]
+template <bool GA, bool SYM, bool GLDS>
+__device__ __forceinline__ void gemm_g(int tid, int mt, int kb, const double* L, int ldl, const double* Gp, int gd,
+                                       double* C, int ldc) {
+  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int ntiles = SYM ? mt * (mt + 1) / 2 : mt * mt;
+  if (wave >= ntiles) return;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tile = wave + NW * q;
+    if (tile >= ntiles) break;
+    int i = 0, j = 0;
+    if (SYM) { int rem = tile, len = mt; while (rem >= len) { rem -= len; ++i; --len; } j = i + rem; }
+    else { i = tile / mt; j = tile % mt; }
+    const int i0 = i * 16, j0 = j * 16;
+    const int o = (GA ? i0 : j0) + c;                         // the G index that is not summed over
+    double gv[12];
+#pragma unroll
+    for (int kk = 0; kk < 12; ++kk) {
+      const int k = g + 4 * kk;
+      const bool ok = kk < kb && k < gd && o < gd;
+      gv[kk] = ok ? (GLDS ? Gp[k * gd + o] : Gp[k + (size_t)o * gd]) : 0.0;
+    }
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int lo = GA ? g * ldl + j0 + c : (i0 + c) * ldl + g;   // B[g][j0 + c]  /  A[i0 + c][g]
+    const int ls = GA ? 4 * ldl : 4;
+#pragma unroll
+    for (int kk = 0; kk < 12; ++kk) {
+      if (kk < kb) {
+        const double lv = L[lo + kk * ls];
+        acc = GA ? __builtin_amdgcn_mfma_f64_16x16x4f64(gv[kk], lv, acc, 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f64_16x16x4f64(lv, gv[kk], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      C[(i0 + 4 * r + g) * ldc + j0 + c] = acc[r];
+      if (SYM && i0 != j0) C[(j0 + c) * ldc + i0 + 4 * r + g] = acc[r];
+    }
+  }
+}
+
+// M = D + A1 B1^T - A2 B2^T - A3 B3^T for a symmetric result (upper tiles, mirrored): the rank-3p update of the
+// backward recursion in ONE phase.  All operands row-major d x p in LDS with leading dimension ld.
+__device__ __forceinline__ void gemm_update3(int tid, int mt, int kb, const double* A1, const double* B1, const double* A2,
+                                             const double* B2, const double* A3, const double* B3, int ld, double* C,
+                                             int ldc, const double* D) {
+  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int ntiles = mt * (mt + 1) / 2;
+  if (wave >= ntiles) return;
+  int i = 0, rem = wave, len = mt;
+  while (rem >= len) { rem -= len; ++i; --len; }
+  const int i0 = i * 16, j0 = (i + rem) * 16;
+  const int ao = (i0 + c) * ld + g, bo = (j0 + c) * ld + g;
+  d4 pos = {0.0, 0.0, 0.0, 0.0}, neg = {0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < kb; ++kk) {
+    const double a1 = A1[ao + 4 * kk], b1 = B1[bo + 4 * kk], a2 = A2[ao + 4 * kk], b2 = B2[bo + 4 * kk];
+    const double a3 = A3[ao + 4 * kk], b3 = B3[bo + 4 * kk];
+    pos = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, pos, 0, 0, 0);
+    neg = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, neg, 0, 0, 0);
+    neg = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, neg, 0, 0, 0);
+  }
+  d4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = (i0 + 4 * r + g) * ldc + j0 + c;
+    v[r] = (D[o] + pos[r]) - neg[r];
+    C[o] = v[r];
+    if (i0 != j0) C[(j0 + c) * ldc + i0 + 4 * r + g] = v[r];
+  }
+  if (i0 == j0) {   // a diagonal tile holds both triangles, rounded differently: average them (same wave wrote all of it)
+    wsync();
+    d4 w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = C[(i0 + c) * ldc + i0 + 4 * r + g];
+    wsync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(i0 + 4 * r + g) * ldc + i0 + c] = 0.5 * (v[r] + w[r]);
+  }
+}
+
+// y[i] = sum_k G[i][k] x[k] (TR: G[k][i]) with G column-major in GLOBAL memory, by the lanes of wave `which`
+template <bool TR>
+__device__ __forceinline__ double wave_matvec_g(int tid, int which, int n, const double* Gg, const double* x) {
+  const int i = tid - which * 64;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (i >= 0 && i < n) {
+    int k = 0;
+    for (; k + 3 < n; k += 4) {
+      s0 = fma(TR ? Gg[k + (size_t)i * n] : Gg[i + (size_t)k * n], x[k], s0);
+      s1 = fma(TR ? Gg[k + 1 + (size_t)i * n] : Gg[i + (size_t)(k + 1) * n], x[k + 1], s1);
+      s2 = fma(TR ? Gg[k + 2 + (size_t)i * n] : Gg[i + (size_t)(k + 2) * n], x[k + 2], s2);
+      s3 = fma(TR ? Gg[k + 3 + (size_t)i * n] : Gg[i + (size_t)(k + 3) * n], x[k + 3], s3);
+    }
+    for (; k < n; ++k) s0 = fma(TR ? Gg[k + (size_t)i * n] : Gg[i + (size_t)k * n], x[k], s0);
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {   // lane `src` -> SGPR pair (uniform)
   const int lo = __builtin_amdgcn_readlane((int)__double2loint(v), src);
@@ -107,7 +261,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-__device__ __forceinline__ bool spd_inverse(int tid, int n_, double* A, double* Li, int* bad_flag) {
+__device__ __noinline__ bool spd_inverse(int tid, int n_, double* A, double* Li, int* bad_flag) {
   const int n = __builtin_amdgcn_readfirstlane(n_);   // uniform: the guards below must be scalar branches
   __syncthreads();
   if (tid < 64) {
@@ -244,7 +398,8 @@ bool tiled_supported(const KArgs& a) { return a.d >= 16 && a.d <= 48 && a.p <= 3
 constexpr int FILT_DOUBLES = 4 * BIG + 3 * MID + 2 * SML + 8 * 48;    // 133 KB (inverse scratch aliases Tm / Kg)
 constexpr int FILT_SIM_DOUBLES = FILT_DOUBLES + BIG + SML + 3 * 48;   // + chol(W), chol(V), x+ (48), normals (96): 158 KB
 constexpr int SIMS_DOUBLES = 2 * BIG + 3 * MID + 4 * SML + 16 * 48;   // mean-only backward pass: 115 KB
-constexpr int SMTH_DOUBLES = 4 * BIG + 3 * MID + 4 * SML + 10 * 48;   // 150.9 KB
+constexpr int GL_MAXD = 46;                                             // largest d whose compact G copy fits
+constexpr int SMTH_DOUBLES = 4 * BIG + 3 * MID + 3 * SML + 10 * 48 + GL_MAXD * GL_MAXD;   // 159.4 KB (the Cholesky scratch aliases T1)
 size_t tiled_filter_lds_bytes() { return sizeof(double) * FILT_DOUBLES + 16; }
 size_t tiled_smoother_lds_bytes() { return sizeof(double) * SMTH_DOUBLES + 16; }
 
@@ -288,7 +443,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
   const unsigned long long series = a.series_offset + (unsigned long long)n;
   const double* zin = (SIM && a.z) ? a.z + (size_t)n * (T + 1) * (d + p) : nullptr;
   double* xp = SIM ? xplus + (size_t)n * (T + 1) * d : nullptr;
-  double* ys = SIM ? ystar + (size_t)n * T * p : nullptr;
+  double* ys = ystar ? ystar + (size_t)n * T * p : nullptr;   // SIM: y* = y - y+ ; otherwise (optional) the innovations
   if (SIM) {
     // factors chol(W), chol(V), and x+_0 = m0 + chol(C0) z_0 (chol(C0) in R, which is idle here)
     load_cm(tid, W, d, d, Lw, DL);
@@ -314,6 +469,8 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
 #endif
   for (int t = 0; t < T; ++t) {
     TSTAMP(7)
+    int tl = tid;   // opaque copy: no hoisting of the products' operand addresses out of the time loop (see k_smoother_tiled)
+    asm volatile("" : "+v"(tl));
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) { __syncthreads(); load_cm(tid, a.G + (size_t)gi * dd, d, d, Gm, DL); gcur = gi; }
@@ -324,12 +481,10 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       for (int idx = tid; idx < 48 * DL; idx += NT) R[idx] = C[idx];
       if (tid < d) av[tid] = mv[tid];
     } else {
-      gemm_t<false, false, 0>(tid, dt16, dt16, kd, Gm, DL, C, DL, Tm, DL);
-      if (tid < d) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Gm[tid * DL + k], mv[k], s); av[tid] = s; }
+      gemm_t<false, false, 0>(tl, dt16, dt16, kd, Gm, DL, C, DL, Tm, DL);
+      { const double s = wave_matvec<false>(tl, VW, d, d, Gm, DL, mv); if (tid >= VW * 64 && tid - VW * 64 < d) av[tid - VW * 64] = s; }
       __syncthreads();
-      gemm_t<false, true, 0>(tid, dt16, dt16, kd, Tm, DL, Gm, DL, R, DL);
-      __syncthreads();
-      FOR_CM(d, d, i, j) R[i * DL + j] = fma(W[i + j * d], dt, R[i * DL + j]);
+      gemm_t<false, true, 3, true>(tl, dt16, dt16, kd, Tm, DL, Gm, DL, R, DL, W, dt, d, d);   // (G C) G^T + W dt
     }
     __syncthreads();
     TSTAMP(0)
@@ -339,12 +494,11 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       FOR_CM(d, d, i, j) pr[d + i + j * d] = R[i * DL + j];
     }
     // forecast: f = F^T a, RF = R F, Q = F^T R F + V
-    gemm_t<false, false, 0>(tid, dt16, pt16, kd, R, DL, Fm, PL, RF, PL);
-    if (tid < p) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Fm[k * PL + tid], av[k], s); fv[tid] = s; }
+    gemm_t<false, false, 0>(tl, dt16, pt16, kd, R, DL, Fm, PL, RF, PL);
+    { const double s = wave_matvec<true>(tl, VW, p, d, Fm, PL, av); if (tid >= VW * 64 && tid - VW * 64 < p) fv[tid - VW * 64] = s; }
     __syncthreads();
-    gemm_t<true, false, 0>(tid, pt16, pt16, kd, Fm, PL, RF, PL, Q, PL);
+    gemm_t<true, false, 3, true>(tl, pt16, pt16, kd, Fm, PL, RF, PL, Q, PL, V, 1.0, p, p);   // F^T (R F) + V
     __syncthreads();
-    FOR_CM(p, p, i, j) Q[i * PL + j] += V[i + j * p];
     if (SIM) {
       // x+_t = G x+_{t-1} + L_W z_x ;  y+_t = F^T x+_t + L_V z_y   (tv = new x+, then copied back)
       if (tid < d + p) zv[tid] = zin ? zin[(size_t)(t + 1) * (d + p) + tid] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)tid);
@@ -373,6 +527,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       }
       ob[tid] = (yv == yv) ? 1.0 : 0.0;
       ev[tid] = (yv == yv) ? yv - fv[tid] : 0.0;
+      if (!SIM && ys) ys[(size_t)t * p + tid] = yv - fv[tid];   // innovations for the fused backward pass (NaN = missing)
     }
     __syncthreads();
     if (fq) {
@@ -404,10 +559,10 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Qi[i * PL + j] = 0.0;
       __syncthreads();
       TSTAMP(2)
-      gemm_t<false, false, 0>(tid, dt16, pt16, kp, RF, PL, Qi, PL, Kg, PL);          // K = R F Qm^-1
+      gemm_t<false, false, 0>(tl, dt16, pt16, kp, RF, PL, Qi, PL, Kg, PL);          // K = R F Qm^-1
       __syncthreads();
-      if (tid < d) { double s = av[tid]; for (int j = 0; j < p; ++j) s = fma(Kg[tid * PL + j], ev[j], s); mv[tid] = s; }
-      gemm_t<false, true, 2>(tid, dt16, dt16, kp, Kg, PL, RF, PL, C, DL, R);          // C = R - K (R F)^T
+      { const double s = wave_matvec<false>(tl, VW, d, p, Kg, PL, ev); if (tid >= VW * 64 && tid - VW * 64 < d) mv[tid - VW * 64] = av[tid - VW * 64] + s; }
+      gemm_t<false, true, 2, true>(tl, dt16, dt16, kp, Kg, PL, RF, PL, C, DL, R);    // C = R - K (R F)^T
     }
     __syncthreads();
     TSTAMP(3)
@@ -430,20 +585,23 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
 // ---------------------------------------------------------------------------------------
 // backward pass (information form, general p)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a) {
+__global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd;
   const int dt16 = (d + 15) / 16, pt16 = (p + 15) / 16, kd = (d + 3) / 4, kp = (p + 3) / 4;
   double* C = sm;            double* P = C + BIG;     double* T1 = P + BIG;    double* T2 = T1 + BIG;
   double* Fm = T2 + BIG;     double* Kg = Fm + MID;   double* PK = Kg + MID;
-  double* Vi = PK + MID;     double* Qi = Vi + SML;   double* X = Qi + SML;    double* Li = X + SML;
-  double* mv = Li + SML;     double* mp = mv + 48;    double* qv = mp + 48;    double* rv = qv + 48;
+  double* Vi = PK + MID;     double* Qi = Vi + SML;   double* X = Qi + SML;    double* Li = T1;   // Cholesky scratch: T1 is idle then
+  double* mv = X + SML;      double* mp = mv + 48;    double* qv = mp + 48;    double* rv = qv + 48;
   double* ev = rv + 48;      double* uv = ev + 48;    double* ob = uv + 48;    double* obp = ob + 48;
   double* tv = obp + 48;     double* cq = tv + 48;
+  double* Glp = cq + 48;           // compact row-major copy of G when it fits (d <= 46); otherwise G is read from global memory
+  const bool Gl = d <= GL_MAXD;
   double* CF = T2;           // d x p scratch aliases (T2 is free while K is built); uses ld PL
+  const int vt = tid - VW * 64;   // lane index inside the vector-work wave (negative on the others)
   const double* V = a.V + (size_t)n * a.v_stride;
-  const double* y = a.y + (size_t)n * T * p;
+  const double* es = innov + (size_t)n * T * p;   // e_t = y_t - f_t from the forward pass (NaN = missing), record t <-> es[(t-1) p ..]
   const double* fin = a.filt_in + (size_t)n * (T + 1) * rec;
   double* out = a.smooth + (size_t)n * (T + 1) * rec;
   int st = 0;
@@ -451,38 +609,62 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a) {
   zero_lds(tid, sm, SMTH_DOUBLES);
   __syncthreads();
   load_cm(tid, a.F, d, p, Fm, PL);
+  int gcur = -1;
   if (tid < p) obp[tid] = -1.0;   // mask of the cached Vm^-1 (none yet)
   __syncthreads();
 
-  // register prefetch of the record stream: C_t one step ahead, the means two steps ahead (the
-  // innovation of step t needs m_{t-1})
-  double pre[6], mcur = 0.0, mnext = 0.0;
+  // register prefetch of the record stream and of the innovations, one step ahead
+  double pre[6], mcur = 0.0, ecur = __builtin_nan("");
   {
     const double* r = fin + (size_t)T * rec;
     int q = 0;
     for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
-    if (tid < d) { mcur = r[tid]; mnext = (T > 0) ? (r - rec)[tid] : 0.0; }
+    if (tid < d) mcur = r[tid];
+    if (tid < p && T > 0) ecur = es[(size_t)(T - 1) * p + tid];
   }
+#ifdef DLM_STAMP
+  unsigned long long seg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
   for (int t = T; t >= 0; --t) {
     __syncthreads();
+    TSTAMP(0)
+    // an opaque copy of the thread index: keeps the compiler from hoisting the operand addresses of the dozen
+    // products below out of the time loop, where they would occupy (and spill) a few hundred registers
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    {   // G of the step INTO record t (the regular grid has one): refresh the LDS copy when it changes
+      const int gi = (a.g_index && t > 0) ? a.g_index[t - 1] : 0;
+      if (Gl && gi != gcur) {
+        const double* Gs = a.G + (size_t)gi * dd;
+        for (int idx = tid; idx < dd; idx += NT) { const int k_ = idx % d, o_ = idx / d; Glp[k_ * d + o_] = Gs[idx]; }   // Gs is column-major
+        gcur = gi;
+      }
+    }
     {
       int q = 0;
       for (int j = tid >> 6; j < d; j += NW, ++q) if ((tid & 63) < d) C[(tid & 63) * DL + j] = pre[q];
-      if (tid < d) { mv[tid] = mcur; mp[tid] = mnext; mcur = mnext; }
+      if (tid < d) mv[tid] = mcur;
+      if (tid < p) {   // the lanes of wave 0: observation mask of this step and whether it repeats the cached one
+        const bool obs = (t > 0) && (ecur == ecur);
+        ob[tid] = obs ? 1.0 : 0.0;
+        ev[tid] = obs ? ecur : 0.0;
+        const unsigned long long mo = __ballot(obs), md = __ballot((obs ? 1.0 : 0.0) != obp[tid]);
+        if (tid == 0) { mp[0] = mo ? 1.0 : 0.0; mp[1] = md ? 0.0 : 1.0; }
+      }
       if (t > 0) {
         const double* r = fin + (size_t)(t - 1) * rec;
         q = 0;
         for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
-        if (tid < d) mnext = (t > 1) ? (r - rec)[tid] : 0.0;
+        if (tid < d) mcur = r[tid];
+        if (tid < p) ecur = (t > 1) ? es[(size_t)(t - 2) * p + tid] : __builtin_nan("");
       }
     }
     if (a.f_stride && t > 0) load_cm(tid, a.F + (size_t)(t - 1) * a.f_stride, d, p, Fm, PL);
-    if (tid < p) { const double yv = (t > 0) ? y[(size_t)(t - 1) * p + tid] : __builtin_nan(""); ob[tid] = (yv == yv) ? 1.0 : 0.0; tv[tid] = yv; }
     __syncthreads();
-    bool any = false, same = true;
-    for (int j = 0; j < p; ++j) { any |= ob[j] != 0.0; same &= ob[j] == obp[j]; }
+    TSTAMP(1)
+    const bool any = mp[0] != 0.0, same = mp[1] != 0.0;
     const double* Gt = a.G + (size_t)((a.g_index && t > 0) ? a.g_index[t - 1] : 0) * dd;   // G of the step INTO record t
-    const double dtt = (a.dt && t > 0) ? a.dt[t - 1] : 1.0;
 
     if (any) {
       if (!same) {   // Vm^-1 for this missingness pattern (cached while the pattern repeats)
@@ -493,32 +675,41 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a) {
         if (tid < p) obp[tid] = ob[tid];
         __syncthreads();
       }
-      gemm_t<false, false, 0>(tid, dt16, pt16, kd, C, DL, Fm, PL, CF, PL);            // C F
-      // e = y - F^T G m_{t-1}  (a_t = G m_{t-1}; identity advance when dt == 0)
-      if (tid < d) {
-        double s = 0.0;
-        if (dtt == 0.0) s = mp[tid];
-        else for (int k = 0; k < d; ++k) s = fma(Gt[tid + k * d], mp[k], s);
-        rv[tid] = s;   // a_t (rv is free here)
-      }
+      TSTAMP(2)
+      // Every phase below is one or two MFMA products on waves 0.. plus the step's vector work on wave VW.
+      gemm_t<false, false, 0>(tl, dt16, pt16, kd, C, DL, Fm, PL, CF, PL);            // C F
       __syncthreads();
-      gemm_t<false, false, 0>(tid, dt16, pt16, kp, CF, PL, Vi, PL, Kg, PL);           // K = C F Vm^-1
-      if (tid < p) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Fm[k * PL + tid], rv[k], s); ev[tid] = (ob[tid] != 0.0) ? tv[tid] - s : 0.0; }
+      TSTAMP(3)
+      gemm_t<false, false, 0>(tl, dt16, pt16, kp, CF, PL, Vi, PL, Kg, PL);           // K = C F Vm^-1
       __syncthreads();
-      gemm_t<true, false, 0>(tid, pt16, pt16, kd, Fm, PL, Kg, PL, X, PL);             // F^T K
+      TSTAMP(4)
+      gemm_t<true, false, 0>(tl, pt16, pt16, kd, Fm, PL, Kg, PL, X, PL);             // F^T K
       __syncthreads();
-      gemm_t<false, false, 2>(tid, pt16, pt16, kp, Vi, PL, X, PL, Qi, PL, Vi);        // Qm^-1 = Vm^-1 - Vm^-1 F^T K
-      __syncthreads();
-      if (tid < p) { double s = 0.0; for (int j = 0; j < p; ++j) s = fma(Qi[tid * PL + j], ev[j], s); uv[tid] = s; }
+      TSTAMP(5)
+      gemm_t<false, false, 2, true>(tl, pt16, pt16, kp, Vi, PL, X, PL, Qi, PL, Vi);  // Qm^-1 = Vm^-1 - Vm^-1 F^T K (symmetric)
     }
     __syncthreads();
-    // x1 = P C -> T1 ; P K ; x2 = C (P C) -> T2 ; C q
-    gemm_t<false, false, 0>(tid, dt16, dt16, kd, P, DL, C, DL, T1, DL);
-    if (any) gemm_t<false, false, 0>(tid, dt16, pt16, kd, P, DL, Kg, PL, PK, PL);
-    if (tid < d) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(C[tid * DL + k], qv[k], s); cq[tid] = s; }
+    TSTAMP(6)
+    // x1 = P C -> T1 ; P K ; u = Qm^-1 e ; C q
+    gemm_t<false, false, 0>(tl, dt16, dt16, kd, P, DL, C, DL, T1, DL);
+    if (any) gemm_t<false, false, 0>(tl, dt16, pt16, kd, P, DL, Kg, PL, PK, PL, nullptr, 1.0, 0, 0, 1);
+    {
+      const double su = any ? wave_matvec<false>(tl, VW, p, p, Qi, PL, ev) : 0.0;
+      const double sc = wave_matvec<false>(tl, VW, d, d, C, DL, qv);
+      if (any && vt >= 0 && vt < p) uv[vt] = su;
+      if (vt >= 0 && vt < d) cq[vt] = sc;
+    }
     __syncthreads();
-    gemm_t<false, false, 0>(tid, dt16, dt16, kd, C, DL, T1, DL, T2, DL);
+    TSTAMP(7)
+    // x2 = C (P C) -> T2 (symmetric) ; X = Qm^-1 + K^T P K (symmetric) on the waves the first product leaves idle ; u - K^T q
+    gemm_t<false, false, 0, true>(tl, dt16, dt16, kd, C, DL, T1, DL, T2, DL);
+    if (any && t > 0) {
+      gemm_t<true, false, 1, true>(tl, pt16, pt16, kd, Kg, PL, PK, PL, X, PL, Qi, 1.0, 0, 0, 6);
+      const double s = wave_matvec<true>(tl, VW, p, d, Kg, PL, qv);
+      if (vt >= 0 && vt < p) tv[vt] = uv[vt] - s;
+    }
     __syncthreads();
+    TSTAMP(8)
     double* o = out + (size_t)t * rec;
     if (tid < d) o[tid] = mv[tid] + cq[tid];                                          // s_t = m_t + C_t q_t
     FOR_CM(d, d, i, j) o[d + i + j * d] = C[i * DL + j] - T2[i * DL + j];                       // S_t
@@ -526,36 +717,39 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a) {
 
     // (q_{t-1}, P_{t-1})
     __syncthreads();
+    TSTAMP(9)
     if (any) {
-      gemm_t<true, false, 1>(tid, pt16, pt16, kd, Kg, PL, PK, PL, X, PL, Qi);         // X = Qm^-1 + K^T P K
-      if (tid < p) { double s = uv[tid]; for (int k = 0; k < d; ++k) s = fma(-Kg[k * PL + tid], qv[k], s); tv[tid] = s; }   // u - K^T q
+      gemm_t<false, false, 0>(tl, dt16, pt16, kp, Fm, PL, X, PL, CF, PL);            // F X   (T2 is free again)
+      {   // r = q + F (u - K^T q)
+        const double s = wave_matvec<false>(tl, VW, d, p, Fm, PL, tv);
+        if (vt >= 0 && vt < d) rv[vt] = qv[vt] + s;
+      }
       __syncthreads();
-      gemm_t<false, false, 0>(tid, dt16, pt16, kp, Fm, PL, X, PL, CF, PL);            // F X   (T2 is free again)
-      if (tid < d) { double s = qv[tid]; for (int j = 0; j < p; ++j) s = fma(Fm[tid * PL + j], tv[j], s); rv[tid] = s; }     // r
-      __syncthreads();
-      gemm_t<false, true, 1>(tid, dt16, dt16, kp, CF, PL, Fm, PL, P, DL, P);          // P += F X F^T
-      __syncthreads();
-      gemm_t<false, true, 2>(tid, dt16, dt16, kp, Fm, PL, PK, PL, P, DL, P);          // P -= F (P K)^T
-      __syncthreads();
-      gemm_t<false, true, 2>(tid, dt16, dt16, kp, PK, PL, Fm, PL, P, DL, P);          // P -= (P K) F^T   => M
-      __syncthreads();
-      // The expanded update treats P as exactly symmetric (it uses (P K)^T for K^T P).  Without this
-      // symmetrisation the antisymmetric rounding component is NOT contracted by (I - F K^T) and grows
-      // exponentially for unit-root models (polynomial trends with dense W): see DESIGN.md 4.3.
-      FOR_CM(d, d, i, j) if (i < j) { const double v = 0.5 * (P[i * DL + j] + P[j * DL + i]); P[i * DL + j] = v; P[j * DL + i] = v; }
-    } else if (tid < d) rv[tid] = qv[tid];
+      TSTAMP(10)
+      // M = P + (F X) F^T - F (P K)^T - (P K) F^T in one symmetric product.  The expanded update treats P as
+      // exactly symmetric (it uses (P K)^T for K^T P); an antisymmetric rounding component would NOT be
+      // contracted by (I - F K^T) and grows exponentially for unit-root models.  Computing the
+      // upper tiles and mirroring them keeps P symmetric by construction.
+      gemm_update3(tl, dt16, kp, CF, Fm, Fm, PK, PK, Fm, PL, P, DL, P);
+    } else if (vt >= 0 && vt < d) rv[vt] = qv[vt];
     __syncthreads();
-    {   // like Smoothing.smoothStep (Smoothing.scala:41): always the table entry g(dt), also for dt == 0
-      zero_lds(tid, T2, BIG);                                                          // keep the zero padding exact
-      __syncthreads();
-      load_cm(tid, Gt, d, d, T2, DL);                                                  // G -> T2
-      __syncthreads();
-      gemm_t<false, false, 0>(tid, dt16, dt16, kd, P, DL, T2, DL, T1, DL);             // M G
-      if (tid < d) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(T2[k * DL + tid], rv[k], s); qv[tid] = s; }        // q = G^T r
-      __syncthreads();
-      gemm_t<true, false, 0>(tid, dt16, dt16, kd, T2, DL, T1, DL, P, DL);              // P = G^T M G
+    TSTAMP(11)
+    // like Smoothing.smoothStep (Smoothing.scala:41): always the table entry g(dt), also for dt == 0
+    if (Gl) gemm_g<false, false, true>(tl, dt16, kd, P, DL, Glp, d, T1, DL);            // M G
+    else gemm_g<false, false, false>(tl, dt16, kd, P, DL, Gt, d, T1, DL);
+    {   // q = G^T r
+      const double s = Gl ? wave_matvec<true>(tl, VW, d, d, Glp, d, rv) : wave_matvec_g<true>(tl, VW, d, Gt, rv);
+      if (vt >= 0 && vt < d) qv[vt] = s;
     }
+    __syncthreads();
+    TSTAMP(12)
+    if (Gl) gemm_g<true, true, true>(tl, dt16, kd, T1, DL, Glp, d, P, DL);
+    else gemm_g<true, true, false>(tl, dt16, kd, T1, DL, Gt, d, P, DL);                           // P = G^T M G (symmetric)
+    TSTAMP(13)
   }
+#ifdef DLM_STAMP
+  if (n == 0 && tid == 0 && a.status) for (int k = 0; k < 16; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)(T + 1));
+#endif
   __syncthreads();
   bool bad = false;
   FOR_CM(d, d, i, j) bad |= !isfinite(T2[i * DL + j]) || !isfinite(C[i * DL + j]);
@@ -718,11 +912,11 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-hipError_t launch_tiled_filter(const KArgs& a, hipStream_t s) {
+hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s) {
   const size_t lds = tiled_filter_lds_bytes();
   hipError_t e = set_lds((const void*)k_filter_tiled<false>, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_filter_tiled<false>, dim3(a.N), dim3(NT), lds, s, a, (double*)nullptr, (double*)nullptr);
+  hipLaunchKernelGGL(k_filter_tiled<false>, dim3(a.N), dim3(NT), lds, s, a, (double*)nullptr, innov);
   return hipGetLastError();
 }
 
@@ -742,11 +936,11 @@ hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, 
   return hipGetLastError();
 }
 
-hipError_t launch_tiled_smoother(const KArgs& a, hipStream_t s) {
+hipError_t launch_tiled_smoother(const KArgs& a, const double* innov, hipStream_t s) {
   const size_t lds = tiled_smoother_lds_bytes();
   hipError_t e = set_lds((const void*)k_smoother_tiled, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_smoother_tiled, dim3(a.N), dim3(NT), lds, s, a);
+  hipLaunchKernelGGL(k_smoother_tiled, dim3(a.N), dim3(NT), lds, s, a, innov);
   return hipGetLastError();
 }
 
