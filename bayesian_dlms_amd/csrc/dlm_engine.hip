@@ -23,6 +23,8 @@ struct dlm_engine {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around the forward and backward kernels
   bool timed = false;
   dlm::SparseT* sp_dev = nullptr;  // [2 n_g]: row table, column table of every G (structured fast path)
+  dlm::SparseBig* spb_dev = nullptr;   // the same for the tiled path (d up to 48)
+  size_t spb_count = 0;
   size_t sp_count = 0;
   int sparse_k = 0;           // 0: some G is not structured (dense MFMA path, regular grids only)
   double* side = nullptr;     // forward->backward innovations buffer of the fused fast path
@@ -143,8 +145,35 @@ bool use_tiled(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dl
 
 // Inspect every G of the table (fast-path shapes only) and upload the sparse tables when all of them are
 // structured.  `G_user` is the caller's pointer (host or device according to host_mode).
-int analyse_g(dlm_engine* e, const KArgs& k, const double* G_user, bool host_mode) {
+int analyse_g_tiled(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
+  const size_t dd = (size_t)k.d * k.d, ng = (size_t)k.n_g;
+  std::vector<double> g(dd * ng);
+  if (host_mode) memcpy(g.data(), G_user, g.size() * sizeof(double));
+  else {
+    HIP_TRY(e, hipMemcpyAsync(g.data(), G_user, g.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  std::vector<dlm::SparseBig> tabs(2 * ng);
+  for (size_t q = 0; q < ng; ++q)
+    if (dlm::sparse48_analyse(g.data() + q * dd, k.d, &tabs[2 * q], &tabs[2 * q + 1]) > 4) return DLM_OK;   // dense G
+  int K = 1;
+  for (auto& t : tabs) K = t.K > K ? t.K : K;
+  for (auto& t : tabs) t.K = K;
+  if (tabs.size() > e->spb_count) {
+    if (e->spb_dev) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->spb_dev)); e->spb_dev = nullptr; }
+    HIP_TRY(e, hipMalloc((void**)&e->spb_dev, tabs.size() * sizeof(dlm::SparseBig)));
+    e->spb_count = tabs.size();
+  }
+  HIP_TRY(e, hipMemcpyAsync(e->spb_dev, tabs.data(), tabs.size() * sizeof(dlm::SparseBig), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));  // tabs lives on this stack frame
+  k.spb = e->spb_dev;
+  return DLM_OK;
+}
+
+int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   e->sparse_k = 0;
+  k.spb = nullptr;
+  if (use_tiled(k)) return analyse_g_tiled(e, k, G_user, host_mode);
   if (!fast_shape_ok(k)) return DLM_OK;
   const size_t dd = (size_t)k.d * k.d, ng = (size_t)k.n_g;
   std::vector<double> g(dd * ng);
@@ -278,6 +307,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->xplus) (void)hipFree(e->xplus);
   if (e->ystar) (void)hipFree(e->ystar);
   if (e->sp_dev) (void)hipFree(e->sp_dev);
+  if (e->spb_dev) (void)hipFree(e->spb_dev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;

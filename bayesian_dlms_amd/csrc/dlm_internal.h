@@ -25,6 +25,7 @@ struct KArgs {
   double* cond;
   double* stats;
   int* status;
+  const struct SparseBig* spb;   // tiled path: [2 n_g] row / column tables of a structured G, or nullptr (dense G)
   unsigned flags;
   unsigned long long seed, series_offset;
 };
@@ -60,6 +61,11 @@ hipError_t launch_sparse16_simsmooth(const KArgs& a, int K, const SparseT* tabs_
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s);
 
 // ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------
+// Nonzeros of the rows (`rows`) and of the columns (`cols`) of a d x d G with at most 4 per row and column (every
+// model the reference can build): the congruences G C G^T and G^T M G are then two gather passes instead of two
+// dense MFMA products.  sparse48_analyse returns the largest count, or 99 if G is not that sparse.
+struct SparseBig { int K; int pad; int idx[48][4]; double val[48][4]; };
+int sparse48_analyse(const double* G_host, int d, SparseBig* rows, SparseBig* cols);
 bool tiled_supported(const KArgs& a);
 // innov [N][T][p] (nullable for the filter): innovations y_t - f_t (NaN = missing) handed from the forward to the backward pass
 hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s);

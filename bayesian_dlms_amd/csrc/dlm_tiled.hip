@@ -37,6 +37,43 @@ constexpr int BIG = 48 * DL;    // doubles in a 48 x d-wide matrix
 constexpr int MID = 48 * PL;    // doubles in a 48 x p-wide matrix
 constexpr int SML = 32 * PL;    // doubles in a 32 x p-wide matrix
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence
+// makes the compiler wait for ALL outstanding memory operations (vmcnt(0)): every barrier that follows a step's
+// record stores or the next record's prefetch loads would then wait for HBM.  Nothing in these kernels exchanges data
+// through global memory inside a launch, so only the LDS queue has to drain.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- record I/O with a FIXED number of instructions per thread -----------------------------------------
+// Raw buffer loads/stores whose padded lanes carry an out-of-range offset (loads give 0, stores are dropped), in
+// loops with compile-time trip counts: the compiler then knows exactly how many vector-memory operations sit
+// between a prefetch and its use and waits with a counted vmcnt.  With data-dependent store loops it falls back to
+// vmcnt(0) at the first use of a prefetched value -- which, vector-memory operations retiring in order, also waits
+// for the record stores of the step before (8k of 51k cycles per backward step at C4).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+constexpr int OOB = 0x7ffffff0;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u2v v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return __hiloint2double((int)v[1], (int)v[0]);
+}
+__device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x) {
+  const u2v v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+// Byte offsets of this thread's share of a record [vector (n) | matrix (n x n, column-major)]: row i = lane,
+// columns j = wave + 8 q, q < 6; the vector element tid (threads 0..n-1).
+struct RecOff { int m[6]; int v; };
+__device__ __forceinline__ RecOff rec_offsets(int tid, int n) {
+  RecOff o;
+  const int i = tid & 63;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const int j = (tid >> 6) + NW * q; o.m[q] = (i < n && j < n) ? (n + i + j * n) * 8 : OOB; }
+  o.v = tid < n ? tid * 8 : OOB;
+  return o;
+}
+
 // C (mt x nt tiles) = op(A) op(B) combined with D, all row-major in LDS.  kb = number of 4-deep k-blocks.
 //   MODE 0: C = acc      1: C = D + acc      2: C = D - acc      (D in LDS, may alias C)
 //   MODE 3: C = acc + dscale * Dg, Dg a column-major drows x dcols matrix in GLOBAL memory (W dt, V): the
@@ -185,6 +222,72 @@ __device__ __forceinline__ void gemm_g(int tid, int mt, int kb, const double* L,
   }
 }
 
+__device__ __forceinline__ double bcast_lane(double v, int src) {   // lane `src` -> SGPR pair (uniform)
+  const int lo = __builtin_amdgcn_readlane((int)__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane((int)__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Z = T X T^T (+ add) for a structured T (at most K <= 4 nonzeros per row), all d x d row-major in LDS with leading
+// dimension DL; Y is scratch, Z may alias X.  Thread (lane i, wave w) owns the elements (i, w + 8 q): pass 1
+// Y[i][c] = sum_s X[i][idx_c[s]] val_c[s], barrier, pass 2 Z[r][i] = sum_s val_r[s] Y[idx_r[s]][i] with r = w + 8 q --
+// both passes read along conflict-free rows/columns and use the SAME six rows of the table of T per wave.  Those 24
+// entries live spread over the lanes of the wave (lane 4 q + s holds entry s of row w + 8 q: tix, tvl, loaded by
+// load_wave_table when the table changes) and are broadcast with v_readlane: no memory traffic, no latency.
+// 12 K multiply-adds per thread replace two dense MFMA products.
+// addw (nullable): this thread's six addends (W dt of the forward pass), for element (r, i).
+// A vector rides along as column d of the scratch: Y[.][d] = x on entry of pass 2 gives yv = T x from lane i == d.
+__device__ __forceinline__ void load_wave_table(int tid, int d, const SparseBig* __restrict__ tab, int& tix, double& tvl) {
+  const int l = tid & 63, r = (tid >> 6) + NW * (l >> 2);
+  const bool ok = l < 24 && r < d;
+  tix = ok ? tab->idx[r][l & 3] : 0;
+  tvl = ok ? tab->val[r][l & 3] : 0.0;
+}
+template <int K>
+__device__ __forceinline__ void sparse_congruence_k(int tid, int d, int tix, double tvl, const double* X, double* Y,
+                                                    double* Z, const double* addw, double ascale, const double* x, double* yv) {
+  const int i = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (w == VW && i < d) Y[i * DL + d] = x[i];
+  int ix[6][K];
+  double vl[6][K];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int s_ = 0; s_ < K; ++s_) { ix[q][s_] = __builtin_amdgcn_readlane(tix, 4 * q + s_); vl[q][s_] = bcast_lane(tvl, 4 * q + s_); }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int c = w + NW * q;
+    if (c < d && i < d) {
+      double acc = X[i * DL + ix[q][0]] * vl[q][0];
+#pragma unroll
+      for (int s_ = 1; s_ < K; ++s_) acc = fma(X[i * DL + ix[q][s_]], vl[q][s_], acc);
+      Y[i * DL + c] = acc;
+    }
+  }
+  lds_barrier();
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int r = w + NW * q;
+    if (r < d && i <= d) {
+      const double y0 = Y[ix[q][0] * DL + i] * vl[q][0];
+      double acc = (addw && i < d) ? fma(addw[q], ascale, y0) : y0;
+#pragma unroll
+      for (int s_ = 1; s_ < K; ++s_) acc = fma(Y[ix[q][s_] * DL + i], vl[q][s_], acc);
+      if (i < d) Z[r * DL + i] = acc;
+      else yv[r] = acc;
+    }
+  }
+}
+__device__ __forceinline__ void sparse_congruence(int tid, int d, int K, int tix, double tvl, const double* X, double* Y,
+                                                  double* Z, const double* addw, double ascale, const double* x, double* yv) {
+  switch (K) {   // wave-uniform
+    case 1: sparse_congruence_k<1>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
+    case 2: sparse_congruence_k<2>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
+    case 3: sparse_congruence_k<3>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
+    default: sparse_congruence_k<4>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
+  }
+}
+
 // M = D + A1 B1^T - A2 B2^T - A3 B3^T for a symmetric result (upper tiles, mirrored): the rank-3p update of the
 // backward recursion in ONE phase.  All operands row-major d x p in LDS with leading dimension ld.
 __device__ __forceinline__ void gemm_update3(int tid, int mt, int kb, const double* A1, const double* B1, const double* A2,
@@ -243,11 +346,6 @@ __device__ __forceinline__ double wave_matvec_g(int tid, int which, int n, const
 }
 
 
-__device__ __forceinline__ double bcast_lane(double v, int src) {   // lane `src` -> SGPR pair (uniform)
-  const int lo = __builtin_amdgcn_readlane((int)__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane((int)__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
 
 // In-place inverse of the SPD n x n (n <= 32) LDS matrix A (ld PL); Li is scratch.
 // Register-resident on wave 0: lane i holds row i (32 doubles); the Cholesky pivot quantities and the
@@ -263,7 +361,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __noinline__ bool spd_inverse(int tid, int n_, double* A, double* Li, int* bad_flag) {
   const int n = __builtin_amdgcn_readfirstlane(n_);   // uniform: the guards below must be scalar branches
-  __syncthreads();
+  lds_barrier();
   if (tid < 64) {
     const int lane = tid;
     double a[32], x[32];
@@ -310,7 +408,7 @@ __device__ __noinline__ bool spd_inverse(int tid, int n_, double* A, double* Li,
     }
     if (lane == 0) *bad_flag = bad ? 1 : 0;
   }
-  __syncthreads();
+  lds_barrier();
   return *bad_flag != 0;
 }
 
@@ -329,20 +427,20 @@ __device__ __forceinline__ void load_cm(int tid, const double* src, int rows, in
 __device__ bool chol_block(int tid, int n, double* A, int ld) {
   bool bad = false;
   for (int k = 0; k < n; ++k) {
-    __syncthreads();
+    lds_barrier();
     double akk = A[k * ld + k];
     if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
     const double lkk = sqrt(akk), inv = 1.0 / lkk;
-    __syncthreads();
+    lds_barrier();
     if (tid >= k && tid < n) A[tid * ld + k] = (tid == k) ? lkk : A[tid * ld + k] * inv;
-    __syncthreads();
+    lds_barrier();
     for (int j = (tid >> 6) + k + 1; j < n; j += NW)
       for (int i = (tid & 63); i < n; i += 64)
         if (i >= j) A[i * ld + j] = fma(-A[i * ld + k], A[j * ld + k], A[i * ld + j]);
   }
-  __syncthreads();
+  lds_barrier();
   for (int j = (tid >> 6); j < n; j += NW) for (int i = (tid & 63); i < n; i += 64) if (i < j) A[i * ld + j] = 0.0;
-  __syncthreads();
+  lds_barrier();
   return bad;
 }
 
@@ -360,9 +458,9 @@ __device__ __forceinline__ bool spd_inverse_warm(int tid, int n, const double* Q
   bool done = false;
   if (have_warm) {
     for (int it = 0; it < 6 && !done; ++it) {
-      __syncthreads();
+      lds_barrier();
       gemm_t<false, false, 0>(tid, nt, nt, kb, Q, PL, X, PL, E, PL);            // Q X
-      __syncthreads();
+      lds_barrier();
       bool big = false, far = false;
       FOR_CM(n, n, i, j) {
         const double e = ((i == j) ? 1.0 : 0.0) - E[i * PL + j];
@@ -376,10 +474,10 @@ __device__ __forceinline__ bool spd_inverse_warm(int tid, int n, const double* Q
       if (any_far && any_big) break;                                             // not contractive enough: go direct
       if (!any_big) done = true;   // ||E|| <= 2e-10: the update below squares it, i.e. lands on the fp64 floor
       gemm_t<false, false, 1>(tid, nt, nt, kb, X, PL, E, PL, Tn, PL, X);         // X + X E
-      __syncthreads();
+      lds_barrier();
       FOR_CM(n, n, i, j) X[i * PL + j] = 0.5 * (Tn[i * PL + j] + Tn[j * PL + i]);  // keep it symmetric
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (done) return false;
   if (dbg && tid == 0) dbg[1] += 1;
@@ -392,6 +490,29 @@ __device__ __forceinline__ bool spd_inverse_warm(int tid, int n, const double* Q
 #else
 #define TSTAMP(k)
 #endif
+
+int sparse48_analyse(const double* G /* d x d column-major, host */, int d, SparseBig* rows, SparseBig* cols) {
+  int kmax = 1;
+  for (int pass = 0; pass < 2; ++pass) {
+    SparseBig* t = pass ? cols : rows;
+    for (int j = 0; j < 48; ++j)
+      for (int s = 0; s < 4; ++s) { t->idx[j][s] = 0; t->val[j][s] = 0.0; }
+    for (int j = 0; j < d; ++j) {
+      int cnt = 0;
+      for (int l = 0; l < d; ++l) {
+        const double v = pass ? G[l + j * d] /* G[l][j] */ : G[j + l * d] /* G[j][l] */;
+        if (v != 0.0) {
+          if (cnt == 4) return 99;
+          t->idx[j][cnt] = l; t->val[j][cnt] = v; ++cnt;
+        }
+      }
+      if (cnt > kmax) kmax = cnt;
+    }
+  }
+  rows->K = cols->K = kmax;
+  rows->pad = cols->pad = 0;
+  return kmax;
+}
 
 bool tiled_supported(const KArgs& a) { return a.d >= 16 && a.d <= 48 && a.p <= 32; }
 
@@ -433,13 +554,13 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
   int st = 0;
 
   zero_lds(tid, sm, SIM ? FILT_SIM_DOUBLES : FILT_DOUBLES);
-  __syncthreads();
+  lds_barrier();
   load_cm(tid, a.C0 + (size_t)n * a.c0_stride, d, d, C, DL);
   load_cm(tid, a.F, d, p, Fm, PL);
   int gcur = a.g_index ? a.g_index[0] : 0;
   load_cm(tid, a.G + (size_t)gcur * dd, d, d, Gm, DL);
   if (tid < d) mv[tid] = (a.m0 + (size_t)n * a.m0_stride)[tid];
-  __syncthreads();
+  lds_barrier();
   const unsigned long long series = a.series_offset + (unsigned long long)n;
   const double* zin = (SIM && a.z) ? a.z + (size_t)n * (T + 1) * (d + p) : nullptr;
   double* xp = SIM ? xplus + (size_t)n * (T + 1) * d : nullptr;
@@ -453,15 +574,29 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
     const bool b1 = chol_block(tid, d, Lw, DL), b2 = chol_block(tid, p, Lv, PL), b3 = chol_block(tid, d, R, DL);
     if (b1 || b2 || b3) st |= DLM_ST_NOT_PD;
     if (tid < d) { double sx = mv[tid]; for (int k = 0; k <= tid; ++k) sx = fma(R[tid * DL + k], zv[k], sx); xv[tid] = sx; }
-    __syncthreads();
+    lds_barrier();
     if (tid < d) { xp[tid] = xv[tid]; mv[tid] = 0.0; }     // y* is filtered from a zero prior mean
-    __syncthreads();
+    lds_barrier();
   }
   FOR_CM(d, d, i, j) out[d + i + j * d] = C[i * DL + j];
   if (tid < d) out[tid] = mv[tid];
   if (pri) { FOR_CM(d, d, i, j) pri[d + i + j * d] = C[i * DL + j]; if (tid < d) pri[tid] = mv[tid]; }
   if (fq) for (int i = tid; i < frec; i += NT) fq[i] = __builtin_nan("");
 
+  // per-step record I/O with a fixed instruction count per thread (see rec_offsets): y is prefetched one step ahead
+  const int recb = rec * 8;
+  const __amdgpu_buffer_rsrc_t rfo = mk_rsrc(out, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rpr = mk_rsrc(pri ? pri : out, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t ry = mk_rsrc(y, (size_t)T * p * 8);
+  const __amdgpu_buffer_rsrc_t rys = mk_rsrc(ys ? ys : out, ys ? (size_t)T * p * 8 : 0);
+  const RecOff ro = rec_offsets(tid, d);
+  const int poff = tid < p ? tid * 8 : OOB;
+  double ynext = bld(ry, poff, 0);
+  int tabcur = -1, tix = 0;   // the wave's rows of the structured-G table, spread over its lanes (load_wave_table)
+  double tvl = 0.0;
+  double wreg[6];   // this thread's elements (r = wave + 8 q, i = lane) of W for the structured congruence
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const int r = (tid >> 6) + NW * q, i = tid & 63; wreg[q] = (a.spb && r < d && i < d) ? W[r + i * d] : 0.0; }
 #ifdef DLM_STAMP
   int dbgc[3] = {0, 0, 0};
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
@@ -473,36 +608,43 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
     asm volatile("" : "+v"(tl));
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
-    if (gi != gcur) { __syncthreads(); load_cm(tid, a.G + (size_t)gi * dd, d, d, Gm, DL); gcur = gi; }
-    if (a.f_stride) { __syncthreads(); load_cm(tid, a.F + (size_t)t * a.f_stride, d, p, Fm, PL); }
-    __syncthreads();
+    if (gi != gcur) { lds_barrier(); load_cm(tid, a.G + (size_t)gi * dd, d, d, Gm, DL); gcur = gi; }
+    if (a.f_stride) { lds_barrier(); load_cm(tid, a.F + (size_t)t * a.f_stride, d, p, Fm, PL); }
+    lds_barrier();
     // advState: a = G m, R = G C G^T + W dt   (dt == 0: a = m, R = C)
     if (dt == 0.0) {
       for (int idx = tid; idx < 48 * DL; idx += NT) R[idx] = C[idx];
       if (tid < d) av[tid] = mv[tid];
     } else {
-      gemm_t<false, false, 0>(tl, dt16, dt16, kd, Gm, DL, C, DL, Tm, DL);
-      { const double s = wave_matvec<false>(tl, VW, d, d, Gm, DL, mv); if (tid >= VW * 64 && tid - VW * 64 < d) av[tid - VW * 64] = s; }
-      __syncthreads();
-      gemm_t<false, true, 3, true>(tl, dt16, dt16, kd, Tm, DL, Gm, DL, R, DL, W, dt, d, d);   // (G C) G^T + W dt
+      if (a.spb) {   // structured G: two gather passes (rows of G) instead of two dense products; also a = G m
+        const SparseBig* tab = a.spb + 2 * gi;
+        if (gi != tabcur) { load_wave_table(tid, d, tab, tix, tvl); tabcur = gi; }
+        sparse_congruence(tl, d, tab->K, tix, tvl, C, Tm, R, wreg, dt, mv, av);
+      } else {
+        gemm_t<false, false, 0>(tl, dt16, dt16, kd, Gm, DL, C, DL, Tm, DL);
+        { const double s = wave_matvec<false>(tl, VW, d, d, Gm, DL, mv); if (tid >= VW * 64 && tid - VW * 64 < d) av[tid - VW * 64] = s; }
+        lds_barrier();
+        gemm_t<false, true, 3, true>(tl, dt16, dt16, kd, Tm, DL, Gm, DL, R, DL, W, dt, d, d);   // (G C) G^T + W dt
+      }
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(0)
     if (pri) {
-      double* pr = pri + (size_t)(t + 1) * rec;
-      if (tid < d) pr[tid] = av[tid];
-      FOR_CM(d, d, i, j) pr[d + i + j * d] = R[i * DL + j];
+      const int i = tid & 63, so = (t + 1) * recb;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) bst(rpr, ro.m[q], so, R[i * DL + (tid >> 6) + NW * q]);
+      bst(rpr, ro.v, so, av[i]);
     }
     // forecast: f = F^T a, RF = R F, Q = F^T R F + V
     gemm_t<false, false, 0>(tl, dt16, pt16, kd, R, DL, Fm, PL, RF, PL);
     { const double s = wave_matvec<true>(tl, VW, p, d, Fm, PL, av); if (tid >= VW * 64 && tid - VW * 64 < p) fv[tid - VW * 64] = s; }
-    __syncthreads();
+    lds_barrier();
     gemm_t<true, false, 3, true>(tl, pt16, pt16, kd, Fm, PL, RF, PL, Q, PL, V, 1.0, p, p);   // F^T (R F) + V
-    __syncthreads();
+    lds_barrier();
     if (SIM) {
       // x+_t = G x+_{t-1} + L_W z_x ;  y+_t = F^T x+_t + L_V z_y   (tv = new x+, then copied back)
       if (tid < d + p) zv[tid] = zin ? zin[(size_t)(t + 1) * (d + p) + tid] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)tid);
-      __syncthreads();
+      lds_barrier();
       double xn = 0.0;
       if (tid < d) {
         if (dt == 0.0) xn = xv[tid];
@@ -512,12 +654,14 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
           for (int k = 0; k <= tid; ++k) xn = fma(Lw[tid * DL + k] * sdt, zv[k], xn);
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (tid < d) { xv[tid] = xn; xp[(size_t)(t + 1) * d + tid] = xn; }
-      __syncthreads();
+      lds_barrier();
     }
+    const double ycur = ynext;
+    ynext = bld(ry, t + 1 < T ? poff : OOB, (t + 1 < T ? t + 1 : 0) * p * 8);
     if (tid < p) {
-      double yv = y[(size_t)t * p + tid];
+      double yv = ycur;
       if (SIM) {
         double yp = 0.0;
         for (int k = 0; k < d; ++k) yp = fma(Fm[k * PL + tid], xv[k], yp);
@@ -527,9 +671,9 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       }
       ob[tid] = (yv == yv) ? 1.0 : 0.0;
       ev[tid] = (yv == yv) ? yv - fv[tid] : 0.0;
-      if (!SIM && ys) ys[(size_t)t * p + tid] = yv - fv[tid];   // innovations for the fused backward pass (NaN = missing)
     }
-    __syncthreads();
+    if (!SIM) bst(rys, poff, t * p * 8, ycur - fv[tid & 31]);   // innovations for the fused backward pass (NaN = missing; dropped when not asked for)
+    lds_barrier();
     if (fq) {
       double* fr = fq + (size_t)(t + 1) * frec;
       if (tid < p) fr[tid] = fv[tid];
@@ -539,15 +683,15 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
     for (int j = 0; j < p; ++j) any |= ob[j] != 0.0;
     TSTAMP(1)
     if (!any) {   // updateState :74-75
-      __syncthreads();
+      lds_barrier();
       for (int idx = tid; idx < 48 * DL; idx += NT) C[idx] = R[idx];
       if (tid < d) mv[tid] = av[tid];
     } else {
       // Qm: missing rows/columns -> identity; inverse; back to zero
-      __syncthreads();
+      lds_barrier();
       zero_lds(tid, Tm, 2 * SML);
       zero_lds(tid, Kg, SML);
-      __syncthreads();
+      lds_barrier();
       FOR_CM(p, p, i, j) Qm[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? Q[i * PL + j] : (i == j ? 1.0 : 0.0);
       if (tid < p && ob[tid] == 0.0) Qi[tid * PL + tid] = 1.0;   // warm start: identity on the missing block
 #ifdef DLM_STAMP
@@ -557,24 +701,27 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
 #endif
       warm = true;
       FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Qi[i * PL + j] = 0.0;
-      __syncthreads();
+      lds_barrier();
       TSTAMP(2)
       gemm_t<false, false, 0>(tl, dt16, pt16, kp, RF, PL, Qi, PL, Kg, PL);          // K = R F Qm^-1
-      __syncthreads();
+      lds_barrier();
       { const double s = wave_matvec<false>(tl, VW, d, p, Kg, PL, ev); if (tid >= VW * 64 && tid - VW * 64 < d) mv[tid - VW * 64] = av[tid - VW * 64] + s; }
       gemm_t<false, true, 2, true>(tl, dt16, dt16, kp, Kg, PL, RF, PL, C, DL, R);    // C = R - K (R F)^T
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(3)
-    double* o = out + (size_t)(t + 1) * rec;
-    if (tid < d) o[tid] = mv[tid];
-    FOR_CM(d, d, i, j) o[d + i + j * d] = C[i * DL + j];
+    {
+      const int i = tid & 63, so = (t + 1) * recb;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) bst(rfo, ro.m[q], so, C[i * DL + (tid >> 6) + NW * q]);
+      bst(rfo, ro.v, so, mv[i]);
+    }
     TSTAMP(4)
   }
 #ifdef DLM_STAMP
   if (n == 0 && tid == 0 && a.status) { for (int k = 0; k < 8; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)T); a.status[6] = dbgc[0]; a.status[7] = dbgc[1]; a.status[9] = dbgc[2]; }
 #endif
-  __syncthreads();
+  lds_barrier();
   bool bad = false;
   FOR_CM(d, d, i, j) bad |= !isfinite(C[i * DL + j]);
   if (tid < d) bad |= !isfinite(mv[tid]);
@@ -602,32 +749,34 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
   const int vt = tid - VW * 64;   // lane index inside the vector-work wave (negative on the others)
   const double* V = a.V + (size_t)n * a.v_stride;
   const double* es = innov + (size_t)n * T * p;   // e_t = y_t - f_t from the forward pass (NaN = missing), record t <-> es[(t-1) p ..]
-  const double* fin = a.filt_in + (size_t)n * (T + 1) * rec;
-  double* out = a.smooth + (size_t)n * (T + 1) * rec;
+  const int recb = rec * 8;
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rout = mk_rsrc(a.smooth + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rinn = mk_rsrc(es, (size_t)T * p * 8);
+  const RecOff ro = rec_offsets(tid, d);
+  const int eoff = tid < p ? tid * 8 : OOB;
   int st = 0;
 
   zero_lds(tid, sm, SMTH_DOUBLES);
-  __syncthreads();
+  lds_barrier();
   load_cm(tid, a.F, d, p, Fm, PL);
-  int gcur = -1;
+  int gcur = -1, tabcur = -1, tix = 0;   // tix / tvl: the wave's rows of the structured-G table (load_wave_table)
+  double tvl = 0.0;
   if (tid < p) obp[tid] = -1.0;   // mask of the cached Vm^-1 (none yet)
-  __syncthreads();
+  lds_barrier();
 
   // register prefetch of the record stream and of the innovations, one step ahead
-  double pre[6], mcur = 0.0, ecur = __builtin_nan("");
-  {
-    const double* r = fin + (size_t)T * rec;
-    int q = 0;
-    for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
-    if (tid < d) mcur = r[tid];
-    if (tid < p && T > 0) ecur = es[(size_t)(T - 1) * p + tid];
-  }
+  double pre[6], mcur, ecur;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) pre[q] = bld(rin, ro.m[q], T * recb);
+  mcur = bld(rin, ro.v, T * recb);
+  ecur = bld(rinn, T > 0 ? eoff : OOB, (T > 0 ? T - 1 : 0) * p * 8);
 #ifdef DLM_STAMP
   unsigned long long seg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
   for (int t = T; t >= 0; --t) {
-    __syncthreads();
+    lds_barrier();
     TSTAMP(0)
     // an opaque copy of the thread index: keeps the compiler from hoisting the operand addresses of the dozen
     // products below out of the time loop, where they would occupy (and spill) a few hundred registers
@@ -635,60 +784,60 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
     asm volatile("" : "+v"(tl));
     {   // G of the step INTO record t (the regular grid has one): refresh the LDS copy when it changes
       const int gi = (a.g_index && t > 0) ? a.g_index[t - 1] : 0;
-      if (Gl && gi != gcur) {
+      if (Gl && !a.spb && gi != gcur) {
         const double* Gs = a.G + (size_t)gi * dd;
         for (int idx = tid; idx < dd; idx += NT) { const int k_ = idx % d, o_ = idx / d; Glp[k_ * d + o_] = Gs[idx]; }   // Gs is column-major
         gcur = gi;
       }
     }
     {
-      int q = 0;
-      for (int j = tid >> 6; j < d; j += NW, ++q) if ((tid & 63) < d) C[(tid & 63) * DL + j] = pre[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) if (ro.m[q] != OOB) C[(tid & 63) * DL + (tid >> 6) + NW * q] = pre[q];
       if (tid < d) mv[tid] = mcur;
       if (tid < p) {   // the lanes of wave 0: observation mask of this step and whether it repeats the cached one
-        const bool obs = (t > 0) && (ecur == ecur);
+        const bool obs = (t > 0) && (ecur == ecur);   // (an out-of-range load returns 0, but t > 0 guards it)
         ob[tid] = obs ? 1.0 : 0.0;
         ev[tid] = obs ? ecur : 0.0;
         const unsigned long long mo = __ballot(obs), md = __ballot((obs ? 1.0 : 0.0) != obp[tid]);
         if (tid == 0) { mp[0] = mo ? 1.0 : 0.0; mp[1] = md ? 0.0 : 1.0; }
       }
-      if (t > 0) {
-        const double* r = fin + (size_t)(t - 1) * rec;
-        q = 0;
-        for (int j = tid >> 6; j < d; j += NW, ++q) pre[q] = ((tid & 63) < d) ? r[d + (tid & 63) + j * d] : 0.0;
-        if (tid < d) mcur = r[tid];
-        if (tid < p) ecur = (t > 1) ? es[(size_t)(t - 2) * p + tid] : __builtin_nan("");
+      {   // next record and innovation (below record 0: record 0 again, unused)
+        const int tp = t > 0 ? t - 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) pre[q] = bld(rin, ro.m[q], tp * recb);
+        mcur = bld(rin, ro.v, tp * recb);
+        ecur = bld(rinn, t > 1 ? eoff : OOB, (t > 1 ? t - 2 : 0) * p * 8);
       }
     }
     if (a.f_stride && t > 0) load_cm(tid, a.F + (size_t)(t - 1) * a.f_stride, d, p, Fm, PL);
-    __syncthreads();
+    lds_barrier();
     TSTAMP(1)
     const bool any = mp[0] != 0.0, same = mp[1] != 0.0;
     const double* Gt = a.G + (size_t)((a.g_index && t > 0) ? a.g_index[t - 1] : 0) * dd;   // G of the step INTO record t
 
     if (any) {
       if (!same) {   // Vm^-1 for this missingness pattern (cached while the pattern repeats)
-        __syncthreads();
+        lds_barrier();
         FOR_CM(p, p, i, j) Vi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0);
         if (spd_inverse(tid, p, Vi, Li, (int*)(cq + 40))) st |= DLM_ST_NOT_PD;
         FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Vi[i * PL + j] = 0.0;
         if (tid < p) obp[tid] = ob[tid];
-        __syncthreads();
+        lds_barrier();
       }
       TSTAMP(2)
       // Every phase below is one or two MFMA products on waves 0.. plus the step's vector work on wave VW.
       gemm_t<false, false, 0>(tl, dt16, pt16, kd, C, DL, Fm, PL, CF, PL);            // C F
-      __syncthreads();
+      lds_barrier();
       TSTAMP(3)
       gemm_t<false, false, 0>(tl, dt16, pt16, kp, CF, PL, Vi, PL, Kg, PL);           // K = C F Vm^-1
-      __syncthreads();
+      lds_barrier();
       TSTAMP(4)
       gemm_t<true, false, 0>(tl, pt16, pt16, kd, Fm, PL, Kg, PL, X, PL);             // F^T K
-      __syncthreads();
+      lds_barrier();
       TSTAMP(5)
       gemm_t<false, false, 2, true>(tl, pt16, pt16, kp, Vi, PL, X, PL, Qi, PL, Vi);  // Qm^-1 = Vm^-1 - Vm^-1 F^T K (symmetric)
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(6)
     // x1 = P C -> T1 ; P K ; u = Qm^-1 e ; C q
     gemm_t<false, false, 0>(tl, dt16, dt16, kd, P, DL, C, DL, T1, DL);
@@ -699,7 +848,7 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
       if (any && vt >= 0 && vt < p) uv[vt] = su;
       if (vt >= 0 && vt < d) cq[vt] = sc;
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(7)
     // x2 = C (P C) -> T2 (symmetric) ; X = Qm^-1 + K^T P K (symmetric) on the waves the first product leaves idle ; u - K^T q
     gemm_t<false, false, 0, true>(tl, dt16, dt16, kd, C, DL, T1, DL, T2, DL);
@@ -708,15 +857,19 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
       const double s = wave_matvec<true>(tl, VW, p, d, Kg, PL, qv);
       if (vt >= 0 && vt < p) tv[vt] = uv[vt] - s;
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP(8)
-    double* o = out + (size_t)t * rec;
-    if (tid < d) o[tid] = mv[tid] + cq[tid];                                          // s_t = m_t + C_t q_t
-    FOR_CM(d, d, i, j) o[d + i + j * d] = C[i * DL + j] - T2[i * DL + j];                       // S_t
+    {   // s_t = m_t + C_t q_t ; S_t = C_t - C_t P_t C_t  (7 stores per thread; rows >= 48 of the lane index read
+        // in-bounds scratch that is never stored)
+      const int i = tid & 63, so = t * recb;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { const int j = (tid >> 6) + NW * q; bst(rout, ro.m[q], so, C[i * DL + j] - T2[i * DL + j]); }
+      bst(rout, ro.v, so, mv[tid & 63] + cq[tid & 63]);
+    }
     if (t == 0) break;
 
     // (q_{t-1}, P_{t-1})
-    __syncthreads();
+    lds_barrier();
     TSTAMP(9)
     if (any) {
       gemm_t<false, false, 0>(tl, dt16, pt16, kp, Fm, PL, X, PL, CF, PL);            // F X   (T2 is free again)
@@ -724,7 +877,7 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
         const double s = wave_matvec<false>(tl, VW, d, p, Fm, PL, tv);
         if (vt >= 0 && vt < d) rv[vt] = qv[vt] + s;
       }
-      __syncthreads();
+      lds_barrier();
       TSTAMP(10)
       // M = P + (F X) F^T - F (P K)^T - (P K) F^T in one symmetric product.  The expanded update treats P as
       // exactly symmetric (it uses (P K)^T for K^T P); an antisymmetric rounding component would NOT be
@@ -732,25 +885,32 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
       // upper tiles and mirroring them keeps P symmetric by construction.
       gemm_update3(tl, dt16, kp, CF, Fm, Fm, PK, PK, Fm, PL, P, DL, P);
     } else if (vt >= 0 && vt < d) rv[vt] = qv[vt];
-    __syncthreads();
+    lds_barrier();
     TSTAMP(11)
     // like Smoothing.smoothStep (Smoothing.scala:41): always the table entry g(dt), also for dt == 0
-    if (Gl) gemm_g<false, false, true>(tl, dt16, kd, P, DL, Glp, d, T1, DL);            // M G
-    else gemm_g<false, false, false>(tl, dt16, kd, P, DL, Gt, d, T1, DL);
-    {   // q = G^T r
-      const double s = Gl ? wave_matvec<true>(tl, VW, d, d, Glp, d, rv) : wave_matvec_g<true>(tl, VW, d, Gt, rv);
-      if (vt >= 0 && vt < d) qv[vt] = s;
-    }
-    __syncthreads();
-    TSTAMP(12)
-    if (Gl) gemm_g<true, true, true>(tl, dt16, kd, T1, DL, Glp, d, P, DL);
-    else gemm_g<true, true, false>(tl, dt16, kd, T1, DL, Gt, d, P, DL);                           // P = G^T M G (symmetric)
+    if (a.spb) {   // structured G: P = G^T M G and q = G^T r as gathers with the columns of G
+      const int gi = (a.g_index && t > 0) ? a.g_index[t - 1] : 0;
+      const SparseBig* tab = a.spb + 2 * gi + 1;
+      if (gi != tabcur) { load_wave_table(tid, d, tab, tix, tvl); tabcur = gi; }
+      sparse_congruence(tl, d, tab->K, tix, tvl, P, T1, P, nullptr, 0.0, rv, qv);
+    } else {
+      if (Gl) gemm_g<false, false, true>(tl, dt16, kd, P, DL, Glp, d, T1, DL);            // M G
+      else gemm_g<false, false, false>(tl, dt16, kd, P, DL, Gt, d, T1, DL);
+      {   // q = G^T r
+        const double s = Gl ? wave_matvec<true>(tl, VW, d, d, Glp, d, rv) : wave_matvec_g<true>(tl, VW, d, Gt, rv);
+        if (vt >= 0 && vt < d) qv[vt] = s;
+      }
+      lds_barrier();
+      TSTAMP(12)
+      if (Gl) gemm_g<true, true, true>(tl, dt16, kd, T1, DL, Glp, d, P, DL);
+      else gemm_g<true, true, false>(tl, dt16, kd, T1, DL, Gt, d, P, DL);
+    }                           // P = G^T M G (symmetric)
     TSTAMP(13)
   }
 #ifdef DLM_STAMP
   if (n == 0 && tid == 0 && a.status) for (int k = 0; k < 16; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)(T + 1));
 #endif
-  __syncthreads();
+  lds_barrier();
   bool bad = false;
   FOR_CM(d, d, i, j) bad |= !isfinite(T2[i * DL + j]) || !isfinite(C[i * DL + j]);
   if (__syncthreads_or(bad)) st |= DLM_ST_NONFINITE;
@@ -785,7 +945,7 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
   int st = 0;
 
   zero_lds(tid, sm, SIMS_DOUBLES);
-  __syncthreads();
+  lds_barrier();
   load_cm(tid, a.F, d, p, Fm, PL);
   if (tid < p) obp[tid] = -1.0;
   double pre[6], mcur = 0.0, mnext = 0.0;
@@ -796,7 +956,7 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
     if (tid < d) { mcur = r[tid]; mnext = (T > 0) ? (r - rec)[tid] : 0.0; }
   }
   for (int t = T; t >= 0; --t) {
-    __syncthreads();
+    lds_barrier();
     {
       int q = 0;
       for (int j = tid >> 6; j < d; j += NW, ++q) if ((tid & 63) < d) C[(tid & 63) * DL + j] = pre[q];
@@ -811,7 +971,7 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
     if (a.f_stride && t > 0) load_cm(tid, a.F + (size_t)(t - 1) * a.f_stride, d, p, Fm, PL);
     if (tid < p) { const double yv = (t > 0) ? ys[(size_t)(t - 1) * p + tid] : __builtin_nan(""); ob[tid] = (yv == yv) ? 1.0 : 0.0; tv[tid] = yv; }
     const double xcur = (tid < d) ? xp[(size_t)t * d + tid] : 0.0;
-    __syncthreads();
+    lds_barrier();
     bool any = false, same = true;
     for (int j = 0; j < p; ++j) { any |= ob[j] != 0.0; same &= ob[j] == obp[j]; }
     const double* Gt = a.G + (size_t)((a.g_index && t > 0) ? a.g_index[t - 1] : 0) * dd;   // G of the step INTO record t
@@ -824,7 +984,7 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
       thc[tid] = s;
       if (thout) thout[(size_t)t * d + tid] = s;
     }
-    __syncthreads();
+    lds_barrier();
     if (a.stats) {
       if (t < T) {   // system innovation theta_{t+1} - G_{t+1} theta_t
         const double* Gn = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
@@ -837,7 +997,7 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
           dfv[tid] = s / sqrt(dts);
           ssd[tid] = fma(s, s / dts, ssd[tid]);
         }
-        __syncthreads();
+        lds_barrier();
         if (outer) FOR_CM(d, d, i, j) OUT[i * DL + j] = fma(dfv[i], dfv[j], OUT[i * DL + j]);
       }
       if (t > 0 && y && tid < p) {   // observation residual of theta_t against the ORIGINAL y_t
@@ -849,18 +1009,18 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < d) thn[tid] = thc[tid];
     if (t == 0) break;
 
     if (any) {
       if (!same) {
-        __syncthreads();
+        lds_barrier();
         FOR_CM(p, p, i, j) Vi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0);
         if (spd_inverse(tid, p, Vi, Li, (int*)flagv)) st |= DLM_ST_NOT_PD;
         FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Vi[i * PL + j] = 0.0;
         if (tid < p) obp[tid] = ob[tid];
-        __syncthreads();
+        lds_barrier();
       }
       gemm_t<false, false, 0>(tid, dt16, pt16, kd, C, DL, Fm, PL, CF, PL);            // C F
       if (tid < d) {
@@ -869,24 +1029,24 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
         else for (int k = 0; k < d; ++k) s = fma(Gt[tid + k * d], mp[k], s);
         rv[tid] = s;   // a*_t
       }
-      __syncthreads();
+      lds_barrier();
       gemm_t<false, false, 0>(tid, dt16, pt16, kp, CF, PL, Vi, PL, Kg, PL);           // K = C F Vm^-1
       if (tid < p) { double s = 0.0; for (int k = 0; k < d; ++k) s = fma(Fm[k * PL + tid], rv[k], s); ev[tid] = (ob[tid] != 0.0) ? tv[tid] - s : 0.0; }
-      __syncthreads();
+      lds_barrier();
       gemm_t<true, false, 0>(tid, pt16, pt16, kd, Fm, PL, Kg, PL, X, PL);             // F^T K
-      __syncthreads();
+      lds_barrier();
       gemm_t<false, false, 2>(tid, pt16, pt16, kp, Vi, PL, X, PL, Qi, PL, Vi);        // Qm^-1
-      __syncthreads();
+      lds_barrier();
       if (tid < p) {
         double s = 0.0;
         for (int j = 0; j < p; ++j) s = fma(Qi[tid * PL + j], ev[j], s);              // u = Qm^-1 e
         for (int k = 0; k < d; ++k) s = fma(-Kg[k * PL + tid], qv[k], s);             // - K^T q
         uv[tid] = s;
       }
-      __syncthreads();
+      lds_barrier();
       if (tid < d) { double s = qv[tid]; for (int j = 0; j < p; ++j) s = fma(Fm[tid * PL + j], uv[j], s); rv[tid] = s; }
     } else if (tid < d) rv[tid] = qv[tid];
-    __syncthreads();
+    lds_barrier();
     if (tid < d) {
       double s = 0.0;
       if (dtt == 0.0) s = rv[tid];
@@ -894,7 +1054,7 @@ __global__ __launch_bounds__(NT) void k_simsmooth_tiled(KArgs a, const double* _
       qv[tid] = s;
     }
   }
-  __syncthreads();
+  lds_barrier();
   bool bad = (tid < d) && !isfinite(thn[tid]);
   if (__syncthreads_or(bad)) st |= DLM_ST_NONFINITE;
   if (a.stats) {
