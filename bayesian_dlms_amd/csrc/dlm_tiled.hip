@@ -43,6 +43,12 @@ constexpr int SML = 32 * PL;    // doubles in a 32 x p-wide matrix
 // through global memory inside a launch, so only the LDS queue has to drain.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+__device__ __forceinline__ void wsync() {   // LDS hand-off inside ONE wavefront (in-order LDS queue)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- record I/O with a FIXED number of instructions per thread -----------------------------------------
 // Raw buffer loads/stores whose padded lanes carry an out-of-range offset (loads give 0, stores are dropped), in
 // loops with compile-time trip counts: the compiler then knows exactly how many vector-memory operations sit
@@ -85,7 +91,9 @@ __device__ __forceinline__ RecOff rec_offsets(int tid, int n) {
 // SIMD: 6 tiles instead of 9 is 20 against 30 on it.  Waves w and w + 4 share a SIMD; tile q goes to wave q % 8.
 // `shift` rotates the tile -> wave assignment (tile q on wave (q + shift) % 8) so that two products issued in
 // the same phase load the SIMDs evenly.
-template <bool TA, bool TB, int MODE, bool SYM = false>
+// AVG (with SYM): a diagonal tile holds both triangles, rounded differently; average them so that the result is
+// EXACTLY symmetric (the wave that computed the tile owns all of it: a wave-level hand-off through LDS suffices).
+template <bool TA, bool TB, int MODE, bool SYM = false, bool AVG = false>
 __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const double* A, int lda, const double* B,
                                        int ldb, double* C, int ldc, const double* D = nullptr, double dscale = 1.0,
                                        int drows = 0, int dcols = 0, int shift = 0) {
@@ -110,6 +118,7 @@ __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const do
   }
   const int as = TA ? 4 * lda : 4, bs = TB ? 4 : 4 * ldb;    // stride of one k-block
   d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  d4 dg[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};   // MODE 3: the global addend, requested now, added after the chain
   if (MODE == 3) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -117,7 +126,7 @@ __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const do
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = ti[q] * 16 + 4 * r + g, j = tj[q] * 16 + c;
-        acc[q][r] = (i < drows && j < dcols) ? dscale * D[i + (size_t)j * drows] : 0.0;
+        dg[q][r] = (i < drows && j < dcols) ? D[i + (size_t)j * drows] : 0.0;
       }
     }
   }
@@ -139,11 +148,22 @@ __device__ __forceinline__ void gemm_t(int tid, int mt, int nt, int kb, const do
     for (int r = 0; r < 4; ++r) {
       const int o = (i0 + 4 * r + g) * ldc + j0 + c;
       double v;
-      if (MODE == 0 || MODE == 3) v = acc[q][r];
+      if (MODE == 0) v = acc[q][r];
+      else if (MODE == 3) v = fma(dscale, dg[q][r], acc[q][r]);
       else if (MODE == 1) v = D[o] + acc[q][r];
       else v = D[o] - acc[q][r];
       C[o] = v;
       if (SYM && i0 != j0) C[(j0 + c) * ldc + i0 + 4 * r + g] = v;
+      if (AVG) acc[q][r] = v;
+    }
+    if (SYM && AVG && i0 == j0) {
+      wsync();
+      d4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = C[(i0 + c) * ldc + i0 + 4 * r + g];
+      wsync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C[(i0 + 4 * r + g) * ldc + i0 + c] = 0.5 * (acc[q][r] + w[r]);
     }
   }
 }
@@ -168,11 +188,6 @@ __device__ __forceinline__ double wave_matvec(int tid, int which, int rows, int 
   return (s0 + s1) + (s2 + s3);
 }
 
-__device__ __forceinline__ void wsync() {   // LDS hand-off inside ONE wavefront (in-order LDS queue)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Products with the d x d transition G of the backward pass.  G is kept in LDS as a compact row-major copy (leading
 // dimension gd = d, no padding: both access patterns below run along a row, so any leading dimension is conflict
@@ -243,9 +258,13 @@ __device__ __forceinline__ void load_wave_table(int tid, int d, const SparseBig*
   tix = ok ? tab->idx[r][l & 3] : 0;
   tvl = ok ? tab->val[r][l & 3] : 0.0;
 }
+// Branch-free: every lane reads in-bounds addresses (rows up to 63 of a 48-row matrix run into the next LDS
+// buffer, harmlessly) and lanes without an element store to `trash`, so that the 6 K reads of a pass are all in
+// flight together instead of one exec-masked block per element.
 template <int K>
 __device__ __forceinline__ void sparse_congruence_k(int tid, int d, int tix, double tvl, const double* X, double* Y,
-                                                    double* Z, const double* addw, double ascale, const double* x, double* yv) {
+                                                    double* Z, const double* addw, double ascale, const double* x, double* yv,
+                                                    double* trash) {
   const int i = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (w == VW && i < d) Y[i * DL + d] = x[i];
   int ix[6][K];
@@ -254,37 +273,44 @@ __device__ __forceinline__ void sparse_congruence_k(int tid, int d, int tix, dou
   for (int q = 0; q < 6; ++q)
 #pragma unroll
     for (int s_ = 0; s_ < K; ++s_) { ix[q][s_] = __builtin_amdgcn_readlane(tix, 4 * q + s_); vl[q][s_] = bcast_lane(tvl, 4 * q + s_); }
+  double in[6][K];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int s_ = 0; s_ < K; ++s_) in[q][s_] = X[i * DL + ix[q][s_]];
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
     const int c = w + NW * q;
-    if (c < d && i < d) {
-      double acc = X[i * DL + ix[q][0]] * vl[q][0];
+    double acc = in[q][0] * vl[q][0];
 #pragma unroll
-      for (int s_ = 1; s_ < K; ++s_) acc = fma(X[i * DL + ix[q][s_]], vl[q][s_], acc);
-      Y[i * DL + c] = acc;
-    }
+    for (int s_ = 1; s_ < K; ++s_) acc = fma(in[q][s_], vl[q][s_], acc);
+    double* dst = (c < d && i < d) ? Y + i * DL + c : trash;
+    *dst = acc;
   }
   lds_barrier();
 #pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int s_ = 0; s_ < K; ++s_) in[q][s_] = Y[ix[q][s_] * DL + i];
+#pragma unroll
   for (int q = 0; q < 6; ++q) {
     const int r = w + NW * q;
-    if (r < d && i <= d) {
-      const double y0 = Y[ix[q][0] * DL + i] * vl[q][0];
-      double acc = (addw && i < d) ? fma(addw[q], ascale, y0) : y0;
+    const double y0 = in[q][0] * vl[q][0];
+    double acc = (addw && i < d) ? fma(addw[q], ascale, y0) : y0;
 #pragma unroll
-      for (int s_ = 1; s_ < K; ++s_) acc = fma(Y[ix[q][s_] * DL + i], vl[q][s_], acc);
-      if (i < d) Z[r * DL + i] = acc;
-      else yv[r] = acc;
-    }
+    for (int s_ = 1; s_ < K; ++s_) acc = fma(in[q][s_], vl[q][s_], acc);
+    double* dst = (r < d && i < d) ? Z + r * DL + i : ((r < d && i == d) ? yv + r : trash);
+    *dst = acc;
   }
 }
 __device__ __forceinline__ void sparse_congruence(int tid, int d, int K, int tix, double tvl, const double* X, double* Y,
-                                                  double* Z, const double* addw, double ascale, const double* x, double* yv) {
+                                                  double* Z, const double* addw, double ascale, const double* x, double* yv,
+                                                  double* trash) {
   switch (K) {   // wave-uniform
-    case 1: sparse_congruence_k<1>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
-    case 2: sparse_congruence_k<2>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
-    case 3: sparse_congruence_k<3>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
-    default: sparse_congruence_k<4>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv); break;
+    case 1: sparse_congruence_k<1>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv, trash); break;
+    case 2: sparse_congruence_k<2>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv, trash); break;
+    case 3: sparse_congruence_k<3>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv, trash); break;
+    default: sparse_congruence_k<4>(tid, d, tix, tvl, X, Y, Z, addw, ascale, x, yv, trash); break;
   }
 }
 
@@ -451,37 +477,75 @@ __device__ bool chol_block(int tid, int n, double* A, int ld) {
 // warm start is too far off (first step, missingness pattern changed: n max|E| >= 0.5) or it has not
 // converged (max|E| <= 2e-10) in 6 iterations, the direct register Cholesky takes over.  E and Tn are p x p scratch.
 // Every thread must call.  Returns whether the direct path met a non-positive pivot.
-__device__ __forceinline__ bool spd_inverse_warm(int tid, int n, const double* Q, double* X, double* E, double* Tn,
-                                                 double* Li, int* flag, bool have_warm, int* dbg = nullptr) {
+// E = I - Q X (n x n, up to 2 x 2 tiles on waves 0..3) with the residual tests folded into the epilogue:
+// big = some |E_ij| > tol, far = some n |E_ij| >= 0.5 (entries i, j < n only).
+__device__ __forceinline__ void gemm_resid(int tid, int nt, int kb, int n, const double* Q, const double* X, double* E,
+                                           double tol, bool& big, bool& far) {
+  const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  if (wave >= nt * nt) return;
+  const int i0 = (wave / nt) * 16, j0 = (wave % nt) * 16;
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < kb; ++kk)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Q[(i0 + c) * PL + g + 4 * kk], X[(g + 4 * kk) * PL + j0 + c], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 4 * r + g, j = j0 + c;
+    const double e = ((i == j) ? 1.0 : 0.0) - acc[r];
+    E[i * PL + j] = e;
+    if (i < n && j < n) { big |= !(fabs(e) <= tol); far |= !(fabs(e) * n < 0.5); }
+  }
+}
+// Workgroup-wide OR of two predicates with ONE barrier: wave ballots, one LDS atomic per wave that has something
+// to report.  `slot` must be zero on entry (nobody touches it between the previous barrier and this call); `other`
+// (the slot of the next call) is cleared for that call.  Returns bit 0 = any a, bit 1 = any b.
+__device__ __forceinline__ int block_or2(int tid, bool a, bool b, int* slot, int* other) {
+  const unsigned long long ba = __ballot(a), bb = __ballot(b);
+  if ((tid & 63) == 0) { const int v = (ba ? 1 : 0) | (bb ? 2 : 0); if (v) atomicOr(slot, v); }
+  lds_barrier();
+  const int r = *slot;
+  if (tid == 0) *other = 0;
+  return r;
+}
+
+// In-place inverse of an SPD matrix by Newton-Schulz refinement of a warm start, on the MFMA pipe:
+//   E = I - Q X ,  X <- X + X E        (||E|| squares every iteration)
+// X holds the inverse of the previous time step's Q on entry (Q_t changes slowly: one or two iterations at steady
+// state).  The iterates ping-pong between X and Xalt (any idle n x n buffer); *Xout tells where the verified inverse
+// ended up.  An iteration is two small products and two barriers: the residual test rides in the epilogue of the
+// first (gemm_resid + block_or2) and X + X E = 2X - X Q X is symmetric, so the second writes its upper tiles to both
+// places and averages the two triangles of its diagonal tiles: the antisymmetric part of X is a neutral mode of the
+// iteration and, left alone, drifts from step to step until the residual test can no longer be met.  If the warm start is too far off (first step, missingness pattern
+// changed: n max|E| >= 0.5) or it has not converged (max|E| <= 2e-10) in 6 iterations, the direct register Cholesky
+// takes over (into X).  Padding: Q and X must be zero outside n x n up to 16 nt (X stays so).  Every thread must call.
+// Returns whether the direct path met a non-positive pivot.
+__device__ __forceinline__ bool spd_inverse_warm(int tid, int n, const double* Q, double* X, double* Xalt, double* E,
+                                                 double* Li, int* flag, int* orflags, bool have_warm, double** Xout,
+                                                 int* dbg = nullptr) {
   const int nt = (n + 15) / 16, kb = (n + 3) / 4;
   const double tol = 2e-10;   // the fp64 floor of max|I - Q X| is ~n cond(Q) eps (1e-11 here, no better for the direct inverse)
   bool done = false;
+  double* cur = X;
+  double* alt = Xalt;
   if (have_warm) {
+    if (tid == 0) { orflags[0] = 0; orflags[1] = 0; }
     for (int it = 0; it < 6 && !done; ++it) {
       lds_barrier();
-      gemm_t<false, false, 0>(tid, nt, nt, kb, Q, PL, X, PL, E, PL);            // Q X
-      lds_barrier();
       bool big = false, far = false;
-      FOR_CM(n, n, i, j) {
-        const double e = ((i == j) ? 1.0 : 0.0) - E[i * PL + j];
-        E[i * PL + j] = e;
-        big |= !(fabs(e) <= tol);
-        far |= !(fabs(e) * n < 0.5);
-      }
-      const int any_far = __syncthreads_or(far);
-      const int any_big = __syncthreads_or(big);
+      gemm_resid(tid, nt, kb, n, Q, cur, E, tol, big, far);
+      const int bits = block_or2(tid, big, far, orflags + (it & 1), orflags + ((it + 1) & 1));
+      const bool any_big = (bits & 1) != 0, any_far = (bits & 2) != 0;
       if (dbg && tid == 0) { dbg[0] += 1; if (any_far) dbg[2] += 1; }
       if (any_far && any_big) break;                                             // not contractive enough: go direct
       if (!any_big) done = true;   // ||E|| <= 2e-10: the update below squares it, i.e. lands on the fp64 floor
-      gemm_t<false, false, 1>(tid, nt, nt, kb, X, PL, E, PL, Tn, PL, X);         // X + X E
-      lds_barrier();
-      FOR_CM(n, n, i, j) X[i * PL + j] = 0.5 * (Tn[i * PL + j] + Tn[j * PL + i]);  // keep it symmetric
+      gemm_t<false, false, 1, true, true>(tid, nt, nt, kb, cur, PL, E, PL, alt, PL, cur);   // alt = cur + cur E, exactly symmetric
+      double* sw = cur; cur = alt; alt = sw;
     }
     lds_barrier();
   }
-  if (done) return false;
+  if (done) { *Xout = cur; return false; }
   if (dbg && tid == 0) dbg[1] += 1;
   FOR_CM(n, n, i, j) X[i * PL + j] = Q[i * PL + j];
+  *Xout = X;
   return spd_inverse(tid, n, X, Li, flag);
 }
 
@@ -542,7 +606,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
   double* mv = Qi + SML;     double* av = mv + 48;    double* ev = av + 48;    double* fv = ev + 48;
   double* ob = fv + 48;      // observed flags (1.0 / 0.0)
   // scratch of the inverse, aliasing buffers that are idle between the forecast and the gain
-  double* Qm = Tm;           double* Es = Tm + SML;   double* Tn = Kg;         double* Li = Es;
+  double* Qm = Tm;           double* Es = Tm + SML;   double* Li = Es;
   bool warm = false;
   double* Lw = sm + FILT_DOUBLES;  double* Lv = Lw + BIG;   double* xv = Lv + SML;   double* zv = xv + 48;   // SIM only
   const double* V = a.V + (size_t)n * a.v_stride;
@@ -619,7 +683,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       if (a.spb) {   // structured G: two gather passes (rows of G) instead of two dense products; also a = G m
         const SparseBig* tab = a.spb + 2 * gi;
         if (gi != tabcur) { load_wave_table(tid, d, tab, tix, tvl); tabcur = gi; }
-        sparse_congruence(tl, d, tab->K, tix, tvl, C, Tm, R, wreg, dt, mv, av);
+        sparse_congruence(tl, d, tab->K, tix, tvl, C, Tm, R, wreg, dt, mv, av, ob + 46);
       } else {
         gemm_t<false, false, 0>(tl, dt16, dt16, kd, Gm, DL, C, DL, Tm, DL);
         { const double s = wave_matvec<false>(tl, VW, d, d, Gm, DL, mv); if (tid >= VW * 64 && tid - VW * 64 < d) av[tid - VW * 64] = s; }
@@ -671,6 +735,8 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       }
       ob[tid] = (yv == yv) ? 1.0 : 0.0;
       ev[tid] = (yv == yv) ? yv - fv[tid] : 0.0;
+      const unsigned long long mo = __ballot(yv == yv), mm = __ballot(!(yv == yv));   // the p lanes are all in wave 0
+      if (tid == 0) { ob[44] = mo ? 1.0 : 0.0; ob[45] = mm ? 0.0 : 1.0; }
     }
     if (!SIM) bst(rys, poff, t * p * 8, ycur - fv[tid & 31]);   // innovations for the fused backward pass (NaN = missing; dropped when not asked for)
     lds_barrier();
@@ -679,31 +745,31 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
       if (tid < p) fr[tid] = fv[tid];
       FOR_CM(p, p, i, j) fr[p + i + j * p] = Q[i * PL + j];
     }
-    bool any = false;
-    for (int j = 0; j < p; ++j) any |= ob[j] != 0.0;
+    const bool any = ob[44] != 0.0, allobs = ob[45] != 0.0;   // wave 0's ballots, published before the last barrier
     TSTAMP(1)
+    double* Xf = Qi;   // where this step's Qm^-1 ends up (Qi or the idle C buffer)
     if (!any) {   // updateState :74-75
       lds_barrier();
       for (int idx = tid; idx < 48 * DL; idx += NT) C[idx] = R[idx];
       if (tid < d) mv[tid] = av[tid];
     } else {
-      // Qm: missing rows/columns -> identity; inverse; back to zero
-      lds_barrier();
-      zero_lds(tid, Tm, 2 * SML);
-      zero_lds(tid, Kg, SML);
-      lds_barrier();
-      FOR_CM(p, p, i, j) Qm[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? Q[i * PL + j] : (i == j ? 1.0 : 0.0);
-      if (tid < p && ob[tid] == 0.0) Qi[tid * PL + tid] = 1.0;   // warm start: identity on the missing block
+      // Qm: Q with the missing rows/columns replaced by the identity, zero padding up to 32 x 32 (it aliases scratch)
+      FOR_CM(32, 32, i, j) Qm[i * PL + j] = (i < p && j < p) ? ((ob[i] != 0.0 && ob[j] != 0.0) ? Q[i * PL + j] : (i == j ? 1.0 : 0.0)) : 0.0;
+      if (!allobs && tid < p && ob[tid] == 0.0) Qi[tid * PL + tid] = 1.0;   // warm start: identity on the missing block
 #ifdef DLM_STAMP
-      if (spd_inverse_warm(tid, p, Qm, Qi, Es, Tn, Li, (int*)(ob + 40), warm, (n == 0) ? dbgc : nullptr)) st |= DLM_ST_NOT_PD;
+      if (spd_inverse_warm(tid, p, Qm, Qi, C, Es, Li, (int*)(ob + 40), (int*)(ob + 42), warm, &Xf, (n == 0) ? dbgc : nullptr)) st |= DLM_ST_NOT_PD;
 #else
-      if (spd_inverse_warm(tid, p, Qm, Qi, Es, Tn, Li, (int*)(ob + 40), warm)) st |= DLM_ST_NOT_PD;
+      if (spd_inverse_warm(tid, p, Qm, Qi, C, Es, Li, (int*)(ob + 40), (int*)(ob + 42), warm, &Xf)) st |= DLM_ST_NOT_PD;
 #endif
       warm = true;
-      FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Qi[i * PL + j] = 0.0;
-      lds_barrier();
+      if (!allobs) {
+        FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Xf[i * PL + j] = 0.0;
+        lds_barrier();
+      }
       TSTAMP(2)
-      gemm_t<false, false, 0>(tl, dt16, pt16, kp, RF, PL, Qi, PL, Kg, PL);          // K = R F Qm^-1
+      gemm_t<false, false, 0>(tl, dt16, pt16, kp, RF, PL, Xf, PL, Kg, PL);          // K = R F Qm^-1 (6 tiles: waves 0..5)
+      if (Xf != Qi && tid >= 6 * 64)                                                 // keep it as the next warm start
+        for (int idx = tid - 6 * 64; idx < 32 * PL; idx += 2 * 64) Qi[idx] = Xf[idx];
       lds_barrier();
       { const double s = wave_matvec<false>(tl, VW, d, p, Kg, PL, ev); if (tid >= VW * 64 && tid - VW * 64 < d) mv[tid - VW * 64] = av[tid - VW * 64] + s; }
       gemm_t<false, true, 2, true>(tl, dt16, dt16, kp, Kg, PL, RF, PL, C, DL, R);    // C = R - K (R F)^T
@@ -892,7 +958,7 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
       const int gi = (a.g_index && t > 0) ? a.g_index[t - 1] : 0;
       const SparseBig* tab = a.spb + 2 * gi + 1;
       if (gi != tabcur) { load_wave_table(tid, d, tab, tix, tvl); tabcur = gi; }
-      sparse_congruence(tl, d, tab->K, tix, tvl, P, T1, P, nullptr, 0.0, rv, qv);
+      sparse_congruence(tl, d, tab->K, tix, tvl, P, T1, P, nullptr, 0.0, rv, qv, ob + 46);
     } else {
       if (Gl) gemm_g<false, false, true>(tl, dt16, kd, P, DL, Glp, d, T1, DL);            // M G
       else gemm_g<false, false, false>(tl, dt16, kd, P, DL, Gt, d, T1, DL);
