@@ -491,10 +491,29 @@ def test_ffbs_simulation_smoother_distribution(eng):
 # ------------------------------------------------------------------------------------------
 # multivariate tiled-MFMA path (16 <= d <= 48, p <= 32): config C4 and friends
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["c4", "d17_p3_irregular", "d24_p5_timevarying_f"])
+@pytest.mark.parametrize("case", ["c4", "d17_p3_irregular", "d24_p5_timevarying_f", "d20_p10_structured_irregular",
+                                  "d48_p32_dense"])
 def test_tiled_mfma_path(eng, case):
-    rng = np.random.default_rng({"c4": 40, "d17_p3_irregular": 17, "d24_p5_timevarying_f": 24}[case])
-    if case == "c4":
+    rng = np.random.default_rng({"c4": 40, "d17_p3_irregular": 17, "d24_p5_timevarying_f": 24,
+                                 "d20_p10_structured_irregular": 20, "d48_p32_dense": 48}[case])
+    if case == "d20_p10_structured_irregular":
+        # |*| of ten polynomial(2) blocks on an irregular grid with a repeated time: several structured G tables
+        # (the gather congruence), W dt, and the dt = 0 identity advance
+        mod = Dlm.polynomial(2)
+        for _ in range(9):
+            mod = mod * Dlm.polynomial(2)
+        times = np.cumsum(np.array([1, 1, 2, 0, 3, 1, 1, 2] * 4, dtype=np.float64)) + 1.0
+        d, p_ = 20, 10
+        V = np.diag(rng.uniform(0.5, 2.0, p_))
+    elif case == "d48_p32_dense":
+        # the largest shape of the tiled path: G read from global memory in the backward pass, full 2 x 2 tile inverse
+        d, p_ = 48, 32
+        A = rng.standard_normal((d, d)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((d, p_))
+        mod = Dlm(lambda t: F, lambda dt: G1)
+        times = np.arange(1, 13, dtype=np.float64)
+        B = rng.standard_normal((p_, p_)); V = B @ B.T / p_ + 0.5 * np.eye(p_)
+    elif case == "c4":
         mod = Dlm.polynomial(2)
         for _ in range(19):
             mod = mod * Dlm.polynomial(2)
