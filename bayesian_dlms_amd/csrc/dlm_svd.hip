@@ -26,51 +26,135 @@ constexpr int STL = 33;  // leading dimension of the stacked matrix (<= 32 rows)
 #define M17(buf, i, j) (buf)[(i) + (j) * SL]
 #define STK(i, j) stack[(i) + (j) * STL]
 
-__device__ __forceinline__ void ssync() { __syncthreads(); }  // block == one wavefront
+// A block is ONE wavefront: LDS hand-offs need only keep the compiler (and the in-order LDS queue) in order --
+// no s_barrier, and none of the vmcnt(0) a __syncthreads() fence would add after the record stores.
+__device__ __forceinline__ void ssync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 8 lanes of a half-row, result in all of them: row_half_mirror (i <-> 7 - i), then the quad
+// permutations xor 1 and xor 2 -- three DPP steps, no LDS
+__device__ __forceinline__ double sum8(double v) {
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  return v;
+}
+// 1/sqrt(x) and 1/x from the hardware estimates + Newton steps (about 1 ulp): the Jacobi rotation needs a division
+// and two square roots per pair, computed redundantly by every lane of the pair's group
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
 
 // One-sided Jacobi SVD of the m x n (m <= 32, n <= 16) LDS matrix A (leading dim lda).
 // On return the columns of A are U * Sigma, V (n x n, ld SL) holds the right singular vectors,
 // sig[j] = ||A[:, j]||.  Returns 1 if not converged after 40 sweeps.
-__device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V, double* sig) {
-  for (int k = lane; k < n * n; k += 64) M17(V, k % n, k / n) = (k % n == k / n) ? 1.0 : 0.0;
+// The n/2 disjoint column pairs of a round-robin round are rotated concurrently, one pair per 8-lane group; a lane
+// keeps its (up to 4) rows of the two columns in registers from the inner products to the rotation.
+// warm: V already holds an orthogonal matrix close to the answer (the right vectors of the same decomposition one
+// time step earlier): A is first multiplied by it, after which one or two sweeps suffice instead of six to ten.
+__device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V, double* sig, bool warm = false) {
+  if (!warm) {
+    for (int k = lane; k < n * n; k += 64) M17(V, k % n, k / n) = (k % n == k / n) ? 1.0 : 0.0;
+  } else {
+    ssync();
+    double row[16];   // lane i < m: row i of A, replaced by row^T V
+    if (lane < m) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) row[j] = j < n ? A[lane + j * lda] : 0.0;
+      for (int j = 0; j < n; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) acc = fma(row[l], l < n ? M17(V, l, j) : 0.0, acc);
+        A[lane + j * lda] = acc;
+      }
+    }
+  }
   const int np = (n + 1) & ~1, half = np >> 1;
   const int grp = lane >> 3, sub = lane & 7;
   bool conv = (n < 2);
+#ifdef DLM_STAMP
+  int nsweeps = 0;
+#endif
   for (int sweep = 0; sweep < 40 && !conv; ++sweep) {
-    bool rot_any = false;
+#ifdef DLM_STAMP
+    ++nsweeps;
+#endif
+    bool rot_any = false, big_any = false;
+    // round-robin schedule: group 0 pairs the fixed column np-1 with column r; group g pairs (r + g) and (r - g)
+    // modulo np-1 -- both advance by one per round, so no integer division in the loop
+    int ra = grp % (np - 1), rb = (np - 1 - grp) % (np - 1);
     for (int r = 0; r < np - 1; ++r) {
       ssync();
       int ca, cb;
       if (grp == 0) { ca = np - 1; cb = r; }
-      else { ca = (r + grp) % (np - 1); cb = (r + np - 1 - grp) % (np - 1); }
+      else { ca = ra; cb = rb; }
+      ra = (ra + 1 == np - 1) ? 0 : ra + 1;
+      rb = (rb + 1 == np - 1) ? 0 : rb + 1;
       const bool act = grp < half && ca < n && cb < n;
       const int p = ca < cb ? ca : cb, q = ca < cb ? cb : ca;
+      double* Ap = A + p * lda;
+      double* Aq = A + q * lda;
+      double x[4], y[4];
       double al = 0.0, be = 0.0, ga = 0.0;
-      if (act)
-        for (int i = sub; i < m; i += 8) {
-          const double x = A[i + p * lda], y = A[i + q * lda];
-          al = fma(x, x, al); be = fma(y, y, be); ga = fma(x, y, ga);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = sub + 8 * k;
+        const bool ok = act && i < m;
+        x[k] = ok ? Ap[i] : 0.0;
+        y[k] = ok ? Aq[i] : 0.0;
+        al = fma(x[k], x[k], al); be = fma(y[k], y[k], be); ga = fma(x[k], y[k], ga);
+      }
+      al = sum8(al); be = sum8(be); ga = sum8(ga);
+      // columns count as orthogonal once |a.b| <= 1e-14 |a||b| (fp64 dot products of <= 32 terms)
+      const double g2 = ga * ga, ab = al * be;
+      const bool rot = act && ga != 0.0 && g2 > 1e-28 * ab;
+      big_any |= act && g2 > 1e-16 * ab;   // a rotation above 1e-8: not yet in the quadratic endgame
+      if (rot) {
+        // tan of the rotation angle from the raw hardware estimates (~1e-7 relative: any t gives an exact rotation,
+        // a slightly wrong one only costs a little convergence); c and s from it at full accuracy, c^2 + s^2 = 1
+        const double zeta = (be - al) * 0.5 * __builtin_amdgcn_rcp(ga);
+        const double h = fma(zeta, zeta, 1.0);
+        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h * __builtin_amdgcn_rsq(h));
+        const double c = fast_rsqrt(fma(t, t, 1.0)), s = t * c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = sub + 8 * k;
+          if (i < m) { Ap[i] = fma(c, x[k], -(s * y[k])); Aq[i] = fma(s, x[k], c * y[k]); }
         }
 #pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { al += __shfl_xor(al, o); be += __shfl_xor(be, o); ga += __shfl_xor(ga, o); }
-      // columns count as orthogonal once |a.b| <= 1e-14 |a||b| (fp64 dot products of <= 32 terms)
-      const bool rot = act && ga != 0.0 && fabs(ga) > 1e-14 * sqrt(al * be);
-      if (rot) {
-        const double zeta = (be - al) / (2.0 * ga);
-        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-        for (int i = sub; i < m; i += 8) {
-          const double x = A[i + p * lda], y = A[i + q * lda];
-          A[i + p * lda] = c * x - s * y; A[i + q * lda] = s * x + c * y;
-        }
-        for (int i = sub; i < n; i += 8) {
-          const double x = M17(V, i, p), y = M17(V, i, q);
-          M17(V, i, p) = c * x - s * y; M17(V, i, q) = s * x + c * y;
+        for (int k = 0; k < 2; ++k) {
+          const int i = sub + 8 * k;
+          if (i < n) {
+            const double vx = M17(V, i, p), vy = M17(V, i, q);
+            M17(V, i, p) = fma(c, vx, -(s * vy)); M17(V, i, q) = fma(s, vx, c * vy);
+          }
         }
       }
       rot_any |= rot;
     }
-    conv = (__ballot(rot_any) == 0ull);
+    // Converged when a sweep rotated nothing -- or when all its rotations were below 1e-8: the off-diagonal mass
+    // then drops quadratically to ~1e-16 within this very sweep, and the verification sweep (a third of the work
+    // with a warm start) can be skipped.
+    conv = (__ballot(rot_any) == 0ull) || (__ballot(big_any) == 0ull);
   }
   ssync();
   if (lane < n) {
@@ -79,7 +163,11 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
     sig[lane] = sqrt(s);
   }
   ssync();
+#ifdef DLM_STAMP
+  return (conv ? 0 : 1) | (nsweeps << 8);
+#else
   return conv ? 0 : 1;
+#endif
 }
 
 // sqrtSvd / sqrtInvSvd (SvdFilter.scala:210-227): out = diag(sig^{+-1/2}) V^T for the SPD n x n Mx.
@@ -102,17 +190,23 @@ struct SvdLds {
   double *m, *a, *dc, *dr, *sig, *e, *yv, *tv, *uc, *ur, *V, *Wadv, *tmp, *stack, *sVinv, *gs, *sWb;
   int* idx;
 };
+// The filter needs only the first part (through the first 16 doubles of gs): its vm fm^T scratch lives in rows 16..31
+// of the stacked matrix, so that ten of its one-wave workgroups fit a CU instead of seven (the Jacobi rounds are
+// latency-bound: more waves per SIMD is throughput).
 __device__ __forceinline__ SvdLds carve(double* sm) {
   SvdLds L;
   L.m = sm; L.a = L.m + 16; L.dc = L.a + 16; L.dr = L.dc + 16; L.sig = L.dr + 16; L.e = L.sig + 16;
   L.yv = L.e + 16; L.tv = L.yv + 16;
   L.uc = L.tv + 16; L.ur = L.uc + 16 * SL; L.V = L.ur + 16 * SL; L.Wadv = L.V + 16 * SL;
-  L.tmp = L.Wadv + 16 * SL; L.sVinv = L.tmp + 16 * SL; L.gs = L.sVinv + 16 * SL; L.sWb = L.gs + 16 * SL;
-  L.stack = L.sWb + 16 * SL;
+  L.sVinv = L.Wadv + 16 * SL;
+  L.stack = L.sVinv + 16 * SL;
   L.idx = (int*)(L.stack + 16 * STL);
+  L.gs = L.stack + 16 * STL + 8;
+  L.tmp = L.gs + 16 * SL; L.sWb = L.tmp + 16 * SL;
   return L;
 }
-size_t svd_filter_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 16 * SL + 16 * STL) + sizeof(int) * 16 + 16; }
+size_t svd_filter_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 5 * 16 * SL + 16 * STL + 8 + 16) + 16; }
+size_t svd_sampler_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 16 * SL + 16 * STL + 8) + 16; }
 
 // ---------------------------------------------------------------------------------------
 // SVD filter.  Record t: [m_t (d) | dc_t (d) | uc_t (d x d, column-major)].
@@ -145,14 +239,30 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
   for (int k = lane; k < dd; k += 64) { M17(L.uc, k % d, k / d) = M17(L.V, k % d, k / d); out[2 * d + k] = M17(L.V, k % d, k / d); }
   ssync();
 
+  // Warm starts: L.ur / L.V still hold the right vectors of the previous step's two decompositions.  They are
+  // dropped every 64th step (a rotation product drifts from orthogonality by ~1e-16 per step) and whenever the
+  // buffers were used for something else.
+  bool warm_r = false, warm_c = false;
+  int dbg_sw1 = 0, dbg_sw2 = 0;   // sweep counts (reported by the diagnostic build only)
+#ifdef DLM_STAMP
+  unsigned long long tj = 0, t0_ = 0, tstart;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart)::"memory");
+#define SVD_T0 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory");
+#define SVD_T1 { unsigned long long t1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_)::"memory"); tj += t1_ - t0_; }
+#else
+#define SVD_T0
+#define SVD_T1
+#endif
   for (int t = 0; t < T; ++t) {
     const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
     const double* Ft = a.F + (size_t)t * a.f_stride;
     const double dt = a.dt ? a.dt[t] : 1.0;
+    if ((t & 63) == 0) { warm_r = false; warm_c = false; }
     // advState (SvdFilter.scala:183-202)
     if (dt == 0.0) {
       for (int i = lane; i < d; i += 64) { L.a[i] = L.m[i]; L.dr[i] = L.dc[i]; }
       for (int k = lane; k < dd; k += 64) M17(L.ur, k % d, k / d) = M17(L.uc, k % d, k / d);
+      warm_r = false;
       ssync();
     } else {
       const double sdt = sqrt(dt);
@@ -169,7 +279,10 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
         STK(d + i, j) = M17(L.Wadv, i, j) * sdt;
       }
       ssync();
-      if (jacobi_svd(lane, 2 * d, d, stack, STL, L.ur, L.dr)) st |= DLM_ST_NOCONV;   // dr = sigma, ur = V
+      SVD_T0
+      { const int rc = jacobi_svd(lane, 2 * d, d, stack, STL, L.ur, L.dr, warm_r); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw1 += rc >> 8; }   // dr = sigma, ur = V
+      SVD_T1
+      warm_r = true;
     }
     // updateState (SvdFilter.scala:38-68)
     const double yl = (lane < p) ? y[(size_t)t * p + lane] : __builtin_nan("");
@@ -191,19 +304,23 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
         const int i = k % pm, j = k / pm;
         double s = 0.0;
         for (int l = 0; l < pm; ++l) s = fma(M17(L.sVinv, L.idx[i], L.idx[l]), Ft[j + L.idx[l] * d], s);
-        M17(L.tmp, i, j) = s;
+        STK(16 + i, j) = s;                    // vm fm^T, parked in rows 16.. of the stack
       }
       ssync();
       // stack ((pm + d) x d) = [vm fm^T ur ; diag(1/dr)]
       for (int k = lane; k < pm * d; k += 64) {
         const int i = k % pm, j = k / pm;
         double s = 0.0;
-        for (int l = 0; l < d; ++l) s = fma(M17(L.tmp, i, l), M17(L.ur, l, j), s);
+        for (int l = 0; l < d; ++l) s = fma(STK(16 + i, l), M17(L.ur, l, j), s);
         STK(i, j) = s;
       }
+      ssync();                                 // rows 16.. are overwritten next
       for (int k = lane; k < dd; k += 64) { const int i = k % d, j = k / d; STK(pm + i, j) = (i == j) ? 1.0 / L.dr[i] : 0.0; }
       ssync();
-      if (jacobi_svd(lane, pm + d, d, stack, STL, L.V, L.sig)) st |= DLM_ST_NOCONV;
+      SVD_T0
+      { const int rc = jacobi_svd(lane, pm + d, d, stack, STL, L.V, L.sig, warm_c); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw2 += rc >> 8; }
+      SVD_T1
+      warm_c = true;
       // uc = ur V ; dc = 1 / sigma
       for (int k = lane; k < dd; k += 64) {
         const int i = k % d, j = k / d;
@@ -246,6 +363,11 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
     for (int i = lane; i < d; i += 64) { o[i] = L.m[i]; o[d + i] = L.dc[i]; }
     for (int k = lane; k < dd; k += 64) o[2 * d + k] = M17(L.uc, k % d, k / d);
   }
+#ifdef DLM_STAMP
+  if (n == 0 && lane == 0 && a.status) { unsigned long long tend; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory"); a.status[1] = dbg_sw1; a.status[2] = dbg_sw2; a.status[3] = (int)(tj / T); a.status[4] = (int)((tend - tstart) / T); }
+#else
+  (void)dbg_sw1; (void)dbg_sw2;
+#endif
   bool bad = false;
   for (int i = lane; i < d; i += 64) bad |= !isfinite(L.m[i]) || !isfinite(L.dc[i]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
@@ -432,7 +554,7 @@ hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s) {
 
 hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s) {
   if (a.d > 16 || a.p > 16) return hipErrorNotSupported;
-  hipLaunchKernelGGL(k_svd_sampler, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec);
+  hipLaunchKernelGGL(k_svd_sampler, dim3(a.N), dim3(64), svd_sampler_lds_bytes(a.d, a.p), s, a, svd_rec);
   return hipGetLastError();
 }
 
