@@ -49,7 +49,11 @@ __device__ __forceinline__ double uniform_from_lane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-bool fast_shape(const KArgs& a) { return a.d <= 15 && a.p == 1; }
+// The fast kernels address a series' records through 32-bit buffer offsets: one series' record stream must stay
+// below 2 GiB (T < 1.4 million steps at d = 13), longer series take the generic kernels.
+bool fast_shape(const KArgs& a) {
+  return a.d <= 15 && a.p == 1 && ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);
+}
 bool mfma16_supported(const KArgs& a) { return fast_shape(a) && a.f_stride == 0 && a.g_index == nullptr && a.dt == nullptr; }
 
 // ---------------------------------------------------------------------------------------

@@ -578,7 +578,9 @@ int sparse48_analyse(const double* G /* d x d column-major, host */, int d, Spar
   return kmax;
 }
 
-bool tiled_supported(const KArgs& a) { return a.d >= 16 && a.d <= 48 && a.p <= 32; }
+bool tiled_supported(const KArgs& a) {   // records are addressed through 32-bit buffer offsets: < 2 GiB per series
+  return a.d >= 16 && a.d <= 48 && a.p <= 32 && ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);
+}
 
 constexpr int FILT_DOUBLES = 4 * BIG + 3 * MID + 2 * SML + 8 * 48;    // 133 KB (inverse scratch aliases Tm / Kg)
 constexpr int FILT_SIM_DOUBLES = FILT_DOUBLES + BIG + SML + 3 * 48;   // + chol(W), chol(V), x+ (48), normals (96): 158 KB
