@@ -53,6 +53,7 @@ SYMBOLS = [
     ("dlm_engine_sync", ctypes.c_int, [_V]),
     ("dlm_last_variant", ctypes.c_char_p, [_V]),
     ("dlm_filter_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V, _V, _V]),
+    ("dlm_loglik_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V]),
     ("dlm_smooth_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V]),
     ("dlm_filter_smooth_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V, _V]),
     ("dlm_last_timing", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_double * 2)]),

@@ -119,6 +119,16 @@ class KalmanFilter:
     def filter(mod, ys, p, engine, **kw):
         return KalmanFilter.filter_dlm(mod, ys, p, engine, keep_init=True, **kw)
 
+    @staticmethod
+    def log_likelihood(mod: Dlm, ys, p, engine: Engine, *, flags: int = 0):
+        """Sum over the series of KalmanFilter.conditionalLikelihood(f_t, Q_t, y_t) (KalmanFilter.scala:138-153): the
+        prediction-error log-likelihood log p(y_{1:T} | V, W).  `p` may be one DlmParameters or one per series (a bank
+        of parameter sets evaluated in one launch, as MetropolisHastings.dlm / RaoBlackwellFilter.kfStep need)."""
+        times, y, batched = pack_observations(ys)
+        mat = materialise(mod, times)
+        ll = np.asarray(engine.loglik(mat, p, y, flags=flags)["loglik"])
+        return ll if batched else float(ll[0])
+
 
 def _records_from_states(kf_states: Sequence[Sequence[KfState]], d: int) -> np.ndarray:
     N, T1 = len(kf_states), len(kf_states[0])

@@ -362,6 +362,24 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
+int dlm_loglik_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                     const double* y, const dlm_options* opts, double* loglik, int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  if (!y || !loglik) return fail(e, DLM_ERR_ARG, "y and loglik are required");
+  const size_t p = model->p, T = model->T, N = model->N;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  st.in(&k.y, y, N * T * p);
+  st.out(&k.loglik, loglik, N);
+  st.zeroed_out(&k.status, (int*)status, N);
+  if ((rc = st.commit())) return rc;
+  if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
+  if ((rc = run_filter(e, k, false))) return rc;   // k.filt == nullptr: the forward kernels store nothing
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
 int dlm_smooth_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
                      const double* filt, const dlm_options* opts, double* smooth, int32_t* status) {
   int rc = check_common(e, model, params, opts);

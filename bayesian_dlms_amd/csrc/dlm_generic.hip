@@ -108,14 +108,15 @@ __global__ __launch_bounds__(64) void k_filter_generic(KArgs a) {
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
   const double* C0 = a.C0 + (size_t)n * a.c0_stride;
   const double* y = a.y + (size_t)n * T * p;
-  double* out = a.filt + (size_t)n * (T + 1) * rec;
+  double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;   // null: likelihood only, nothing stored
+  double ll = 0.0;   // sum_t log N(y_t^obs; f_t^obs, Q_t^obs) (KalmanFilter.scala:138-153)
   double* pri = a.prior ? a.prior + (size_t)n * (T + 1) * rec : nullptr;
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * frec : nullptr;
   int st = 0;
 
   // initialiseState (KalmanFilter.scala:112-118): m = a = m0, C = R = C0, f/Q absent
-  for (int i = lane; i < d; i += 64) { m[i] = m0[i]; out[i] = m0[i]; if (pri) pri[i] = m0[i]; }
-  for (int i = lane; i < dd; i += 64) { C[i] = C0[i]; out[d + i] = C0[i]; if (pri) pri[d + i] = C0[i]; }
+  for (int i = lane; i < d; i += 64) { m[i] = m0[i]; if (out) out[i] = m0[i]; if (pri) pri[i] = m0[i]; }
+  for (int i = lane; i < dd; i += 64) { C[i] = C0[i]; if (out) out[d + i] = C0[i]; if (pri) pri[d + i] = C0[i]; }
   if (fq) for (int i = lane; i < frec; i += 64) fq[i] = __builtin_nan("");
 
   for (int t = 0; t < T; ++t) {
@@ -174,6 +175,15 @@ __global__ __launch_bounds__(64) void k_filter_generic(KArgs a) {
       wsync();
       if (chol_lds(lane, pm, Qm)) st |= DLM_ST_NOT_PD;
       chol_solve_lds(lane, pm, d, Qm, Kt);  // Kt = Qm^-1 (R Fm)^T  => K = Kt^T
+      if (a.loglik) {   // -1/2 (pm log 2pi + log det Qm + e^T Qm^-1 e) from the factor just computed
+        for (int j = lane; j < pm; j += 64) yv[j] = ev[j];    // yv (the packed observations) is free now
+        wsync();
+        chol_solve_lds(lane, pm, 1, Qm, yv);
+        double part = 0.0;
+        for (int j = lane; j < pm; j += 64) part += 2.0 * log(Qm[CM(j, j, pm)]) + ev[j] * yv[j];
+        for (int o_ = 32; o_ > 0; o_ >>= 1) part += __shfl_xor(part, o_);
+        ll -= 0.5 * (1.8378770664093453 * pm + part);
+      }
       // m = a + K e
       for (int i = lane; i < d; i += 64) {
         double s = av[i];
@@ -205,11 +215,14 @@ __global__ __launch_bounds__(64) void k_filter_generic(KArgs a) {
       }
     }
     wsync();
-    double* o = out + (size_t)(t + 1) * rec;
-    for (int i = lane; i < d; i += 64) o[i] = m[i];
-    for (int i = lane; i < dd; i += 64) o[d + i] = C[i];
+    if (out) {
+      double* o = out + (size_t)(t + 1) * rec;
+      for (int i = lane; i < d; i += 64) o[i] = m[i];
+      for (int i = lane; i < dd; i += 64) o[d + i] = C[i];
+    }
     if (any_nonfinite(lane, dd, C) || any_nonfinite(lane, d, m)) st |= DLM_ST_NONFINITE;
   }
+  if (a.loglik && lane == 0) a.loglik[n] = ll;
   if (a.status && lane == 0) a.status[n] |= st;
 }
 

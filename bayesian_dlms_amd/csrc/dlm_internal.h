@@ -24,6 +24,7 @@ struct KArgs {
   double* theta;
   double* cond;
   double* stats;
+  double* loglik;      // [N] prediction-error log-likelihood (nullable); with it, filt may be null (nothing stored)
   int* status;
   const struct SparseBig* spb;   // tiled path: [2 n_g] row / column tables of a structured G, or nullptr (dense G)
   unsigned flags;

@@ -72,9 +72,10 @@ __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restri
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
   const double V = a.V[(size_t)n * a.v_stride];
   const double* y = a.y + (size_t)n * T;
-  double* out = a.filt + (size_t)n * (T + 1) * rec;
+  double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;   // null: likelihood only, nothing stored
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
   double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
+  double ll = 0.0;   // sum_t log N(y_t; f_t, Q_t) (KalmanFilter.scala:138-153)
 
   d4 gt, w, cc, mrow;
   double Fr[4];
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restri
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * r + g;
-    if (vr[r] && vc) out[d + i * d + c] = cc[r];
-    if (vr[r] && col15) out[i] = mrow[r];
+    if (out && vr[r] && vc) out[d + i * d + c] = cc[r];
+    if (out && vr[r] && col15) out[i] = mrow[r];
   }
   if (lane == 0) {
     if (fq) { fq[0] = __builtin_nan(""); fq[1] = __builtin_nan(""); }
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restri
         mrow[r] = fma(Kr, e, rp[r]);                  // meaningful in column-15 lanes
       }
       if (sd && lane == 0) { sd[2 * (t + 1)] = e * rq; sd[2 * (t + 1) + 1] = rq; }
+      if (a.loglik) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * e * rq);
     } else {
       cc = R;
       mrow = rp;
@@ -154,10 +156,11 @@ __global__ __launch_bounds__(256) void k_filter_mfma16(KArgs a, double* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * r + g;
-      if (vr[r] && vc) o[d + i * d + c] = cc[r];
-      if (vr[r] && col15) o[i] = mrow[r];
+      if (out && vr[r] && vc) o[d + i * d + c] = cc[r];
+      if (out && vr[r] && col15) o[i] = mrow[r];
     }
   }
+  if (a.loglik && lane == 0) a.loglik[n] = ll;
   // a non-finite value, once present, propagates to every later state: test the last one
   bool bad = false;
 #pragma unroll

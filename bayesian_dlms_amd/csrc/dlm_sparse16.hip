@@ -363,8 +363,10 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
   const double V = a.V[(size_t)n * a.v_stride];
   const double* y = a.y + (size_t)n * T;
-  char* bout = (char*)(a.filt + (size_t)n * (T + 1) * rec);
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
+  // likelihood-only calls pass no record buffer: a zero-sized resource drops every store
+  char* bout = a.filt ? (char*)(a.filt + (size_t)n * (T + 1) * rec) : nullptr;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, a.filt ? (size_t)(T + 1) * rec * 8 : 0);
+  double ll = 0.0;   // sum_t log N(y_t; f_t, Q_t) (KalmanFilter.conditionalLikelihood, KalmanFilter.scala:138-153)
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
   double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
   char* bpri = a.prior ? (char*)(a.prior + (size_t)n * (T + 1) * rec) : nullptr;   // optional (a_t, R_t) records
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
 #pragma unroll
       for (int r = 0; r < 3; ++r) cc[r] = fma(rfr[r], ngam, R[r]);
       cc[3] = (g == 3) ? fma(Kc, e, R[3]) : fma(rfr[3], ngam, R[3]);
+      if (a.loglik) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * erq);   // log(2 pi) = 1.83787...
       if (sd && lane == 0) { sd[2 * (t + 1)] = erq; sd[2 * (t + 1) + 1] = rq; }
     } else {
       cc = R;
@@ -543,6 +546,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
     for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], so, cc[r]);
     wave_sync();   // the images are rewritten at the top of the next step
   }
+  if (a.loglik && lane == 0) a.loglik[n] = ll;
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(cc[r]);

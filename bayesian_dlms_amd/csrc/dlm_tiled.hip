@@ -614,7 +614,8 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
   const double* V = a.V + (size_t)n * a.v_stride;
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* y = a.y + (size_t)n * T * p;
-  double* out = a.filt + (size_t)n * (T + 1) * rec;
+  double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;   // null: likelihood only, nothing stored
+  double ll = 0.0;   // prediction-error log-likelihood, accumulated by lane 0 of wave VW (KalmanFilter.scala:138-153)
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * frec : nullptr;
   double* pri = a.prior ? a.prior + (size_t)n * (T + 1) * rec : nullptr;   // optional (a_t, R_t) records
   int st = 0;
@@ -644,17 +645,16 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
     if (tid < d) { xp[tid] = xv[tid]; mv[tid] = 0.0; }     // y* is filtered from a zero prior mean
     lds_barrier();
   }
-  FOR_CM(d, d, i, j) out[d + i + j * d] = C[i * DL + j];
-  if (tid < d) out[tid] = mv[tid];
+  if (out) { FOR_CM(d, d, i, j) out[d + i + j * d] = C[i * DL + j]; if (tid < d) out[tid] = mv[tid]; }
   if (pri) { FOR_CM(d, d, i, j) pri[d + i + j * d] = C[i * DL + j]; if (tid < d) pri[tid] = mv[tid]; }
   if (fq) for (int i = tid; i < frec; i += NT) fq[i] = __builtin_nan("");
 
   // per-step record I/O with a fixed instruction count per thread (see rec_offsets): y is prefetched one step ahead
   const int recb = rec * 8;
-  const __amdgpu_buffer_rsrc_t rfo = mk_rsrc(out, (size_t)(T + 1) * recb);
-  const __amdgpu_buffer_rsrc_t rpr = mk_rsrc(pri ? pri : out, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rfo = mk_rsrc(out, out ? (size_t)(T + 1) * recb : 0);   // zero-sized: every store is dropped
+  const __amdgpu_buffer_rsrc_t rpr = mk_rsrc(pri, pri ? (size_t)(T + 1) * recb : 0);
   const __amdgpu_buffer_rsrc_t ry = mk_rsrc(y, (size_t)T * p * 8);
-  const __amdgpu_buffer_rsrc_t rys = mk_rsrc(ys ? ys : out, ys ? (size_t)T * p * 8 : 0);
+  const __amdgpu_buffer_rsrc_t rys = mk_rsrc(ys, ys ? (size_t)T * p * 8 : 0);
   const RecOff ro = rec_offsets(tid, d);
   const int poff = tid < p ? tid * 8 : OOB;
   double ynext = bld(ry, poff, 0);
@@ -769,6 +769,17 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
         lds_barrier();
       }
       TSTAMP(2)
+      if (a.loglik) {   // -1/2 (n_obs log 2pi + log det Qm + e^T Qm^-1 e): det from a Cholesky factor of a copy of Qm
+        for (int idx = tid; idx < 32 * PL; idx += NT) Es[idx] = Qm[idx];
+        if (chol_block(tid, p, Es, PL)) st |= DLM_ST_NOT_PD;
+        const double sj = wave_matvec<false>(tl, VW, p, p, Xf, PL, ev);
+        if (tid >= VW * 64) {
+          const int j = tid - VW * 64;
+          double part = (j < p) ? 2.0 * log(Es[j * PL + j]) + ev[j] * sj + 1.8378770664093453 * ob[j] : 0.0;
+          for (int o_ = 32; o_ > 0; o_ >>= 1) part += __shfl_xor(part, o_);
+          ll -= 0.5 * part;
+        }
+      }
       gemm_t<false, false, 0>(tl, dt16, pt16, kp, RF, PL, Xf, PL, Kg, PL);          // K = R F Qm^-1 (6 tiles: waves 0..5)
       if (Xf != Qi && tid >= 6 * 64)                                                 // keep it as the next warm start
         for (int idx = tid - 6 * 64; idx < 32 * PL; idx += 2 * 64) Qi[idx] = Xf[idx];
@@ -789,6 +800,7 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
 #ifdef DLM_STAMP
   if (n == 0 && tid == 0 && a.status) { for (int k = 0; k < 8; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)T); a.status[6] = dbgc[0]; a.status[7] = dbgc[1]; a.status[9] = dbgc[2]; }
 #endif
+  if (a.loglik && tid == VW * 64) a.loglik[n] = ll;
   lds_barrier();
   bool bad = false;
   FOR_CM(d, d, i, j) bad |= !isfinite(C[i * DL + j]);

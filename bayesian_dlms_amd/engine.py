@@ -168,6 +168,17 @@ class Engine:
                                               be.ptr(fq), be.ptr(status)))
         return {"filt": filt, "prior": prior, "fq": fq, "status": status}
 
+    def loglik(self, mat, params, y, *, flags=0):
+        """Per-series prediction-error log-likelihood (dlm_loglik_batch); nothing but [N] numbers leaves the GPU."""
+        be = self._backend(y)
+        N = int(y.shape[0]); p, T = mat.p, mat.T
+        yb = be.put(y).reshape(N, T, p)
+        md, pd, op, keep = self.prepare(mat, params, N, be, flags)
+        ll = be.empty((N,))
+        status = be.empty((N,), np.int32)
+        self._check(self.lib.dlm_loglik_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(ll), be.ptr(status)))
+        return {"loglik": ll, "status": status}
+
     def smooth(self, mat, params, filt, *, flags=0):
         be = self._backend(filt)
         N = int(filt.shape[0]); d, T = mat.d, mat.T

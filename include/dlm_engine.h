@@ -121,6 +121,15 @@ int dlm_filter_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_param
 int dlm_smooth_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
                      const double *filt, const dlm_options *opts, double *smooth, int32_t *status);
 
+/* Per-series log-likelihood by the prediction-error decomposition,
+ *   loglik[n] = sum_t log N(y_t^obs ; f_t^obs, Q_t^obs),
+ * i.e. KalmanFilter.conditionalLikelihood (KalmanFilter.scala:138-153) summed over the series (steps with no observed
+ * component contribute 0).  It is the filter recursion with one scalar reduction per series and no record output, for
+ * the callers that evaluate a bank of parameter sets (MetropolisHastings.scala:126-137, RaoBlackwellFilter.scala:43-57;
+ * SURVEY 8f #2): params strides select per-series parameters.  loglik [N]; status [N] as for dlm_filter_batch. */
+int dlm_loglik_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                     const double* y, const dlm_options* opts, double* loglik, int32_t* status);
+
 /* ---- fused filter + smoother (the headline metric path) ---------------------------- */
 int dlm_filter_smooth_batch(dlm_engine *e, const dlm_model_desc *model,
                             const dlm_params_desc *params, const double *y,

@@ -8,6 +8,7 @@
 //   Dlm{f, g}, Dlm::polynomial, Dlm::seasonal, compose (|+|), outer (|*|)     Dlm.scala:14-31,107-243
 //   DlmParameters{v, w, m0, c0}, Data{time, observation}                       Dlm.scala:36-39,94
 //   KalmanFilter::filterDlm / filter                                          KalmanFilter.scala:262-294
+//   KalmanFilter::logLikelihood (sum of conditionalLikelihood)                KalmanFilter.scala:138-153
 //   Smoothing::backwardsSmoother / filterSmooth / ffbsDlm                      Smoothing.scala:57-64,173-180
 //
 // Matrices are column-major (Breeze DenseMatrix.data).  All entry points run the HIP engine in
@@ -168,6 +169,15 @@ inline std::vector<std::vector<KfState>> filter(Engine& e, const Dlm& mod, const
       out[n].push_back(KfState{k == 0 ? t.times[0] - t.dt[0] : t.times[k - 1], std::vector<double>(r, r + t.d), detail::matAt(r + t.d, t.d)});
     }
   return out;
+}
+// sum over the series of KalmanFilter.conditionalLikelihood (KalmanFilter.scala:138-153): log p(y_1:T | V, W) per series
+inline std::vector<double> logLikelihood(Engine& e, const Dlm& mod, const std::vector<std::vector<Data>>& ys, const DlmParameters& p) {
+  detail::Tables t = detail::materialise(mod, ys);
+  const dlm_model_desc m = detail::modelDesc(t); const dlm_params_desc q = detail::paramsDesc(p);
+  const dlm_options o{0, DLM_MEM_HOST, 0, 0};
+  std::vector<double> ll((size_t)t.N);
+  e.check(dlm_loglik_batch(e.get(), &m, &q, t.y.data(), &o, ll.data(), nullptr));
+  return ll;
 }
 // KalmanFilter.filterDlm: `filterTraverse` drops the initial state (Filter.scala:32-36)
 inline std::vector<std::vector<KfState>> filterDlm(Engine& e, const Dlm& mod, const std::vector<std::vector<Data>>& ys, const DlmParameters& p) {

@@ -64,6 +64,18 @@ JNIEXPORT void JNICALL Java_com_github_jonnylaw_dlm_gpu_Native_filterSmooth(
                                            addr<double>(env, smooth), addr<int32_t>(env, status)));
 }
 
+// sum over each series of KalmanFilter.conditionalLikelihood  (KalmanFilter.scala:138-153)
+JNIEXPORT void JNICALL Java_com_github_jonnylaw_dlm_gpu_Native_logLikelihood(
+    JNIEnv* env, jclass, jlong h, jint d, jint p, jint T, jint N, jobject F, jlong fStride, jobject G, jint nG,
+    jobject gIndex, jobject dt, jobject V, jlong vs, jobject W, jlong ws, jobject m0, jlong ms, jobject C0, jlong cs,
+    jobject y, jint flags, jobject loglik, jobject status) {
+  dlm_engine* e = reinterpret_cast<dlm_engine*>(h);
+  dlm_model_desc m = model(env, d, p, T, N, F, fStride, G, nG, gIndex, dt);
+  dlm_params_desc q = params(env, V, vs, W, ws, m0, ms, C0, cs);
+  dlm_options o{static_cast<uint32_t>(flags), DLM_MEM_HOST, 0, 0};
+  throw_if(env, e, dlm_loglik_batch(e, &m, &q, addr<double>(env, y), &o, addr<double>(env, loglik), addr<int32_t>(env, status)));
+}
+
 // replaces KalmanFilter.filterDlm  (KalmanFilter.scala:291-294)
 JNIEXPORT void JNICALL Java_com_github_jonnylaw_dlm_gpu_Native_filter(
     JNIEnv* env, jclass, jlong h, jint d, jint p, jint T, jint N, jobject F, jlong fStride, jobject G, jint nG,

@@ -20,6 +20,10 @@ object Native {
       g: DoubleBuffer, nG: Int, gIndex: IntBuffer, dt: DoubleBuffer,
       v: DoubleBuffer, vs: Long, w: DoubleBuffer, ws: Long, m0: DoubleBuffer, ms: Long, c0: DoubleBuffer, cs: Long,
       y: DoubleBuffer, flags: Int, filt: DoubleBuffer, smooth: DoubleBuffer, status: IntBuffer): Unit
+  @native def logLikelihood(h: Long, d: Int, p: Int, t: Int, n: Int, f: DoubleBuffer, fStride: Long,
+      g: DoubleBuffer, nG: Int, gIndex: IntBuffer, dt: DoubleBuffer,
+      v: DoubleBuffer, vs: Long, w: DoubleBuffer, ws: Long, m0: DoubleBuffer, ms: Long, c0: DoubleBuffer, cs: Long,
+      y: DoubleBuffer, flags: Int, loglik: DoubleBuffer, status: IntBuffer): Unit
   @native def filter(h: Long, d: Int, p: Int, t: Int, n: Int, f: DoubleBuffer, fStride: Long,
       g: DoubleBuffer, nG: Int, gIndex: IntBuffer, dt: DoubleBuffer,
       v: DoubleBuffer, vs: Long, w: DoubleBuffer, ws: Long, m0: DoubleBuffer, ms: Long, c0: DoubleBuffer, cs: Long,
@@ -66,6 +70,22 @@ final class Batched(device: Int = 0) extends AutoCloseable {
     def filtered(i: Int, t: Int) = { val o = (i * (times.length + 1) + t) * rec; (vec(filt, o), mat(filt, o + d)) }
     /** Smoothing.SmoothingState-like (mean, covariance) */
     def smoothed(i: Int, t: Int) = { val o = (i * (times.length + 1) + t) * rec; (vec(smooth, o), mat(smooth, o + d)) }
+  }
+
+  /** Sum over each series of KalmanFilter.conditionalLikelihood(f_t, Q_t, y_t): log p(y | V, W), one value per series. */
+  def logLikelihood(mod: Dlm, ys: Vector[Vector[Data]], p: DlmParameters): Array[Double] = {
+    require(ys.nonEmpty && ys.head.nonEmpty, "empty observations")
+    val times = ys.head.map(_.time).toArray
+    val tb = materialise(mod, times)
+    val (n, t) = (ys.length, times.length)
+    val y = dbuf(n.toLong * t * tb.p)
+    for (s <- ys; d <- s; o <- d.observation.data) y.put(o.getOrElse(Double.NaN))
+    y.rewind()
+    val ll = dbuf(n.toLong)
+    val status = ByteBuffer.allocateDirect(4 * n).order(ByteOrder.nativeOrder).asIntBuffer
+    Native.logLikelihood(h, tb.d, tb.p, t, n, tb.f, tb.fStride, tb.g, tb.nG, tb.gIndex, tb.dt,
+      dbuf(p.v.data), 0L, dbuf(p.w.data), 0L, dbuf(p.m0.data), 0L, dbuf(p.c0.data), 0L, y, 0, ll, status)
+    Array.tabulate(n)(ll.get)
   }
 
   /** KalmanFilter(advanceState(p, mod.g)).filter + Smoothing.backwardsSmoother for N series

@@ -93,6 +93,14 @@ def kf_filter(M, V, W, m0, C0, y):
     return out
 
 
+def loglik(M, filt, y):
+    """Sum of KalmanFilter.conditionalLikelihood over the series, from the forecasts of kf_filter."""
+    y = np.ascontiguousarray(y, dtype=np.float64).reshape(M.T, M.p)
+    fn = lib().oracle_loglik
+    fn.restype = ctypes.c_double
+    return float(fn(M.p, M.T, _p(filt["f"]), _p(filt["Q"]), _p(y)))
+
+
 def smoother(M, filt, compat_q1=False):
     d, T = M.d, M.T
     s = np.empty((T + 1, d)); S = np.empty((T + 1, d * d))

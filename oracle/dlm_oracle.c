@@ -434,6 +434,38 @@ static int chol_lower(int n, const double *A, double *L) {
   return 0;
 }
 
+/* Sum over a series of KalmanFilter.conditionalLikelihood (KalmanFilter.scala:138-153):
+ *   log N(y_t^obs ; f_t^obs, Q_t^obs)  with the observed components selected as there
+ * (indexNonMissing :190-197); a step with no observed component contributes 0.
+ * f [T+1][p] and Q [T+1][p*p] (column-major) are the forecasts written by oracle_kf_filter
+ * (record t+1 belongs to observation t); y [T][p], NaN = missing. */
+double oracle_loglik(int p, int T, const double *f, const double *Q, const double *y) {
+  double ll = 0.0;
+  int *idx = (int *)malloc(sizeof(int) * (size_t)p);
+  double *Qm = (double *)malloc(sizeof(double) * (size_t)p * p);
+  double *L = (double *)malloc(sizeof(double) * (size_t)p * p);
+  double *w = (double *)malloc(sizeof(double) * (size_t)p);
+  for (int t = 0; t < T; ++t) {
+    const double *ft = f + (size_t)(t + 1) * p, *Qt = Q + (size_t)(t + 1) * p * p, *yt = y + (size_t)t * p;
+    int pm = 0;
+    for (int j = 0; j < p; ++j) if (yt[j] == yt[j]) idx[pm++] = j;
+    if (pm == 0) continue;
+    for (int j = 0; j < pm; ++j) for (int i = 0; i < pm; ++i) Qm[i + j * pm] = Qt[idx[i] + idx[j] * p];
+    chol_lower(pm, Qm, L);
+    double logdet = 0.0, quad = 0.0;
+    for (int i = 0; i < pm; ++i) {   /* w = L^-1 e */
+      double v = yt[idx[i]] - ft[idx[i]];
+      for (int l = 0; l < i; ++l) v -= L[i + l * pm] * w[l];
+      w[i] = v / L[i + i * pm];
+      quad += w[i] * w[i];
+      logdet += 2.0 * log(L[i + i * pm]);
+    }
+    ll -= 0.5 * (pm * 1.8378770664093453 + logdet + quad);
+  }
+  free(idx); free(Qm); free(L); free(w);
+  return ll;
+}
+
 static void mvn_draw(int d, const double *mu, const double *cov, const double *z, int factor,
                      double *out, double *w1, double *w2, double *w3) {
   if (factor == 0) {

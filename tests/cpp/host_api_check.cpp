@@ -3,6 +3,7 @@
 //   2. first_order_dlm golden CSVs (examples/src/main/scala/dlm/FirstOrderDlm.scala:52-77,237-255)
 //   3. seasonal d = 13 batch: filterDlm drops the initial state, smoothed == filtered at T
 // usage: host_api_check <tests/golden dir>; prints "HOST API OK" and returns 0 on success.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -63,6 +64,15 @@ int main(int argc, char** argv) {
     std::printf("first_order_dlm: max |filtered - golden| = %.3g, max |smoothed - golden| = %.3g\n", ef, es);
     expect(ef < 1e-11 && es < 1e-10, "golden CSVs reproduced");
     expect(sm[0].time == 0.0 && sm[1000].time == 1000.0, "times");
+    // log-likelihood against the forecasts (f, Q) the reference itself wrote into the golden CSV
+    double want = 0.0;
+    for (size_t t = 1; t < 1001; ++t) {
+      const double e = obs[t - 1][1] - fr[t][3], Q = fr[t][4];
+      want -= 0.5 * (std::log(2.0 * M_PI) + std::log(Q) + e * e / Q);
+    }
+    const double got = KalmanFilter::logLikelihood(eng, Dlm::polynomial(1), {ys}, p)[0];
+    std::printf("first_order_dlm: log-likelihood %.10f (from the golden forecasts %.10f)\n", got, want);
+    expect(std::fabs(got - want) < 1e-8 * std::fabs(want), "log-likelihood from the reference's forecasts");
   }
   {  // 3. seasonal d = 13 batch + FFBS shape
     Dlm mod = Dlm::polynomial(1).compose(Dlm::seasonal(24, 6));

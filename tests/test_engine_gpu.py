@@ -882,3 +882,47 @@ def test_time_varying_f_regression_on_fast_path(eng):
         st = oracle.gibbs_stats(om, y[n], ref)
         np.testing.assert_allclose(o2["stats"][n, 0], st["ssy"][0], rtol=1e-7)
         np.testing.assert_allclose(o2["stats"][n, 2:2 + d], st["ss"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("case", ["sparse16_d13", "mfma16_dense_d6", "generic_d8_p4", "tiled_d17_p3", "per_series_params"])
+def test_log_likelihood_prediction_error_decomposition(eng, case):
+    """dlm_loglik_batch = sum_t KalmanFilter.conditionalLikelihood(f_t, Q_t, y_t) (KalmanFilter.scala:138-153) on every
+    forward variant, with missing observations; nothing but N numbers leaves the GPU."""
+    rng = np.random.default_rng(abs(hash(case)) % 1000 if False else {"sparse16_d13": 1, "mfma16_dense_d6": 2, "generic_d8_p4": 3,
+                                                                      "tiled_d17_p3": 4, "per_series_params": 5}[case])
+    N = 3
+    if case in ("sparse16_d13", "per_series_params"):
+        mod, mat, p = seasonal_model(T=80)
+        expect = "sparse16"
+    elif case == "mfma16_dense_d6":
+        A = rng.standard_normal((6, 6)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((6, 1))
+        mat = materialise(Dlm(lambda t: F, lambda dt: G1), np.arange(1, 61, dtype=np.float64))
+        p = DlmParameters([[0.8]], np.eye(6) * 0.3, np.zeros(6), np.eye(6))
+        expect = "mfma16"
+    elif case == "generic_d8_p4":
+        mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
+        mat = materialise(mod, np.cumsum(np.array([1, 2, 1, 1, 3] * 8, dtype=np.float64)))
+        B = rng.standard_normal((4, 4))
+        p = DlmParameters(B @ B.T / 4 + 0.5 * np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8))
+        expect = "generic"
+    else:
+        d, q = 17, 3
+        A = rng.standard_normal((d, d)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((d, q))
+        mat = materialise(Dlm(lambda t: F, lambda dt: G1), np.arange(1, 41, dtype=np.float64))
+        B = rng.standard_normal((q, q)); A2 = rng.standard_normal((d, d))
+        p = DlmParameters(B @ B.T / q + 0.5 * np.eye(q), A2 @ A2.T / d + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d))
+        expect = "tiled-mfma"
+    y = rng.standard_normal((N, mat.T, mat.p)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.15] = np.nan
+    y[:, 7, :] = np.nan
+    params = p
+    if case == "per_series_params":   # a bank of parameter sets in one launch
+        params = [DlmParameters(p.v * s, p.w * s, p.m0, p.c0) for s in (0.5, 1.0, 2.0)]
+    out = eng.loglik(mat, params, y)
+    assert eng.last_variant == expect and np.all(out["status"] == 0)
+    for n in range(N):
+        pn = params[n] if isinstance(params, list) else params
+        f = oracle.kf_filter(omodel(mat), pn.v, pn.w, pn.m0, pn.c0, y[n])
+        np.testing.assert_allclose(out["loglik"][n], oracle.loglik(omodel(mat), f, y[n]), rtol=1e-10, atol=1e-9)

@@ -335,3 +335,28 @@ def test_svd_sampler_zero_noise_matches_rts():
     sm1 = oracle.smoother(om, kf1, compat_q1=False)
     lit1 = oracle.svd_backward_sample(om, p1.w, sf1, np.zeros((31, 13)), literal_q9=True)
     np.testing.assert_allclose(lit1["theta"], sm1["s"], rtol=1e-6, atol=1e-7)
+
+
+def test_loglik_matches_scipy_and_scalar_closed_form():
+    """oracle_loglik = sum of KalmanFilter.conditionalLikelihood (KalmanFilter.scala:138-153): checked against
+    scipy.stats on the forecasts, observed components only; all-missing steps contribute nothing."""
+    from scipy.stats import multivariate_normal, norm
+    rng = np.random.default_rng(11)
+    mod = Dlm.polynomial(2) * Dlm.polynomial(1)
+    mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
+    B = rng.standard_normal((2, 2))
+    p = DlmParameters(B @ B.T + np.eye(2), np.eye(3) * 0.4, np.zeros(3), np.eye(3) * 2)
+    y = rng.standard_normal((mat.T, 2)).cumsum(axis=0)
+    y[rng.random(y.shape) < 0.25] = np.nan
+    y[4] = np.nan
+    M = oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+    f = oracle.kf_filter(M, p.v, p.w, p.m0, p.c0, y)
+    want = 0.0
+    for t in range(mat.T):
+        ob = ~np.isnan(y[t])
+        if not ob.any():
+            continue
+        Q = f["Q"][t + 1].reshape(2, 2).T[np.ix_(ob, ob)]
+        mu = f["f"][t + 1][ob]
+        want += norm(mu[0], np.sqrt(Q[0, 0])).logpdf(y[t][ob][0]) if ob.sum() == 1 else multivariate_normal(mu, Q).logpdf(y[t][ob])
+    assert oracle.loglik(M, f, y) == pytest.approx(want, rel=1e-12, abs=1e-10)
