@@ -33,7 +33,8 @@ class ParamsDesc(ctypes.Structure):
     _fields_ = [("V", ctypes.c_void_p), ("v_stride", ctypes.c_int64),
                 ("W", ctypes.c_void_p), ("w_stride", ctypes.c_int64),
                 ("m0", ctypes.c_void_p), ("m0_stride", ctypes.c_int64),
-                ("C0", ctypes.c_void_p), ("c0_stride", ctypes.c_int64)]
+                ("C0", ctypes.c_void_p), ("c0_stride", ctypes.c_int64),
+                ("v_tstride", ctypes.c_int64), ("w_tstride", ctypes.c_int64)]
 
 
 class Options(ctypes.Structure):

@@ -115,6 +115,8 @@ int check_common(dlm_engine* e, const dlm_model_desc* m, const dlm_params_desc* 
   if (m->n_g > 1 && !m->g_index) return fail(e, DLM_ERR_ARG, "n_g > 1 needs g_index");
   if (m->f_stride != 0 && m->f_stride != (int64_t)m->d * m->p) return fail(e, DLM_ERR_ARG, "f_stride must be 0 or d*p");
   if (!p->V || !p->W || !p->m0 || !p->C0) return fail(e, DLM_ERR_ARG, "parameter arrays missing");
+  if ((p->v_tstride != 0 && p->v_tstride != (int64_t)m->p * m->p) || (p->w_tstride != 0 && p->w_tstride != (int64_t)m->d * m->d))
+    return fail(e, DLM_ERR_ARG, "v_tstride must be 0 or p*p, w_tstride 0 or d*d");
   if (o->mem != DLM_MEM_DEVICE && o->mem != DLM_MEM_HOST) return fail(e, DLM_ERR_ARG, "opts->mem");
   if (m->d > 64 || m->p > 64) return fail(e, DLM_ERR_UNSUPPORTED, "d and p are limited to 64 in this build");
   HIP_TRY(e, hipSetDevice(e->device));
@@ -126,14 +128,17 @@ void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params
   const size_t d = m->d, pp = m->p, T = m->T, N = m->N;
   k.d = m->d; k.p = m->p; k.T = m->T; k.N = m->N; k.n_g = m->n_g;
   k.f_stride = m->f_stride; k.v_stride = p->v_stride; k.w_stride = p->w_stride;
+  k.v_tstride = p->v_tstride; k.w_tstride = p->w_tstride;
   k.m0_stride = p->m0_stride; k.c0_stride = p->c0_stride;
   k.flags = o->flags; k.seed = o->seed; k.series_offset = o->series_offset;
   st.in(&k.F, m->F, (m->f_stride ? T : 1) * d * pp);
   st.in(&k.G, m->G, (size_t)m->n_g * d * d);
   st.in(&k.g_index, (const int*)m->g_index, m->g_index ? T : 0);
   st.in(&k.dt, m->dt, m->dt ? T : 0);
-  st.in(&k.V, p->V, p->v_stride ? (N - 1) * (size_t)p->v_stride + pp * pp : pp * pp);
-  st.in(&k.W, p->W, p->w_stride ? (N - 1) * (size_t)p->w_stride + d * d : d * d);
+  const size_t vblk = p->v_tstride ? (T - 1) * (size_t)p->v_tstride + pp * pp : pp * pp;   // one series' V (or V_0 .. V_{T-1})
+  const size_t wblk = p->w_tstride ? (T - 1) * (size_t)p->w_tstride + d * d : d * d;
+  st.in(&k.V, p->V, p->v_stride ? (N - 1) * (size_t)p->v_stride + vblk : vblk);
+  st.in(&k.W, p->W, p->w_stride ? (N - 1) * (size_t)p->w_stride + wblk : wblk);
   st.in(&k.m0, p->m0, p->m0_stride ? (N - 1) * (size_t)p->m0_stride + d : d);
   st.in(&k.C0, p->C0, p->c0_stride ? (N - 1) * (size_t)p->c0_stride + d * d : d * d);
 }
@@ -440,6 +445,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
   const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
+  if (simflag && (params->v_tstride || params->w_tstride))
+    return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes time-invariant V and W (drop DLM_OPT_FFBS_SIMSMOOTH for V_t / W_t streams)");
   st.in(&k.y, y, y ? N * T * p : 0);
   st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + p : d) : 0);
   if (forward) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
@@ -494,6 +501,7 @@ int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
                          const dlm_options* opts, double* svd_rec, int32_t* status) {
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
+  if (params->v_tstride || params->w_tstride) return fail(e, DLM_ERR_UNSUPPORTED, "the SVD filter takes time-invariant V and W");
   if (!y || !svd_rec) return fail(e, DLM_ERR_ARG, "y and svd_rec are required");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
   KArgs k{};
@@ -514,6 +522,7 @@ int dlm_svd_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_par
                        double* svd_ws, double* theta, double* stats, int32_t* status) {
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
+  if (params->v_tstride || params->w_tstride) return fail(e, DLM_ERR_UNSUPPORTED, "the SVD filter takes time-invariant V and W");
   if (!y || !svd_ws) return fail(e, DLM_ERR_ARG, "y and svd_ws are required");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
   KArgs k{};

@@ -119,10 +119,13 @@ __global__ __launch_bounds__(64) void k_filter_generic(KArgs a) {
   for (int i = lane; i < dd; i += 64) { C[i] = C0[i]; if (out) out[d + i] = C0[i]; if (pri) pri[d + i] = C0[i]; }
   if (fq) for (int i = lane; i < frec; i += 64) fq[i] = __builtin_nan("");
 
+  const double* V0 = V; const double* W0 = W;
   for (int t = 0; t < T; ++t) {
     const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
     const double* Ft = a.F + (size_t)t * a.f_stride;
     const double dt = a.dt ? a.dt[t] : 1.0;
+    V = V0 + (size_t)t * a.v_tstride;   // time-varying variances (StudentTGibbs.scala:100-136, DlmFsvSystem.scala:137-208)
+    W = W0 + (size_t)t * a.w_tstride;
     wsync();
     // advState (KalmanFilter.scala:273-286)
     if (dt == 0.0) {
@@ -285,7 +288,8 @@ __global__ __launch_bounds__(64) void k_smoother_generic(KArgs a) {
     for (int i = lane; i < d; i += 64) m[i] = r[i];
     for (int i = lane; i < dd; i += 64) C[i] = r[d + i];
     wsync();
-    if (backward_prologue(lane, d, Gt, W, dt, m, C, a1, R, T1, X)) st |= DLM_ST_NOT_PD;
+    const double* Wt = W + (size_t)t * a.w_tstride;   // the transition into record t+1
+    if (backward_prologue(lane, d, Gt, Wt, dt, m, C, a1, R, T1, X)) st |= DLM_ST_NOT_PD;
     // X = R_{t+1} - S_{t+1}; u = s_{t+1} - a_{t+1}
     for (int i = lane; i < dd; i += 64) X[i] -= S[i];
     for (int i = lane; i < d; i += 64) u[i] = s[i] - a1[i];
@@ -389,7 +393,8 @@ __global__ __launch_bounds__(64) void k_sampler_generic(KArgs a) {
     }
     for (int i = lane; i < dd; i += 64) C[i] = r[d + i];
     wsync();
-    if (backward_prologue(lane, d, Gt, W, dt, m, C, a1, R, T1, nullptr)) st |= DLM_ST_NOT_PD;
+    const double* Wt = W + (size_t)t * a.w_tstride;   // the transition into record t+1
+    if (backward_prologue(lane, d, Gt, Wt, dt, m, C, a1, R, T1, nullptr)) st |= DLM_ST_NOT_PD;
     for (int i = lane; i < d; i += 64) u[i] = th[i] - a1[i];
     wsync();
     // h = m + J u ; D = I - J G   (Smoothing.scala:88-93)
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(64) void k_sampler_generic(KArgs a) {
     gemm<false, false>(lane, d, d, d, D, d, C, d, T2, d);     // D C
     wsync();
     gemm<false, true>(lane, d, d, d, T2, d, D, d, H, d);      // D C D^T
-    gemm<true, false>(lane, d, d, d, T1, d, W, d, R, d);       // J W -> R (its Cholesky factor is spent)
+    gemm<true, false>(lane, d, d, d, T1, d, Wt, d, R, d);      // J W -> R (its Cholesky factor is spent)
     wsync();
     for (int k = lane; k < dd; k += 64) {                      // H += dt * (J W) J^T
       const int i = k % d, j = k / d;

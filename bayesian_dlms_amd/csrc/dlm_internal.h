@@ -12,6 +12,7 @@ struct KArgs {
   const double* G; int n_g; const int* g_index; const double* dt;
   const double* V; long long v_stride;
   const double* W; long long w_stride;
+  long long v_tstride, w_tstride;   // per-time strides of V_t / W_t (0 = time-invariant)
   const double* m0; long long m0_stride;
   const double* C0; long long c0_stride;
   const double* y;     // [N][T][p]

@@ -54,7 +54,9 @@ __device__ __forceinline__ double uniform_from_lane(double v, int src) {
 bool fast_shape(const KArgs& a) {
   return a.d <= 15 && a.p == 1 && ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);
 }
-bool mfma16_supported(const KArgs& a) { return fast_shape(a) && a.f_stride == 0 && a.g_index == nullptr && a.dt == nullptr; }
+bool mfma16_supported(const KArgs& a) {
+  return fast_shape(a) && a.f_stride == 0 && a.g_index == nullptr && a.dt == nullptr && a.v_tstride == 0 && a.w_tstride == 0;
+}
 
 // ---------------------------------------------------------------------------------------
 // forward pass

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* C0 = a.C0 + (size_t)n * a.c0_stride;
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
-  const double V = a.V[(size_t)n * a.v_stride];
+  double V = a.V[(size_t)n * a.v_stride];   // V_0; reloaded every step when time-varying (IRR instantiation)
   const double* y = a.y + (size_t)n * T;
   // likelihood-only calls pass no record buffer: a zero-sized resource drops every store
   char* bout = a.filt ? (char*)(a.filt + (size_t)n * (T + 1) * rec) : nullptr;
@@ -467,6 +467,15 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
       Fc = vc ? Ft[c] : 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) Fr[r] = vr[r] ? Ft[4 * r + g] : 0.0;
+    }
+    if (IRR && a.v_tstride) {                                // time-varying V_t (StudentTGibbs.scala:100-136)
+      V = a.V[(size_t)n * a.v_stride + (size_t)t * a.v_tstride];
+      if (!(V > 0.0)) st |= DLM_ST_NOT_PD;
+    }
+    if (IRR && a.w_tstride) {                                // time-varying W_t (DlmFsvSystem.scala:137-208)
+      const double* Wt = W + (size_t)t * a.w_tstride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (vr[r] && vc) ? Wt[(4 * r + g) * d + c] : 0.0;
     }
 
     // advState: a = G m, R = G C G^T + W dt   (dt == 0: a = m, R = C, KalmanFilter.scala:279-280)
@@ -584,7 +593,7 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
   const bool vc = c < d, col15 = (c == 15);
 
   const double V = a.V[(size_t)n * a.v_stride];
-  const double rV = 1.0 / V;
+  double rV = 1.0 / V;   // 1 / V_t of the record's observation when time-varying (IRR instantiation)
   const char* bin = (const char*)(a.filt_in + (size_t)n * (T + 1) * rec);
   char* bout = (char*)(a.smooth + (size_t)n * (T + 1) * rec);
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
@@ -657,6 +666,11 @@ __global__ __launch_bounds__(256, DLM_SM_WAVES) void k_smoother_sp16(KArgs a, co
       Fc = vc ? Ft[c] : 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) Fr[r] = (4 * r + g < d) ? Ft[4 * r + g] : 0.0;
+    }
+    if (IRR && a.v_tstride && t > 0) {                       // V of the observation at record t
+      const double Vt = a.V[(size_t)n * a.v_stride + (size_t)(t - 1) * a.v_tstride];
+      if (!(Vt > 0.0)) st |= DLM_ST_NOT_PD;
+      rV = 1.0 / Vt;
     }
 
     // K_t = C_t F / V  (column 15 would give F.m: masked)
@@ -964,7 +978,7 @@ int sparse16_analyse(const double* G /* d x d column-major, host */, int d, Spar
 
 template <int K>
 static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, double* xplus, hipStream_t s) {
-  const bool irr = a.g_index || a.dt || a.f_stride;
+  const bool irr = a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride;
   const dim3 grid((a.N + 3) / 4), blk(256);
   if (xplus && irr) hipLaunchKernelGGL((k_filter_sp16<K, true, true>), grid, blk, 0, s, a, sp, side, xplus);
   else if (xplus) hipLaunchKernelGGL((k_filter_sp16<K, true, false>), grid, blk, 0, s, a, sp, side, xplus);
@@ -981,7 +995,7 @@ static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* sid
 template <int K>
 static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
   const size_t ring = (size_t)4 * 2 * ((a.d + a.d * a.d) * 8 + 16);   // dynamic LDS: DMA ring, 2 slots per wave
-  if (a.g_index || a.dt || a.f_stride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
+  if (a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   return hipGetLastError();
 }

@@ -611,8 +611,9 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
   double* Qm = Tm;           double* Es = Tm + SML;   double* Li = Es;
   bool warm = false;
   double* Lw = sm + FILT_DOUBLES;  double* Lv = Lw + BIG;   double* xv = Lv + SML;   double* zv = xv + 48;   // SIM only
-  const double* V = a.V + (size_t)n * a.v_stride;
+  const double* V = a.V + (size_t)n * a.v_stride;   // V_0 / W_0; advanced every step when time-varying
   const double* W = a.W + (size_t)n * a.w_stride;
+  const double* const V0 = V; const double* const W0 = W;
   const double* y = a.y + (size_t)n * T * p;
   double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;   // null: likelihood only, nothing stored
   double ll = 0.0;   // prediction-error log-likelihood, accumulated by lane 0 of wave VW (KalmanFilter.scala:138-153)
@@ -672,6 +673,12 @@ __global__ __launch_bounds__(NT) void k_filter_tiled(KArgs a, double* __restrict
     TSTAMP(7)
     int tl = tid;   // opaque copy: no hoisting of the products' operand addresses out of the time loop (see k_smoother_tiled)
     asm volatile("" : "+v"(tl));
+    if (a.v_tstride) V = V0 + (size_t)t * a.v_tstride;   // time-varying variances (StudentTGibbs.scala:100-136, DlmFsvSystem.scala:137-208)
+    if (a.w_tstride) {
+      W = W0 + (size_t)t * a.w_tstride;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { const int r = (tid >> 6) + NW * q, i = tid & 63; wreg[q] = (a.spb && r < d && i < d) ? W[r + i * d] : 0.0; }
+    }
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) { lds_barrier(); load_cm(tid, a.G + (size_t)gi * dd, d, d, Gm, DL); gcur = gi; }
@@ -896,9 +903,10 @@ __global__ __launch_bounds__(NT) void k_smoother_tiled(KArgs a, const double* __
     const double* Gt = a.G + (size_t)((a.g_index && t > 0) ? a.g_index[t - 1] : 0) * dd;   // G of the step INTO record t
 
     if (any) {
-      if (!same) {   // Vm^-1 for this missingness pattern (cached while the pattern repeats)
+      if (!same || a.v_tstride) {   // Vm^-1 for this missingness pattern (cached while the pattern repeats and V is time-invariant)
+        const double* Vt = V + (size_t)(t - 1) * a.v_tstride;   // V of the observation at record t
         lds_barrier();
-        FOR_CM(p, p, i, j) Vi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0);
+        FOR_CM(p, p, i, j) Vi[i * PL + j] = (ob[i] != 0.0 && ob[j] != 0.0) ? Vt[i + j * p] : (i == j ? 1.0 : 0.0);
         if (spd_inverse(tid, p, Vi, Li, (int*)(cq + 40))) st |= DLM_ST_NOT_PD;
         FOR_CM(p, p, i, j) if (!(ob[i] != 0.0 && ob[j] != 0.0)) Vi[i * PL + j] = 0.0;
         if (tid < p) obp[tid] = ob[tid];

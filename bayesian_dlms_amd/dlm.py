@@ -110,7 +110,9 @@ class Dlm:
 
 @dataclass
 class DlmParameters:
-    """DlmParameters(v, w, m0, c0) (Dlm.scala:36-39)."""
+    """DlmParameters(v, w, m0, c0) (Dlm.scala:36-39).  `v` / `w` may also be [T] streams of matrices (shape
+    (T, p, p) / (T, d, d)): V_t of observation t and W_t of the transition into it -- the per-step variances of
+    StudentT.filter (StudentTGibbs.scala:100-136) and DlmFsvSystem.ffbs (DlmFsvSystem.scala:137-208)."""
 
     v: np.ndarray
     w: np.ndarray
@@ -118,8 +120,12 @@ class DlmParameters:
     c0: np.ndarray
 
     def __post_init__(self):
-        self.v = np.atleast_2d(np.asarray(self.v, dtype=np.float64))
-        self.w = np.atleast_2d(np.asarray(self.w, dtype=np.float64))
+        self.v = np.asarray(self.v, dtype=np.float64)
+        self.w = np.asarray(self.w, dtype=np.float64)
+        if self.v.ndim != 3:
+            self.v = np.atleast_2d(self.v)
+        if self.w.ndim != 3:
+            self.w = np.atleast_2d(self.w)
         self.m0 = np.atleast_1d(np.asarray(self.m0, dtype=np.float64))
         self.c0 = np.atleast_2d(np.asarray(self.c0, dtype=np.float64))
 

@@ -20,18 +20,32 @@ def _cm(a):
     return np.ascontiguousarray(a.T).reshape(-1) if a.ndim == 2 else np.ascontiguousarray(a).reshape(-1)
 
 
+def _cm_stream(a):
+    """One matrix, or a [T] stream of matrices -> flat column-major array(s)."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 3:
+        return np.ascontiguousarray(np.transpose(a, (0, 2, 1))).reshape(-1)
+    return _cm(a)
+
+
 def pack_params(params: Union[DlmParameters, Sequence[DlmParameters]], N: int):
-    """DlmParameters (shared) or a sequence of N DlmParameters (per series) -> flat
-    column-major arrays and strides in doubles."""
+    """DlmParameters (shared) or a sequence of N DlmParameters (per series) -> flat column-major arrays and strides
+    in doubles: (V, v_stride, W, w_stride, m0, m0_stride, C0, c0_stride, v_tstride, w_tstride).  The last two are
+    the per-time strides of V_t / W_t streams (0 = time-invariant)."""
+    plist = [params] if isinstance(params, DlmParameters) else list(params)
+    if not isinstance(params, DlmParameters) and len(plist) != N:
+        raise ValueError(f"need {N} DlmParameters, got {len(plist)}")
+    p0 = plist[0]
+    vts = p0.v.shape[-1] ** 2 if p0.v.ndim == 3 else 0
+    wts = p0.w.shape[-1] ** 2 if p0.w.ndim == 3 else 0
+    if any((q.v.ndim == 3) != (vts != 0) or (q.w.ndim == 3) != (wts != 0) for q in plist):
+        raise ValueError("either every series has time-varying V (W) or none")
     if isinstance(params, DlmParameters):
-        return (_cm(params.v), 0, _cm(params.w), 0, _cm(params.m0), 0, _cm(params.c0), 0)
-    params = list(params)
-    if len(params) != N:
-        raise ValueError(f"need {N} DlmParameters, got {len(params)}")
-    V = np.stack([_cm(q.v) for q in params]); W = np.stack([_cm(q.w) for q in params])
-    m0 = np.stack([_cm(q.m0) for q in params]); C0 = np.stack([_cm(q.c0) for q in params])
+        return (_cm_stream(p0.v), 0, _cm_stream(p0.w), 0, _cm(p0.m0), 0, _cm(p0.c0), 0, vts, wts)
+    V = np.stack([_cm_stream(q.v) for q in plist]); W = np.stack([_cm_stream(q.w) for q in plist])
+    m0 = np.stack([_cm(q.m0) for q in plist]); C0 = np.stack([_cm(q.c0) for q in plist])
     return (V.reshape(-1), V.shape[1], W.reshape(-1), W.shape[1], m0.reshape(-1), m0.shape[1],
-            C0.reshape(-1), C0.shape[1])
+            C0.reshape(-1), C0.shape[1], vts, wts)
 
 
 class _Host:
@@ -122,7 +136,11 @@ class Engine:
 
     def prepare(self, mat: MaterialisedModel, params, N: int, be, flags=0, seed=0, series_offset=0):
         """Build the descriptors; returns (model, params, opts, keepalive list)."""
-        V, vs, W, ws, m0, m0s, C0, c0s = pack_params(params, N) if not isinstance(params, tuple) else params
+        packed = pack_params(params, N) if not isinstance(params, tuple) else params
+        V, vs, W, ws, m0, m0s, C0, c0s = packed[:8]
+        vts, wts = (packed[8], packed[9]) if len(packed) > 8 else (0, 0)
+        if vts and np.size(V) // max(1, (N if vs else 1)) != mat.T * vts or wts and np.size(W) // max(1, (N if ws else 1)) != mat.T * wts:
+            raise ValueError("time-varying V / W need one matrix per observation")
         items = dict(F=(mat.F, np.float64), G=(mat.G, np.float64), gi=(mat.g_index, np.int32), dt=(mat.dt, np.float64),
                      V=(V, np.float64), W=(W, np.float64), m0=(m0, np.float64), C0=(C0, np.float64))
         if isinstance(be, _Device) and not any(isinstance(a, be.torch.Tensor) for a, _ in items.values()):
@@ -143,13 +161,13 @@ class Engine:
             bufs = {"blob": blob}
             P = lambda name: (base + offs[name]) if name in offs else None
             md = _lib.ModelDesc(mat.d, mat.p, mat.T, N, P("F"), mat.f_stride, P("G"), mat.n_g, P("gi"), P("dt"))
-            pd = _lib.ParamsDesc(P("V"), vs, P("W"), ws, P("m0"), m0s, P("C0"), c0s)
+            pd = _lib.ParamsDesc(P("V"), vs, P("W"), ws, P("m0"), m0s, P("C0"), c0s, vts, wts)
             return md, pd, _lib.Options(flags, be.mem, seed, series_offset), bufs
         bufs = {name: be.put(a, dt) for name, (a, dt) in items.items()}
         P = lambda a: (be.ptr(a).value if a is not None else None)
         md = _lib.ModelDesc(mat.d, mat.p, mat.T, N, P(bufs["F"]), mat.f_stride, P(bufs["G"]), mat.n_g,
                             P(bufs["gi"]), P(bufs["dt"]))
-        pd = _lib.ParamsDesc(P(bufs["V"]), vs, P(bufs["W"]), ws, P(bufs["m0"]), m0s, P(bufs["C0"]), c0s)
+        pd = _lib.ParamsDesc(P(bufs["V"]), vs, P(bufs["W"]), ws, P(bufs["m0"]), m0s, P(bufs["C0"]), c0s, vts, wts)
         op = _lib.Options(flags, be.mem, seed, series_offset)
         return md, pd, op, bufs
 

@@ -75,12 +75,18 @@ typedef struct {
 } dlm_model_desc;
 
 /* `DlmParameters(v, w, m0, c0)` (Dlm.scala:36-39); a stride of 0 shares the array between
- * all series, otherwise series n reads base + n * stride (doubles). */
+ * all series, otherwise series n reads base + n * stride (doubles).
+ * Time-varying variances (the per-step V_t / W_t streams of StudentT.filter, StudentTGibbs.scala:100-136,
+ * and of DlmFsvSystem.ffbs, DlmFsvSystem.scala:137-208): with v_tstride / w_tstride != 0 observation t (0-based) uses
+ * V + n * v_stride + t * v_tstride and the transition INTO observation t uses W + n * w_stride + t * w_tstride
+ * (T matrices each).  0 = time-invariant.  Not available on the SVD entry points (DLM_ERR_UNSUPPORTED). */
 typedef struct {
   const double *V;  int64_t v_stride;   /* p x p */
   const double *W;  int64_t w_stride;   /* d x d */
   const double *m0; int64_t m0_stride;  /* d     */
   const double *C0; int64_t c0_stride;  /* d x d */
+  int64_t v_tstride;                    /* 0 or p * p */
+  int64_t w_tstride;                    /* 0 or d * d */
 } dlm_params_desc;
 
 typedef struct {

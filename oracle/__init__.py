@@ -74,10 +74,29 @@ class Model:
         self.f_stride = int(f_stride)
 
 
+def _tv(A, n):
+    """A single n x n matrix, or a [T] stream of them -> (flat column-major array, per-time stride)."""
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim == 3:
+        return np.ascontiguousarray(np.transpose(A, (0, 2, 1))).reshape(-1), n * n
+    return cm(A), 0
+
+
 def kf_filter(M, V, W, m0, C0, y):
     """KalmanFilter(...).filter: returns dict of m,C,a,R,f,Q with T+1 records
-    (matrices column-major flattened in the last axis)."""
+    (matrices column-major flattened in the last axis).  V / W may be [T] streams of matrices."""
     d, p, T = M.d, M.p, M.T
+    if np.ndim(V) == 3 or np.ndim(W) == 3:
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(T, p)
+        out = {"m": np.empty((T + 1, d)), "C": np.empty((T + 1, d * d)), "a": np.empty((T + 1, d)),
+               "R": np.empty((T + 1, d * d)), "f": np.empty((T + 1, p)), "Q": np.empty((T + 1, p * p))}
+        (Vf, vts), (Wf, wts) = _tv(V, p), _tv(W, d)
+        m0, C0 = cm(m0), cm(C0)
+        out["rc"] = lib().oracle_kf_filter_tv(
+            d, p, T, _p(M.F), ctypes.c_long(M.f_stride), _p(M.G), _pi(M.g_index), _p(M.dt),
+            _p(Vf), ctypes.c_long(vts), _p(Wf), ctypes.c_long(wts), _p(m0), _p(C0), _p(y),
+            _p(out["m"]), _p(out["C"]), _p(out["a"]), _p(out["R"]), _p(out["f"]), _p(out["Q"]))
+        return out
     y = np.ascontiguousarray(y, dtype=np.float64).reshape(T, p)
     out = {
         "m": np.empty((T + 1, d)), "C": np.empty((T + 1, d * d)),
@@ -113,10 +132,10 @@ def backward_sample(M, W, filt, z, factor="eig"):
     d, T = M.d, M.T
     z = np.ascontiguousarray(z, dtype=np.float64).reshape(T + 1, d)
     theta = np.empty((T + 1, d)); h = np.empty((T + 1, d)); H = np.empty((T + 1, d * d))
-    W = cm(W)
-    rc = lib().oracle_backward_sample(d, T, _p(M.G), _pi(M.g_index), _p(M.dt), _p(W),
-                                      _p(filt["m"]), _p(filt["C"]), _p(filt["a"]), _p(filt["R"]),
-                                      _p(z), 0 if factor == "eig" else 1, _p(theta), _p(h), _p(H))
+    W, wts = _tv(W, d)
+    rc = lib().oracle_backward_sample_tv(d, T, _p(M.G), _pi(M.g_index), _p(M.dt), _p(W), ctypes.c_long(wts),
+                                         _p(filt["m"]), _p(filt["C"]), _p(filt["a"]), _p(filt["R"]),
+                                         _p(z), 0 if factor == "eig" else 1, _p(theta), _p(h), _p(H))
     return {"theta": theta, "h": h, "H": H, "rc": rc}
 
 

@@ -255,9 +255,9 @@ static double dt_at(const model_t *M, int t) { return M->dt ? M->dt[t] : 1.0; }
 /* m=a=m0, C=R=C0 and f,Q = NaN (the reference's None).                   */
 /* Returns 0 or (t+1) of the first singular Q solve.                      */
 /* ------------------------------------------------------------------ */
-int oracle_kf_filter(int d, int p, int T, const double *F, long f_stride,
+static int kf_filter_core(int d, int p, int T, const double *F, long f_stride,
                      const double *G, const int *g_index, const double *dts,
-                     const double *V, const double *W, const double *m0,
+                     const double *V0, long v_tstride, const double *W0, long w_tstride, const double *m0,
                      const double *C0, const double *y, /* [T][p], NaN = missing */
                      double *m_out, double *C_out,       /* [T+1][d], [T+1][d*d] */
                      double *a_out, double *R_out,       /* same shapes, may be NULL */
@@ -285,6 +285,8 @@ int oracle_kf_filter(int d, int p, int T, const double *F, long f_stride,
   if (Q_out) for (int i = 0; i < p * p; ++i) Q_out[i] = NAN;
 
   for (int t = 0; t < T; ++t) {
+    /* time-varying variances: V_t of observation t, W_t of the transition into it (StudentTGibbs.scala:100-136) */
+    const double *V = V0 + (size_t)t * v_tstride, *W = W0 + (size_t)t * w_tstride;
     const double *m = m_out + (size_t)t * d, *C = C_out + (size_t)t * dd;
     double *mn = m_out + (size_t)(t + 1) * d, *Cn = C_out + (size_t)(t + 1) * dd;
     const double *Ft = F_at(&M, t), *Gt = G_at(&M, t);
@@ -355,6 +357,22 @@ int oracle_kf_filter(int d, int p, int T, const double *F, long f_stride,
   free(a); free(R); free(GC); free(Fm); free(Vm); free(Qm); free(RF); free(X);
   free(K); free(D); free(DR); free(KV); free(yo); free(res); free(idx);
   return rc;
+}
+
+int oracle_kf_filter(int d, int p, int T, const double *F, long f_stride,
+                     const double *G, const int *g_index, const double *dts,
+                     const double *V, const double *W, const double *m0,
+                     const double *C0, const double *y, double *m_out, double *C_out,
+                     double *a_out, double *R_out, double *f_out, double *Q_out) {
+  return kf_filter_core(d, p, T, F, f_stride, G, g_index, dts, V, 0, W, 0, m0, C0, y, m_out, C_out, a_out, R_out, f_out, Q_out);
+}
+/* the same with V_t [T][p*p] / W_t [T][d*d] streams (a stride of 0 keeps that matrix time-invariant) */
+int oracle_kf_filter_tv(int d, int p, int T, const double *F, long f_stride,
+                        const double *G, const int *g_index, const double *dts,
+                        const double *V, long v_tstride, const double *W, long w_tstride, const double *m0,
+                        const double *C0, const double *y, double *m_out, double *C_out,
+                        double *a_out, double *R_out, double *f_out, double *Q_out) {
+  return kf_filter_core(d, p, T, F, f_stride, G, g_index, dts, V, v_tstride, W, w_tstride, m0, C0, y, m_out, C_out, a_out, R_out, f_out, Q_out);
 }
 
 /* cgrinv = (rt1.t \ (g(dt) * ct.t)).t  -- Smoothing.scala:41 and :85.
@@ -486,8 +504,8 @@ static void mvn_draw(int d, const double *mu, const double *cov, const double *z
   }
 }
 
-int oracle_backward_sample(int d, int T, const double *G, const int *g_index, const double *dts,
-                           const double *W, const double *m, const double *C, const double *a,
+static int backward_sample_core(int d, int T, const double *G, const int *g_index, const double *dts,
+                           const double *W0, long w_tstride, const double *m, const double *C, const double *a,
                            const double *R, const double *z, int factor, double *theta,
                            double *h_out, double *H_out) {
   const int dd = d * d;
@@ -502,6 +520,7 @@ int oracle_backward_sample(int d, int T, const double *G, const int *g_index, co
   if (h_out) memcpy(h_out + (size_t)T * d, m + (size_t)T * d, sizeof(double) * d);
   if (H_out) memcpy(H_out + (size_t)T * dd, C + (size_t)T * dd, sizeof(double) * dd);
   for (int t = T - 1; t >= 0; --t) {
+    const double *W = W0 + (size_t)t * w_tstride;   /* W of the transition into record t+1 */
     const double *Gn = G + (size_t)(g_index ? g_index[t] : 0) * dd;
     const double dt = dts ? dts[t] : 1.0;
     const double *R1 = R + (size_t)(t + 1) * dd, *a1 = a + (size_t)(t + 1) * d;
@@ -532,6 +551,20 @@ int oracle_backward_sample(int d, int T, const double *G, const int *g_index, co
   }
   free(J); free(s1); free(s2); free(D); free(H); free(h); free(u); free(w3);
   return rc;
+}
+
+int oracle_backward_sample(int d, int T, const double *G, const int *g_index, const double *dts,
+                           const double *W, const double *m, const double *C, const double *a,
+                           const double *R, const double *z, int factor, double *theta,
+                           double *h_out, double *H_out) {
+  return backward_sample_core(d, T, G, g_index, dts, W, 0, m, C, a, R, z, factor, theta, h_out, H_out);
+}
+/* the same with a W_t [T][d*d] stream */
+int oracle_backward_sample_tv(int d, int T, const double *G, const int *g_index, const double *dts,
+                              const double *W, long w_tstride, const double *m, const double *C, const double *a,
+                              const double *R, const double *z, int factor, double *theta,
+                              double *h_out, double *H_out) {
+  return backward_sample_core(d, T, G, g_index, dts, W, w_tstride, m, C, a, R, z, factor, theta, h_out, H_out);
 }
 
 /* ------------------------------------------------------------------ */

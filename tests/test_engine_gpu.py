@@ -10,6 +10,7 @@ import pytest
 import oracle
 from bayesian_dlms_amd import _lib
 from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
+from bayesian_dlms_amd.engine import EngineError
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +19,7 @@ VARIANTS = [0, _lib.OPT_FORCE_GENERIC]
 
 @pytest.fixture(scope="module")
 def eng():
-    from bayesian_dlms_amd.engine import Engine
+    from bayesian_dlms_amd.engine import Engine, EngineError
     e = Engine(0)
     yield e
     e.close()
@@ -926,3 +927,72 @@ def test_log_likelihood_prediction_error_decomposition(eng, case):
         pn = params[n] if isinstance(params, list) else params
         f = oracle.kf_filter(omodel(mat), pn.v, pn.w, pn.m0, pn.c0, y[n])
         np.testing.assert_allclose(out["loglik"][n], oracle.loglik(omodel(mat), f, y[n]), rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["sparse16_d13", "dense_d6_to_generic", "generic_d8_p4", "tiled_d17_p3_dense", "tiled_d20_p10_structured"])
+def test_time_varying_variance_streams(eng, case):
+    """V_t / W_t streams (StudentT.filter, StudentTGibbs.scala:100-136; DlmFsvSystem.ffbs,
+    DlmFsvSystem.scala:137-208): filter, smoother, log-likelihood and the literal backward sampler against the oracle."""
+    seed = {"sparse16_d13": 1, "dense_d6_to_generic": 2, "generic_d8_p4": 3, "tiled_d17_p3_dense": 4, "tiled_d20_p10_structured": 5}[case]
+    rng = np.random.default_rng(100 + seed)
+    if case == "sparse16_d13":
+        mod, mat, p0 = seasonal_model(T=60)
+        expect = "sparse16"
+    elif case == "dense_d6_to_generic":
+        A = rng.standard_normal((6, 6)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((6, 1))
+        mat = materialise(Dlm(lambda t: F, lambda dt: G1), np.arange(1, 41, dtype=np.float64))
+        p0 = DlmParameters([[0.8]], np.eye(6) * 0.3, np.zeros(6), np.eye(6))
+        expect = "generic"          # the dense-G MFMA kernels take time-invariant variances only
+    elif case == "generic_d8_p4":
+        mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
+        mat = materialise(mod, np.cumsum(np.array([1, 2, 1, 1, 3] * 6, dtype=np.float64)))
+        p0 = DlmParameters(np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8))
+        expect = "generic"
+    elif case == "tiled_d17_p3_dense":
+        d, q = 17, 3
+        A = rng.standard_normal((d, d)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((d, q))
+        mat = materialise(Dlm(lambda t: F, lambda dt: G1), np.arange(1, 31, dtype=np.float64))
+        p0 = DlmParameters(np.eye(q), np.eye(d) * 0.3, rng.standard_normal(d), np.eye(d))
+        expect = "tiled-mfma"
+    else:
+        mod = Dlm.polynomial(2)
+        for _ in range(9):
+            mod = mod * Dlm.polynomial(2)
+        mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
+        p0 = DlmParameters(np.eye(10), np.eye(20) * 0.2, np.zeros(20), np.eye(20))
+        expect = "tiled-mfma"
+    d, q, T = mat.d, mat.p, mat.T
+    # SPD streams: V_t = s_t (B B^T / q + I/2), W_t = diag scale + a dense SPD part
+    B = rng.standard_normal((q, q)); Vb = B @ B.T / q + 0.5 * np.eye(q)
+    A2 = rng.standard_normal((d, d)); Wb = A2 @ A2.T / (10 * d)
+    Vs = np.stack([Vb * rng.uniform(0.3, 3.0) for _ in range(T)])
+    Ws = np.stack([np.diag(np.diag(p0.w) * rng.uniform(0.2, 4.0, d)) + Wb * rng.uniform(0.0, 1.0) for _ in range(T)])
+    if case == "sparse16_d13":
+        Ws = np.stack([np.diag(np.diag(p0.w) * rng.uniform(0.2, 4.0, d)) for _ in range(T)])
+    p = DlmParameters(Vs, Ws, p0.m0, p0.c0)
+    N = 2
+    y = rng.standard_normal((N, T, q)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == expect and np.all(out["status"] == 0)
+    ll = eng.loglik(mat, p, y)["loglik"]
+    z = rng.standard_normal((N, T + 1, d))
+    draws = eng.ffbs(mat, p, y, z=z)
+    for n in range(N):
+        f = oracle.kf_filter(omodel(mat), Vs, Ws, p.m0, p.c0, y[n])
+        sm = oracle.smoother(omodel(mat), f)
+        m, C = split(out["filt"][n], d); s_, S = split(out["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(s_, sm["s"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(S, sm["S"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ll[n], oracle.loglik(omodel(mat), f, y[n]), rtol=1e-9, atol=1e-8)
+        ref = oracle.backward_sample(omodel(mat), Ws, f, z[n], factor="chol")
+        np.testing.assert_allclose(draws["theta"][n], ref["theta"], rtol=1e-6, atol=1e-7)
+    with pytest.raises(EngineError):
+        eng.ffbs(mat, p, y, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    if d <= 16 and q <= 16:
+        with pytest.raises(EngineError):
+            eng.svd_filter(mat, p, y)

@@ -64,9 +64,10 @@ def test_materialise_irregular_times_and_time_varying_f():
 
 def test_pack_params_and_observations():
     p = DlmParameters([[1.0]], np.array([[1.0, 2.0], [3.0, 4.0]]), [0.0, 1.0], np.eye(2))
-    V, vs, W, ws, m0, ms, C0, cs = pack_params(p, 5)
+    V, vs, W, ws, m0, ms, C0, cs, vts, wts = pack_params(p, 5)
+    assert (vts, wts) == (0, 0)
     assert (vs, ws, ms, cs) == (0, 0, 0, 0) and list(W) == [1, 3, 2, 4]           # column-major
-    V, vs, W, ws, m0, ms, C0, cs = pack_params([p, p, p], 3)
+    V, vs, W, ws, m0, ms, C0, cs, vts, wts = pack_params([p, p, p], 3)
     assert (vs, ws, ms, cs) == (1, 4, 2, 4) and W.size == 12
     with pytest.raises(ValueError):
         pack_params([p], 2)
