@@ -222,3 +222,36 @@ class SvdSampler:
         tt = _times_with_init(times)
         res = [[SamplingState(float(tt[t]), out["theta"][n, t]) for t in range(mat.T + 1)] for n in range(y.shape[0])]
         return res if batched else res[0]
+
+
+@dataclass
+class SvParameters:
+    """SvParameters(phi, mu, sigmaEta) of the AR(1) log-volatility (StochasticVolatility.scala)."""
+    phi: float
+    mu: float
+    sigma_eta: float
+
+
+class FilterAr:
+    """FilterAr (FilterAr.scala:15-82) for a batch of scalar series: ys [N][T] with NaN for None, vs the per-step
+    observation variances ([N][T], [T] or a scalar), p one SvParameters or one per series."""
+
+    @staticmethod
+    def _sv(p):
+        if isinstance(p, SvParameters):
+            return np.array([p.phi, p.mu, p.sigma_eta])
+        return np.array([[q.phi, q.mu, q.sigma_eta] for q in p])
+
+    @staticmethod
+    def filter_univariate(ys, vs, p, engine: Engine):
+        """filterUnivariate: (m_t, c_t) for t = 0..T, record 0 = (mu, sigma_eta^2 / (1 - phi^2))."""
+        out = engine.ar1_ffbs(np.atleast_2d(np.asarray(ys, dtype=np.float64)), vs, FilterAr._sv(p), want_theta=False)
+        f = np.asarray(out["filt"])
+        return f[..., 0], f[..., 1]
+
+    @staticmethod
+    def ffbs(p, ys, vs, engine: Engine, *, seed: int = 0, series_offset: int = 0, z=None):
+        """ffbs: one draw of the state path per series (T+1 values, the first at t0 - 1)."""
+        out = engine.ar1_ffbs(np.atleast_2d(np.asarray(ys, dtype=np.float64)), vs, FilterAr._sv(p), z=z, seed=seed,
+                              series_offset=series_offset, want_filt=False)
+        return np.asarray(out["theta"])

@@ -197,6 +197,27 @@ class Engine:
         self._check(self.lib.dlm_loglik_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(ll), be.ptr(status)))
         return {"loglik": ll, "status": status}
 
+    def ar1_ffbs(self, y, v, sv, *, z=None, seed=0, series_offset=0, want_filt=True, want_theta=True):
+        """Scalar AR(1) FFBS, one lane per series (dlm_ar1_ffbs_batch; FilterAr.scala:15-82).  y [N][T] (NaN = missing),
+        v [N][T] or [T] per-step observation variances, sv [N][3] or [3] = (phi, mu, sigma_eta)."""
+        be = self._backend(y)
+        N, T = int(y.shape[0]), int(y.shape[1])
+        yb = be.put(y).reshape(N, T)
+        vv = np.asarray(v, dtype=np.float64) if not hasattr(v, "data_ptr") else v
+        if np.ndim(vv) == 0:
+            vv = np.full(T, float(vv))
+        v_stride = T if vv.ndim == 2 else 0
+        svv = np.asarray(sv, dtype=np.float64) if not hasattr(sv, "data_ptr") else sv
+        sv_stride = 3 if svv.ndim == 2 else 0
+        vb, sb, zb = be.put(vv), be.put(svv), be.put(z)
+        filt = be.empty((N, T + 1, 2)) if want_filt else None
+        theta = be.empty((N, T + 1)) if want_theta else None
+        status = be.empty((N,), np.int32)
+        op = _lib.Options(0, be.mem, seed, series_offset)
+        self._check(self.lib.dlm_ar1_ffbs_batch(self.h, N, T, be.ptr(yb), be.ptr(vb), v_stride, be.ptr(sb), sv_stride,
+                                                be.ptr(zb), op, be.ptr(filt), be.ptr(theta), be.ptr(status)))
+        return {"filt": filt, "theta": theta, "status": status}
+
     def smooth(self, mat, params, filt, *, flags=0):
         be = self._backend(filt)
         N = int(filt.shape[0]); d, T = mat.d, mat.T

@@ -127,6 +127,19 @@ int dlm_filter_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_param
 int dlm_smooth_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
                      const double *filt, const dlm_options *opts, double *smooth, int32_t *status);
 
+/* Scalar AR(1) state-space FFBS, one GPU lane per series: FilterAr.filterUnivariate / univariateSample / ffbs
+ * (FilterAr.scala:15-82), the filter of the stochastic-volatility samplers (StochasticVolatility.scala:142-162,
+ * FactorSv.scala:415-512):
+ *   alpha_t = mu + phi (alpha_{t-1} - mu) + eta_t, eta_t ~ N(0, sigma_eta^2);   y_t = alpha_t + eps_t, eps_t ~ N(0, v_t)
+ * y [N][T] (NaN = None); v: per-step observation variances, [N][T] with v_stride = T or one shared stream [T] with
+ * v_stride = 0; sv: (phi, mu, sigma_eta) in SvParameters order, [N][3] with sv_stride = 3 or one shared triple with
+ * sv_stride = 0; z [N][T+1] injected normals or NULL (Philox stream (seed, series_offset + n, t, 0));
+ * filt [N][T+1][2] = (m_t, c_t) with record 0 = (mu, sigma_eta^2 / (1 - phi^2)), nullable;
+ * theta [N][T+1] one draw per state, NULL = filter only; status [N] nullable.  opts->flags: DLM_OPT_ASYNC only. */
+int dlm_ar1_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* y, const double* v, int64_t v_stride,
+                       const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
+                       double* filt, double* theta, int32_t* status);
+
 /* Per-series log-likelihood by the prediction-error decomposition,
  *   loglik[n] = sum_t log N(y_t^obs ; f_t^obs, Q_t^obs),
  * i.e. KalmanFilter.conditionalLikelihood (KalmanFilter.scala:138-153) summed over the series (steps with no observed

@@ -120,6 +120,26 @@ def loglik(M, filt, y):
     return float(fn(M.p, M.T, _p(filt["f"]), _p(filt["Q"]), _p(y)))
 
 
+def ar1_filter(y, v, phi, mu, sigma_eta):
+    """FilterAr.filterUnivariate: T+1 records of (m, c, a, r)."""
+    y = np.ascontiguousarray(y, dtype=np.float64); T = y.size
+    v = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (T,)))
+    out = {k: np.empty(T + 1) for k in ("m", "c", "a", "r")}
+    lib().oracle_ar1_filter(T, _p(y), _p(v), ctypes.c_double(phi), ctypes.c_double(mu), ctypes.c_double(sigma_eta),
+                            _p(out["m"]), _p(out["c"]), _p(out["a"]), _p(out["r"]))
+    return out
+
+
+def ar1_backward_sample(filt, phi, z):
+    """FilterAr.univariateSample with injected normals z [T+1]."""
+    T = filt["m"].size - 1
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    theta = np.empty(T + 1)
+    lib().oracle_ar1_backward_sample(T, ctypes.c_double(phi), _p(filt["m"]), _p(filt["c"]), _p(filt["a"]), _p(filt["r"]),
+                                     _p(z), _p(theta))
+    return theta
+
+
 def smoother(M, filt, compat_q1=False):
     d, T = M.d, M.T
     s = np.empty((T + 1, d)); S = np.empty((T + 1, d * d))

@@ -484,6 +484,36 @@ double oracle_loglik(int p, int T, const double *f, const double *Q, const doubl
   return ll;
 }
 
+/* ---- scalar AR(1) state (FilterAr.scala:15-82) -------------------------------------------------
+ * alpha_t = mu + phi (alpha_{t-1} - mu) + eta_t, eta_t ~ N(0, sigma_eta^2);  y_t = alpha_t + eps_t, eps_t ~ N(0, v_t).
+ * filterUnivariate (:34-49): m0 = mu, c0 = sigma_eta^2 / (1 - phi^2); stepUni (:17-32).  Outputs have T+1 records. */
+void oracle_ar1_filter(int T, const double *y /* NaN = None */, const double *v, double phi, double mu,
+                       double sigma_eta, double *m, double *c, double *a, double *r) {
+  m[0] = a[0] = mu;
+  c[0] = r[0] = sigma_eta * sigma_eta / (1.0 - phi * phi);
+  for (int t = 0; t < T; ++t) {
+    const double at = mu + phi * (m[t] - mu);
+    const double rt = phi * phi * c[t] + sigma_eta * sigma_eta;
+    a[t + 1] = at; r[t + 1] = rt;
+    if (y[t] == y[t]) {
+      const double kt = rt / (rt + v[t]);
+      m[t + 1] = at + kt * (y[t] - at);
+      c[t + 1] = kt * v[t];
+    } else { m[t + 1] = at; c[t + 1] = rt; }
+  }
+}
+/* univariateSample / backStepUni (:58-76): theta_T = m_T + sqrt(c_T) z_T;
+ * mean = m_t + (c_t phi / r_{t+1}) (theta_{t+1} - a_{t+1}), cov = c_t - c_t^2 phi^2 / r_{t+1}. */
+void oracle_ar1_backward_sample(int T, double phi, const double *m, const double *c, const double *a,
+                                const double *r, const double *z, double *theta) {
+  theta[T] = m[T] + sqrt(c[T]) * z[T];
+  for (int t = T - 1; t >= 0; --t) {
+    const double mean = m[t] + (c[t] * phi / r[t + 1]) * (theta[t + 1] - a[t + 1]);
+    const double cov = c[t] - (c[t] * c[t]) * (phi * phi) / r[t + 1];
+    theta[t] = mean + sqrt(cov) * z[t];
+  }
+}
+
 static void mvn_draw(int d, const double *mu, const double *cov, const double *z, int factor,
                      double *out, double *w1, double *w2, double *w3) {
   if (factor == 0) {

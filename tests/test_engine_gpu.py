@@ -996,3 +996,40 @@ def test_time_varying_variance_streams(eng, case):
     if d <= 16 and q <= 16:
         with pytest.raises(EngineError):
             eng.svd_filter(mat, p, y)
+
+
+def test_ar1_lane_per_series_golden_and_draws(eng, golden_dir):
+    """dlm_ar1_ffbs_batch (FilterAr.scala:15-82): the reference's ar_dlm_filtered.csv, per-series
+    parameters and variance streams with missing values, draws under injected and Philox normals."""
+    from bayesian_dlms_amd.api import FilterAr, SvParameters
+    obs = np.loadtxt(os.path.join(golden_dir, "ar_dlm.csv"), delimiter=",", skiprows=1)
+    want = np.loadtxt(os.path.join(golden_dir, "ar_dlm_filtered.csv"), delimiter=",", skiprows=1)
+    m, c = FilterAr.filter_univariate(obs[:, 1], 0.5, SvParameters(0.8, 1.0, 0.3), eng)
+    assert eng.last_variant == "ar1-lane" and m.shape == (1, 5001)
+    np.testing.assert_allclose(m[0], want[:, 1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(c[0], want[:, 2], rtol=0, atol=1e-13)
+    # a batch: per-series (phi, mu, sigma), per-series variance streams, missing observations, more series than a block
+    rng = np.random.default_rng(8)
+    N, T = 300, 97
+    sv = np.stack([rng.uniform(-0.95, 0.95, N), rng.standard_normal(N), rng.uniform(0.1, 1.0, N)], axis=1)
+    v = rng.uniform(0.2, 2.0, (N, T))
+    y = rng.standard_normal((N, T)).cumsum(axis=1) * 0.3
+    y[rng.random(y.shape) < 0.1] = np.nan
+    z = rng.standard_normal((N, T + 1))
+    out = eng.ar1_ffbs(y, v, sv, z=z)
+    assert np.all(out["status"] == 0)
+    for n in (0, 63, 64, 255, 256, 299):
+        f = oracle.ar1_filter(y[n], v[n], *sv[n])
+        np.testing.assert_allclose(out["filt"][n, :, 0], f["m"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(out["filt"][n, :, 1], f["c"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(out["theta"][n], oracle.ar1_backward_sample(f, sv[n, 0], z[n]), rtol=1e-11, atol=1e-12)
+    # Philox stream (seed, series_offset + n, t, 0), identical for a shard starting at series 100
+    o1 = eng.ar1_ffbs(y, v, sv, seed=5, want_filt=False)
+    o2 = eng.ar1_ffbs(y[100:], v[100:], sv[100:], seed=5, series_offset=100, want_filt=False)
+    np.testing.assert_array_equal(o1["theta"][100:], o2["theta"])
+    zz = oracle.normals(5, 7, T + 1, 1).reshape(-1)
+    f7 = oracle.ar1_filter(y[7], v[7], *sv[7])
+    np.testing.assert_allclose(o1["theta"][7], oracle.ar1_backward_sample(f7, sv[7, 0], zz), rtol=1e-11, atol=1e-12)
+    # a non-stationary phi is flagged, not fatal
+    bad = eng.ar1_ffbs(y[:2], 0.5, np.array([[1.2, 0.0, 0.3], [0.5, 0.0, 0.3]]))
+    assert bad["status"][0] & _lib.ST_NOT_PD and bad["status"][1] == 0

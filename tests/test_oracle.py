@@ -360,3 +360,18 @@ def test_loglik_matches_scipy_and_scalar_closed_form():
         mu = f["f"][t + 1][ob]
         want += norm(mu[0], np.sqrt(Q[0, 0])).logpdf(y[t][ob][0]) if ob.sum() == 1 else multivariate_normal(mu, Q).logpdf(y[t][ob])
     assert oracle.loglik(M, f, y) == pytest.approx(want, rel=1e-12, abs=1e-10)
+
+
+def test_ar1_filter_reproduces_reference_csv(golden_dir):
+    """FilterAr.filterUnivariate on examples/data/ar_dlm.csv with SvParameters(0.8, 1.0, 0.3), v = 0.5
+    (examples/src/main/scala/dlm/ar.scala:47-61) reproduces ar_dlm_filtered.csv (5001 rows)."""
+    obs = np.loadtxt(os.path.join(golden_dir, "ar_dlm.csv"), delimiter=",", skiprows=1)
+    want = np.loadtxt(os.path.join(golden_dir, "ar_dlm_filtered.csv"), delimiter=",", skiprows=1)
+    f = oracle.ar1_filter(obs[:, 1], 0.5, 0.8, 1.0, 0.3)
+    assert want.shape == (5001, 3)
+    np.testing.assert_allclose(f["m"], want[:, 1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(f["c"], want[:, 2], rtol=0, atol=1e-13)
+    # backward sampler: with z = 0 it is the conditional-mean recursion; check one step by hand
+    th = oracle.ar1_backward_sample(f, 0.8, np.zeros(5002 - 1))
+    t = 4000
+    assert th[t] == pytest.approx(f["m"][t] + f["c"][t] * 0.8 / f["r"][t + 1] * (th[t + 1] - f["a"][t + 1]), rel=1e-14)

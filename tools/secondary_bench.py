@@ -61,6 +61,16 @@ def main():
         dt = timeit(lambda: eng.loglik(mat, p, y))
         print(json.dumps({"config": "log-likelihood (prediction-error decomposition), d=13, N=10000, T=1000, no record output",
                           "variant": eng.last_variant, "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "ar1" in which:
+        N, T = 100000, 1000
+        rng = np.random.default_rng(3)
+        y = torch.as_tensor(rng.standard_normal((N, T)).cumsum(axis=1) * 0.1, device=dev)
+        v = torch.as_tensor(rng.uniform(0.2, 2.0, (N, T)), device=dev)
+        sv = torch.as_tensor(np.stack([rng.uniform(0.5, 0.95, N), rng.standard_normal(N), rng.uniform(0.1, 0.5, N)], axis=1), device=dev)
+        dt = timeit(lambda: eng.ar1_ffbs(y, v, sv, seed=1, want_filt=False))
+        print(json.dumps({"config": "scalar AR(1) FFBS (FilterAr.ffbs), one lane per series, N=100000, T=1000, per-step v_t",
+                          "variant": eng.last_variant, "ms": dt * 1e3, "series_steps_per_s": N * T / dt,
+                          "GBps_algorithmic": N * T * (8 * 2 + 16 * 2 + 8) / dt / 1e9}))
     if "c5" in which:
         mod, p = seasonal_c2(); N, T = 10000, 200
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
