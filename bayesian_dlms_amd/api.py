@@ -255,3 +255,20 @@ class FilterAr:
         out = engine.ar1_ffbs(np.atleast_2d(np.asarray(ys, dtype=np.float64)), vs, FilterAr._sv(p), z=z, seed=seed,
                               series_offset=series_offset, want_filt=False)
         return np.asarray(out["theta"])
+
+
+class FilterOu:
+    """FilterOu (FilterOu.scala:7-79): the Ornstein-Uhlenbeck state on an irregular grid `times` [T] shared by the batch;
+    p.phi > 0 is the mean-reversion rate.  Literal reference behaviour is kept: c0 = sigma^2 and a first dt of 0."""
+
+    @staticmethod
+    def filter_univariate(times, ys, vs, p, engine: Engine):
+        out = engine.ar1_ffbs(np.atleast_2d(np.asarray(ys, dtype=np.float64)), vs, FilterAr._sv(p), want_theta=False, times=times)
+        f = np.asarray(out["filt"])
+        return f[..., 0], f[..., 1]
+
+    @staticmethod
+    def ffbs(p, times, ys, vs, engine: Engine, *, seed: int = 0, series_offset: int = 0, z=None):
+        out = engine.ar1_ffbs(np.atleast_2d(np.asarray(ys, dtype=np.float64)), vs, FilterAr._sv(p), z=z, seed=seed,
+                              series_offset=series_offset, want_filt=False, times=times)
+        return np.asarray(out["theta"])

@@ -367,9 +367,26 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
+static int ar1_common(dlm_engine* e, int32_t N, int32_t T, const double* times, bool ou, const double* y, const double* v,
+                      int64_t v_stride, const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
+                      double* filt, double* theta, int32_t* status);
+
 int dlm_ar1_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* y, const double* v, int64_t v_stride,
                        const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
                        double* filt, double* theta, int32_t* status) {
+  return ar1_common(e, N, T, nullptr, false, y, v, v_stride, sv, sv_stride, z, opts, filt, theta, status);
+}
+
+int dlm_ou_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* times, const double* y, const double* v,
+                      int64_t v_stride, const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
+                      double* filt, double* theta, int32_t* status) {
+  if (e && !times) return fail(e, DLM_ERR_ARG, "times are required");
+  return ar1_common(e, N, T, times, true, y, v, v_stride, sv, sv_stride, z, opts, filt, theta, status);
+}
+
+static int ar1_common(dlm_engine* e, int32_t N, int32_t T, const double* times, bool ou, const double* y, const double* v,
+                      int64_t v_stride, const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
+                      double* filt, double* theta, int32_t* status) {
   if (!e) return DLM_ERR_ARG;
   if (!opts || (opts->mem != DLM_MEM_DEVICE && opts->mem != DLM_MEM_HOST)) return fail(e, DLM_ERR_ARG, "opts");
   if (N < 1 || T < 1) return fail(e, DLM_ERR_ARG, "N and T must be >= 1 (the reference throws on empty input, FilterAr.scala:40)");
@@ -377,9 +394,10 @@ int dlm_ar1_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* y, con
   if (!filt && !theta) return fail(e, DLM_ERR_ARG, "nothing to compute: filt and theta are both NULL");
   if ((v_stride != 0 && v_stride != T) || (sv_stride != 0 && sv_stride != 3)) return fail(e, DLM_ERR_ARG, "v_stride must be 0 or T, sv_stride 0 or 3");
   HIP_TRY(e, hipSetDevice(e->device));
-  struct { const double *y, *v, *sv, *z; double *filt, *theta; int* status; } k{};
+  struct { const double *times, *y, *v, *sv, *z; double *filt, *theta; int* status; } k{};
   const size_t n = N, t = T;
   Stager st(e, opts->mem == DLM_MEM_HOST);
+  st.in(&k.times, times, ou ? t : 0);
   st.in(&k.y, y, n * t);
   st.in(&k.v, v, v_stride ? n * t : t);
   st.in(&k.sv, sv, sv_stride ? n * 3 : 3);
@@ -395,8 +413,8 @@ int dlm_ar1_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* y, con
     if ((rc = ensure_side(e, ks))) return rc;
     fws = e->side;
   }
-  e->variant = "ar1-lane";
-  HIP_TRY(e, dlm::launch_ar1_ffbs(N, T, k.y, k.v, v_stride, k.sv, sv_stride, k.z, opts->seed, opts->series_offset, fws,
+  e->variant = ou ? "ou-lane" : "ar1-lane";
+  HIP_TRY(e, dlm::launch_ar1_ffbs(N, T, k.times, k.y, k.v, v_stride, k.sv, sv_stride, k.z, opts->seed, opts->series_offset, fws,
                                   k.theta, k.status, e->stream));
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }

@@ -81,9 +81,10 @@ hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s);
 hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s);
 
 // ---- scalar AR(1) FFBS, one lane per series (FilterAr.scala:15-82), dlm_ar1.hip -----------------
-hipError_t launch_ar1_ffbs(int N, int T, const double* y, const double* v, long long v_stride, const double* sv,
-                           long long sv_stride, const double* z, unsigned long long seed, unsigned long long series_offset,
-                           double* filt, double* theta, int* status, hipStream_t s);
+// times != nullptr: the Ornstein-Uhlenbeck variant on that (shared, irregular) time grid (FilterOu.scala:7-79)
+hipError_t launch_ar1_ffbs(int N, int T, const double* times, const double* y, const double* v, long long v_stride,
+                           const double* sv, long long sv_stride, const double* z, unsigned long long seed,
+                           unsigned long long series_offset, double* filt, double* theta, int* status, hipStream_t s);
 
 // ---- counter-based normals (same stream as oracle_normal in oracle/dlm_oracle.c) ------
 __device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {

@@ -197,9 +197,10 @@ class Engine:
         self._check(self.lib.dlm_loglik_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(ll), be.ptr(status)))
         return {"loglik": ll, "status": status}
 
-    def ar1_ffbs(self, y, v, sv, *, z=None, seed=0, series_offset=0, want_filt=True, want_theta=True):
+    def ar1_ffbs(self, y, v, sv, *, z=None, seed=0, series_offset=0, want_filt=True, want_theta=True, times=None):
         """Scalar AR(1) FFBS, one lane per series (dlm_ar1_ffbs_batch; FilterAr.scala:15-82).  y [N][T] (NaN = missing),
-        v [N][T] or [T] per-step observation variances, sv [N][3] or [3] = (phi, mu, sigma_eta)."""
+        v [N][T] or [T] per-step observation variances, sv [N][3] or [3] = (phi, mu, sigma_eta).  With `times` [T] it is
+        the Ornstein-Uhlenbeck variant on that grid (dlm_ou_ffbs_batch; FilterOu.scala:7-79)."""
         be = self._backend(y)
         N, T = int(y.shape[0]), int(y.shape[1])
         yb = be.put(y).reshape(N, T)
@@ -214,8 +215,13 @@ class Engine:
         theta = be.empty((N, T + 1)) if want_theta else None
         status = be.empty((N,), np.int32)
         op = _lib.Options(0, be.mem, seed, series_offset)
-        self._check(self.lib.dlm_ar1_ffbs_batch(self.h, N, T, be.ptr(yb), be.ptr(vb), v_stride, be.ptr(sb), sv_stride,
-                                                be.ptr(zb), op, be.ptr(filt), be.ptr(theta), be.ptr(status)))
+        if times is None:
+            self._check(self.lib.dlm_ar1_ffbs_batch(self.h, N, T, be.ptr(yb), be.ptr(vb), v_stride, be.ptr(sb), sv_stride,
+                                                    be.ptr(zb), op, be.ptr(filt), be.ptr(theta), be.ptr(status)))
+        else:
+            tb = be.put(np.asarray(times, dtype=np.float64))
+            self._check(self.lib.dlm_ou_ffbs_batch(self.h, N, T, be.ptr(tb), be.ptr(yb), be.ptr(vb), v_stride, be.ptr(sb),
+                                                   sv_stride, be.ptr(zb), op, be.ptr(filt), be.ptr(theta), be.ptr(status)))
         return {"filt": filt, "theta": theta, "status": status}
 
     def smooth(self, mat, params, filt, *, flags=0):

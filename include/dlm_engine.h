@@ -140,6 +140,14 @@ int dlm_ar1_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* y, con
                        const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
                        double* filt, double* theta, int32_t* status);
 
+/* The Ornstein-Uhlenbeck variant of the above on an irregular time grid: FilterOu.filterUnivariate / univariateSample /
+ * ffbs (FilterOu.scala:7-79).  times [T] observation times shared by the batch; sv = (phi, mu, sigma_eta) with phi > 0
+ * the mean-reversion rate.  Literal reference behaviour: c0 = sigma * sigma / phi * phi (= sigma^2) and the initial
+ * state sits at the first observation time (first dt = 0).  Everything else as dlm_ar1_ffbs_batch. */
+int dlm_ou_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* times, const double* y, const double* v,
+                      int64_t v_stride, const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
+                      double* filt, double* theta, int32_t* status);
+
 /* Per-series log-likelihood by the prediction-error decomposition,
  *   loglik[n] = sum_t log N(y_t^obs ; f_t^obs, Q_t^obs),
  * i.e. KalmanFilter.conditionalLikelihood (KalmanFilter.scala:138-153) summed over the series (steps with no observed

@@ -140,6 +140,27 @@ def ar1_backward_sample(filt, phi, z):
     return theta
 
 
+def ou_filter(times, y, v, phi, mu, sigma_eta):
+    """FilterOu.filterUnivariate (literal c0 and initial time): T+1 records of (m, c, a, r)."""
+    y = np.ascontiguousarray(y, dtype=np.float64); T = y.size
+    times = np.ascontiguousarray(times, dtype=np.float64)
+    v = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (T,)))
+    out = {k: np.empty(T + 1) for k in ("m", "c", "a", "r")}
+    lib().oracle_ou_filter(T, _p(times), _p(y), _p(v), ctypes.c_double(phi), ctypes.c_double(mu), ctypes.c_double(sigma_eta),
+                           _p(out["m"]), _p(out["c"]), _p(out["a"]), _p(out["r"]))
+    return out
+
+
+def ou_backward_sample(times, filt, phi, z):
+    T = filt["m"].size - 1
+    times = np.ascontiguousarray(times, dtype=np.float64)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    theta = np.empty(T + 1)
+    lib().oracle_ou_backward_sample(T, _p(times), ctypes.c_double(phi), _p(filt["m"]), _p(filt["c"]), _p(filt["a"]),
+                                    _p(filt["r"]), _p(z), _p(theta))
+    return theta
+
+
 def smoother(M, filt, compat_q1=False):
     d, T = M.d, M.T
     s = np.empty((T + 1, d)); S = np.empty((T + 1, d * d))

@@ -509,7 +509,45 @@ void oracle_ar1_backward_sample(int T, double phi, const double *m, const double
   theta[T] = m[T] + sqrt(c[T]) * z[T];
   for (int t = T - 1; t >= 0; --t) {
     const double mean = m[t] + (c[t] * phi / r[t + 1]) * (theta[t + 1] - a[t + 1]);
-    const double cov = c[t] - (c[t] * c[t]) * (phi * phi) / r[t + 1];
+    double cov = c[t] - (c[t] * c[t]) * (phi * phi) / r[t + 1];
+    if (cov < 0.0) cov = 0.0;
+    theta[t] = mean + sqrt(cov) * z[t];
+  }
+}
+
+/* ---- scalar Ornstein-Uhlenbeck state on an irregular grid (FilterOu.scala:7-79) -----------------------------------
+ * stepUni (:7-27): dt = t - st.time; variance = sigma^2 (1 - exp(-2 phi dt)) / (2 phi);
+ *   a = mu + exp(-phi dt) (m - mu);  r = exp(-2 phi dt) c + variance;  update as FilterAr.
+ * filterUnivariate (:34-46), LITERALLY: m0 = mu, c0 = sigma * sigma / phi * phi (= sigma^2 by operator precedence, the
+ * stationary variance sigma^2 / (2 phi) was presumably meant), and the initial state carries the time of the FIRST
+ * observation, so the first step has dt = 0.  parity unpinned: the reference holds no fixture for this filter. */
+void oracle_ou_filter(int T, const double *times, const double *y, const double *v, double phi, double mu,
+                      double sigma_eta, double *m, double *c, double *a, double *r) {
+  m[0] = a[0] = mu;
+  c[0] = r[0] = sigma_eta * sigma_eta / phi * phi;
+  for (int t = 0; t < T; ++t) {
+    const double dt = times[t] - (t == 0 ? times[0] : times[t - 1]);
+    const double variance = (pow(sigma_eta, 2) * (1 - exp(-2 * phi * dt))) / (2 * phi);
+    const double at = mu + exp(-phi * dt) * (m[t] - mu);
+    const double rt = exp(-2 * phi * dt) * c[t] + variance;
+    a[t + 1] = at; r[t + 1] = rt;
+    if (y[t] == y[t]) {
+      const double kt = rt / (rt + v[t]);
+      m[t + 1] = at + kt * (y[t] - at);
+      c[t + 1] = kt * v[t];
+    } else { m[t + 1] = at; c[t + 1] = rt; }
+  }
+}
+/* univariateSample / backStepUni (:48-71): phi(dt) = exp(-phi dt) with dt = ss.time - fs.time */
+void oracle_ou_backward_sample(int T, const double *times, double phi, const double *m, const double *c,
+                               const double *a, const double *r, const double *z, double *theta) {
+  theta[T] = m[T] + sqrt(c[T]) * z[T];
+  for (int t = T - 1; t >= 0; --t) {
+    const double dt = times[t] - (t == 0 ? times[0] : times[t - 1]);   /* time(record t+1) - time(record t) */
+    const double ph = exp(-phi * dt);
+    const double mean = m[t] + (c[t] * ph / r[t + 1]) * (theta[t + 1] - a[t + 1]);
+    double cov = c[t] - (pow(c[t], 2) * pow(ph, 2)) / r[t + 1];
+    if (cov < 0.0) cov = 0.0;   /* dt = 0 (the first step, always): c - c^2/c at rounding level; the reference would draw NaN */
     theta[t] = mean + sqrt(cov) * z[t];
   }
 }

@@ -1033,3 +1033,23 @@ def test_ar1_lane_per_series_golden_and_draws(eng, golden_dir):
     # a non-stationary phi is flagged, not fatal
     bad = eng.ar1_ffbs(y[:2], 0.5, np.array([[1.2, 0.0, 0.3], [0.5, 0.0, 0.3]]))
     assert bad["status"][0] & _lib.ST_NOT_PD and bad["status"][1] == 0
+
+
+def test_ou_lane_per_series_irregular_grid(eng):
+    """dlm_ou_ffbs_batch (FilterOu.scala:7-79): irregular grid, per-series parameters, missing values, draws."""
+    rng = np.random.default_rng(9)
+    N, T = 130, 61
+    times = np.cumsum(rng.choice([0.5, 1.0, 2.5, 4.0], T))
+    sv = np.stack([rng.uniform(0.05, 1.5, N), rng.standard_normal(N), rng.uniform(0.1, 1.0, N)], axis=1)
+    v = rng.uniform(0.2, 2.0, T)                      # one shared variance stream
+    y = rng.standard_normal((N, T)).cumsum(axis=1) * 0.3
+    y[rng.random(y.shape) < 0.1] = np.nan
+    z = rng.standard_normal((N, T + 1))
+    out = eng.ar1_ffbs(y, v, sv, z=z, times=times)
+    assert eng.last_variant == "ou-lane" and np.all(out["status"] == 0)
+    for n in (0, 64, 129):
+        f = oracle.ou_filter(times, y[n], v, *sv[n])
+        np.testing.assert_allclose(out["filt"][n, :, 0], f["m"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(out["filt"][n, :, 1], f["c"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(out["theta"][n], oracle.ou_backward_sample(times, f, sv[n, 0], z[n]), rtol=1e-10, atol=1e-11)
+    assert out["filt"][5, 0, 1] == pytest.approx(sv[5, 2] ** 2)   # the literal c0 = sigma * sigma / phi * phi

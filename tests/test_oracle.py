@@ -375,3 +375,25 @@ def test_ar1_filter_reproduces_reference_csv(golden_dir):
     th = oracle.ar1_backward_sample(f, 0.8, np.zeros(5002 - 1))
     t = 4000
     assert th[t] == pytest.approx(f["m"][t] + f["c"][t] * 0.8 / f["r"][t + 1] * (th[t + 1] - f["a"][t + 1]), rel=1e-14)
+
+
+def test_ou_filter_closed_forms():
+    """oracle_ou_filter follows FilterOu.stepUni literally: dt-dependent AR coefficient and innovation variance, the
+    literal c0 = sigma^2 and first dt = 0; on a unit grid it equals the AR(1) filter with phi' = exp(-phi),
+    sigma'^2 = sigma^2 (1 - exp(-2 phi)) / (2 phi) from the second record on."""
+    rng = np.random.default_rng(2)
+    T = 40
+    y = rng.standard_normal(T).cumsum() * 0.2
+    y[[3, 17]] = np.nan
+    phi, mu, sig = 0.3, 0.5, 0.4
+    f = oracle.ou_filter(np.arange(1.0, T + 1), y, 0.7, phi, mu, sig)
+    assert f["c"][0] == pytest.approx(sig * sig) and f["r"][1] == pytest.approx(sig * sig)   # first dt = 0
+    ph, s2 = np.exp(-phi), sig * sig * (1 - np.exp(-2 * phi)) / (2 * phi)
+    m, c = f["m"][1], f["c"][1]
+    for t in range(1, T):
+        a, r = mu + ph * (m - mu), ph * ph * c + s2
+        if np.isnan(y[t]):
+            m, c = a, r
+        else:
+            k = r / (r + 0.7); m, c = a + k * (y[t] - a), k * 0.7
+        assert f["m"][t + 1] == pytest.approx(m, rel=1e-13) and f["c"][t + 1] == pytest.approx(c, rel=1e-13)
