@@ -367,6 +367,28 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
+int dlm_dinvgamma_step_batch(dlm_engine* e, int32_t d, int32_t p, int32_t N, const double* stats, double alpha_v,
+                             double beta_v, double alpha_w, double beta_w, uint64_t iteration, const dlm_options* opts,
+                             double* V_out, double* W_out) {
+  if (!e) return DLM_ERR_ARG;
+  if (!opts || (opts->mem != DLM_MEM_DEVICE && opts->mem != DLM_MEM_HOST)) return fail(e, DLM_ERR_ARG, "opts");
+  if (d < 1 || p < 1 || N < 1 || !stats || !V_out || !W_out) return fail(e, DLM_ERR_ARG, "d, p, N >= 1; stats, V_out, W_out required");
+  if (!(alpha_v > 0.0 && beta_v > 0.0 && alpha_w > 0.0 && beta_w > 0.0)) return fail(e, DLM_ERR_ARG, "InverseGamma priors need positive shape and scale");
+  HIP_TRY(e, hipSetDevice(e->device));
+  struct { const double* stats; double *V, *W; } k{};
+  const size_t n = N, L = 2 * (size_t)p + d + 1;
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  st.in(&k.stats, stats, n * L);
+  st.out(&k.V, V_out, n * p * p);
+  st.out(&k.W, W_out, n * d * d);
+  int rc;
+  if ((rc = st.commit())) return rc;
+  e->variant = "dinvgamma-step";
+  HIP_TRY(e, dlm::launch_dinvgamma_step(d, p, N, k.stats, alpha_v, beta_v, alpha_w, beta_w, opts->seed, opts->series_offset,
+                                        iteration, k.V, k.W, e->stream));
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
 static int ar1_common(dlm_engine* e, int32_t N, int32_t T, const double* times, bool ou, const double* y, const double* v,
                       int64_t v_stride, const double* sv, int64_t sv_stride, const double* z, const dlm_options* opts,
                       double* filt, double* theta, int32_t* status);

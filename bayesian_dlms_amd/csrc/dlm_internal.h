@@ -86,6 +86,11 @@ hipError_t launch_ar1_ffbs(int N, int T, const double* times, const double* y, c
                            const double* sv, long long sv_stride, const double* z, unsigned long long seed,
                            unsigned long long series_offset, double* filt, double* theta, int* status, hipStream_t s);
 
+// ---- d-Inverse-Gamma conjugate draws on the device (Gibbs.scala:23-78), dlm_gibbs.hip --------------
+hipError_t launch_dinvgamma_step(int d, int p, int N, const double* stats, double av, double bv, double aw, double bw,
+                                 unsigned long long seed, unsigned long long series_offset, unsigned long long iteration,
+                                 double* Vout, double* Wout, hipStream_t s);
+
 // ---- counter-based normals (same stream as oracle_normal in oracle/dlm_oracle.c) ------
 __device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
 #pragma unroll

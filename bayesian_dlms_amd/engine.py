@@ -224,6 +224,21 @@ class Engine:
                                                    sv_stride, be.ptr(zb), op, be.ptr(filt), be.ptr(theta), be.ptr(status)))
         return {"filt": filt, "theta": theta, "status": status}
 
+    def dinvgamma_step(self, d, p, stats, prior_v, prior_w, *, iteration, seed=0, series_offset=0):
+        """GibbsSampling.dinvGammaStep on the device (dlm_dinvgamma_step_batch): stats [N][2p + d + 1] from an FFBS call
+        -> (V [N][p*p], W [N][d*d]) dense diagonal matrices, ready as the next call's per-series parameters.
+        prior_v / prior_w: (shape, scale) pairs or objects with .shape / .scale."""
+        be = self._backend(stats)
+        N = int(stats.shape[0])
+        sb = be.put(stats)
+        av, bv = (prior_v.shape, prior_v.scale) if hasattr(prior_v, "scale") else prior_v
+        aw, bw = (prior_w.shape, prior_w.scale) if hasattr(prior_w, "scale") else prior_w
+        V = be.empty((N, p * p)); W = be.empty((N, d * d))
+        op = _lib.Options(0, be.mem, seed, series_offset)
+        self._check(self.lib.dlm_dinvgamma_step_batch(self.h, d, p, N, be.ptr(sb), float(av), float(bv), float(aw), float(bw),
+                                                      int(iteration), op, be.ptr(V), be.ptr(W)))
+        return V, W
+
     def smooth(self, mat, params, filt, *, flags=0):
         be = self._backend(filt)
         N = int(filt.shape[0]); d, T = mat.d, mat.T

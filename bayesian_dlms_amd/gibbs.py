@@ -114,6 +114,35 @@ class GibbsSampling:
                       series_offset, allreduce, keep_theta, ffbs, wishart=False, simsmooth=simulation_smoother)
 
 
+def gibbs_dinvgamma_device(mod: Dlm, prior_v: InverseGamma, prior_w: InverseGamma, init_params: DlmParameters, times, y,
+                           engine, *, n_iter: int, seed: int = 0, series_offset: int = 0, simulation_smoother: bool = True,
+                           on_iteration: Optional[Callable] = None):
+    """Per-series d-Inverse-Gamma Gibbs that never leaves the GPU: FFBS + statistics (dlm_ffbs_batch) and the conjugate
+    draws (dlm_dinvgamma_step_batch) alternate on device-resident parameter arrays; nothing crosses PCIe per iteration.
+    `y` is a device tensor [N][T][p]; every series starts from `init_params`.  Returns (V [N][p*p], W [N][d*d]) of the last
+    iteration (device tensors); `on_iteration(it, V, W, stats)` may copy out whatever chain summaries are wanted.
+    The draws use the Philox stream (seed, global series index, iteration, component), so a sharded run reproduces the
+    single-GPU run; they are the same distributions as GibbsSampling.sample draws on the host, not the same numbers."""
+    import torch
+    N = int(y.shape[0])
+    mat = materialise(mod, times)
+    d, p = mat.d, mat.p
+    dev = y.device
+    flags = _lib.OPT_FFBS_SIMSMOOTH if simulation_smoother else 0
+    cmf = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64).T).reshape(-1), device=dev)
+    V = cmf(init_params.v).repeat(N, 1).contiguous(); W = cmf(init_params.w).repeat(N, 1).contiguous()
+    m0 = torch.as_tensor(np.asarray(init_params.m0, dtype=np.float64), device=dev)
+    C0 = cmf(init_params.c0)
+    for it in range(n_iter):
+        packed = (V.reshape(-1), p * p, W.reshape(-1), d * d, m0, 0, C0, 0)
+        out = engine.ffbs(mat, packed, y, seed=seed * 1000003 + it, series_offset=series_offset, flags=flags,
+                          want_theta=False, want_stats=True)
+        V, W = engine.dinvgamma_step(d, p, out["stats"], prior_v, prior_w, iteration=it, seed=seed, series_offset=series_offset)
+        if on_iteration is not None:
+            on_iteration(it, V, W, out["stats"])
+    return V, W
+
+
 class GibbsWishart:
     @staticmethod
     def sample(mod: Dlm, prior_v: InverseGamma, prior_w: InverseWishart, init_params, times, y, engine,

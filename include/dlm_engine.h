@@ -127,6 +127,17 @@ int dlm_filter_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_param
 int dlm_smooth_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
                      const double *filt, const dlm_options *opts, double *smooth, int32_t *status);
 
+/* GibbsSampling.dinvGammaStep on the device (Gibbs.scala:23-78, :134-151) for per-series parameters: from the
+ * statistics [N][2p + d + 1] = [ssy | n | ss | T] of an FFBS call (without DLM_OPT_STATS_OUTER) draw
+ *   V_jj ~ InverseGamma(alpha_v + n_j / 2, beta_v + ssy_j / 2),   W_ii ~ InverseGamma(alpha_w + T / 2, beta_w + ss_i / 2)
+ * and write the dense diagonal matrices V_out [N][p*p], W_out [N][d*d] -- directly usable as the next call's
+ * per-series parameters (v_stride = p*p, w_stride = d*d), so that a Gibbs iteration never leaves the GPU.
+ * Marsaglia-Tsang Gamma draws on the Philox stream (opts->seed, opts->series_offset + n, iteration, component):
+ * reproducible and shard-invariant; the reference's generator cannot be seeded, only the distribution compares. */
+int dlm_dinvgamma_step_batch(dlm_engine* e, int32_t d, int32_t p, int32_t N, const double* stats, double alpha_v,
+                             double beta_v, double alpha_w, double beta_w, uint64_t iteration, const dlm_options* opts,
+                             double* V_out, double* W_out);
+
 /* Scalar AR(1) state-space FFBS, one GPU lane per series: FilterAr.filterUnivariate / univariateSample / ffbs
  * (FilterAr.scala:15-82), the filter of the stochastic-volatility samplers (StochasticVolatility.scala:142-162,
  * FactorSv.scala:415-512):

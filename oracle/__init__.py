@@ -224,6 +224,16 @@ def svd_backward_sample(M, W, sf, z, literal_q9=True):
     return {"theta": theta, "h": h, "dh": dh, "uh": uh}
 
 
+def dinvgamma_step(d, p, stats, av, bv, aw, bw, seed, series, iteration):
+    """The engine's device d-Inverse-Gamma step for one series, restated on the CPU: (diag V, diag W)."""
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    v = np.empty(p); w = np.empty(d)
+    lib().oracle_dinvgamma_step(d, p, _p(stats), ctypes.c_double(av), ctypes.c_double(bv), ctypes.c_double(aw),
+                                ctypes.c_double(bw), ctypes.c_uint64(seed), ctypes.c_uint64(series),
+                                ctypes.c_uint64(iteration), _p(v), _p(w))
+    return v, w
+
+
 def normals(seed, series, T1, d):
     z = np.empty((T1, d))
     lib().oracle_normals(ctypes.c_uint64(seed), ctypes.c_uint64(series), T1, d, _p(z))

@@ -903,6 +903,42 @@ double oracle_normal(uint64_t seed, uint64_t series, uint32_t t, uint32_t i) {
   return (i & 1) ? r * sin(ang) : r * cos(ang);
 }
 
+/* The engine's d-Inverse-Gamma step (bayesian_dlms_amd/csrc/dlm_gibbs.hip), restated: Marsaglia-Tsang Gamma(a, 1) on
+ * Philox draws keyed (seed, series, iteration, component, attempt); value = rate / gamma, i.e.
+ * InverseGamma(shape, rate).draw = 1 / Gamma(shape, 1 / rate).draw (InverseGamma.scala:14).  The reference's own
+ * generator cannot be seeded: this pins the engine's stream, the distribution is checked separately. */
+static void gibbs_rand(uint64_t seed, uint64_t series, uint64_t iteration, uint32_t comp, uint32_t attempt,
+                       uint32_t which, double *u1, double *u2) {
+  uint32_t c[4] = {(uint32_t)series, (uint32_t)(series >> 32), (uint32_t)iteration, comp * 2048u + attempt * 2u + which};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x47494242u);
+  *u1 = ((double)c[0] * 4294967296.0 + (double)c[1] + 1.0) * (1.0 / 18446744073709551616.0);
+  *u2 = ((double)c[2] * 4294967296.0 + (double)c[3]) * (1.0 / 18446744073709551616.0);
+}
+double oracle_gamma_unit(double a, uint64_t seed, uint64_t series, uint64_t iteration, uint32_t comp) {
+  double boost = 1.0, u1, u2, w1, w2;
+  if (a < 1.0) { gibbs_rand(seed, series, iteration, comp, 1023u, 0u, &u1, &u2); boost = pow(u1, 1.0 / a); a += 1.0; }
+  const double dd = a - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+  for (uint32_t k = 0; k < 1023u; ++k) {
+    gibbs_rand(seed, series, iteration, comp, k, 0u, &u1, &u2);
+    const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+    double v = 1.0 + cc * x;
+    if (v <= 0.0) continue;
+    v = v * v * v;
+    gibbs_rand(seed, series, iteration, comp, k, 1u, &w1, &w2);
+    if (log(w1) < 0.5 * x * x + dd - dd * v + dd * log(v)) return dd * v * boost;
+  }
+  return dd * boost;
+}
+/* dinvGammaStep for one series (Gibbs.scala:41-48, :72-77): stats = [ssy (p) | n (p) | ss (d) | T]; vdiag [p], wdiag [d] */
+void oracle_dinvgamma_step(int d, int p, const double *stats, double av, double bv, double aw, double bw, uint64_t seed,
+                           uint64_t series, uint64_t iteration, double *vdiag, double *wdiag) {
+  const int L = 2 * p + d + 1;
+  for (int j = 0; j < p; ++j)
+    vdiag[j] = (bv + 0.5 * stats[j]) / oracle_gamma_unit(av + 0.5 * stats[p + j], seed, series, iteration, (uint32_t)j);
+  for (int i = 0; i < d; ++i)
+    wdiag[i] = (bw + 0.5 * stats[2 * p + i]) / oracle_gamma_unit(aw + 0.5 * stats[L - 1], seed, series, iteration, (uint32_t)(p + i));
+}
+
 void oracle_normals(uint64_t seed, uint64_t series, int T1, int d, double *z) {
   for (int t = 0; t < T1; ++t)
     for (int i = 0; i < d; ++i) z[(size_t)t * d + i] = oracle_normal(seed, series, (uint32_t)t, (uint32_t)i);

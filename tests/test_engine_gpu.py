@@ -1053,3 +1053,45 @@ def test_ou_lane_per_series_irregular_grid(eng):
         np.testing.assert_allclose(out["filt"][n, :, 1], f["c"], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(out["theta"][n], oracle.ou_backward_sample(times, f, sv[n, 0], z[n]), rtol=1e-10, atol=1e-11)
     assert out["filt"][5, 0, 1] == pytest.approx(sv[5, 2] ** 2)   # the literal c0 = sigma * sigma / phi * phi
+
+
+def test_device_dinvgamma_step_stream_distribution_and_gibbs(eng):
+    """dlm_dinvgamma_step_batch (Gibbs.scala:23-78): (i) equals the oracle's restatement of the same Philox /
+    Marsaglia-Tsang stream, (ii) the draws follow InverseGamma(shape, scale) (KS test against scipy), (iii) the
+    device-resident Gibbs loop recovers the variances of a local-level model."""
+    import torch
+    from scipy import stats as sps
+    from bayesian_dlms_amd.gibbs import InverseGamma, gibbs_dinvgamma_device
+    rng = np.random.default_rng(12)
+    d, p_, N = 3, 2, 4000
+    st = np.empty((N, 2 * p_ + d + 1))
+    st[:, :p_] = rng.uniform(5, 50, (N, p_)); st[:, p_:2 * p_] = rng.integers(10, 60, (N, p_))
+    st[:, 2 * p_:2 * p_ + d] = rng.uniform(1, 30, (N, d)); st[:, -1] = 55
+    V, W = eng.dinvgamma_step(d, p_, st, (2.0, 3.0), (0.4, 0.5), iteration=7, seed=11, series_offset=100)
+    assert eng.last_variant == "dinvgamma-step"
+    V = np.asarray(V).reshape(N, p_, p_); W = np.asarray(W).reshape(N, d, d)
+    assert np.all(V[:, 0, 1] == 0) and np.all(W[:, 2, 0] == 0)
+    for n in (0, 17, 3999):
+        v, w = oracle.dinvgamma_step(d, p_, st[n], 2.0, 3.0, 0.4, 0.5, 11, 100 + n, 7)
+        np.testing.assert_allclose(np.diag(V[n]), v, rtol=1e-12)
+        np.testing.assert_allclose(np.diag(W[n]), w, rtol=1e-12)
+    # distribution: identical statistics for every series -> N iid draws per component
+    st2 = np.tile(st[0], (N, 1))
+    V2, W2 = eng.dinvgamma_step(d, p_, st2, (2.0, 3.0), (0.4, 0.5), iteration=1, seed=3)
+    V2 = np.asarray(V2).reshape(N, p_, p_); W2 = np.asarray(W2).reshape(N, d, d)
+    ks_v = sps.kstest(V2[:, 1, 1], sps.invgamma(2.0 + 0.5 * st[0, p_ + 1], scale=3.0 + 0.5 * st[0, 1]).cdf)
+    ks_w = sps.kstest(W2[:, 0, 0], sps.invgamma(0.4 + 0.5 * 55, scale=0.5 + 0.5 * st[0, 2 * p_]).cdf)
+    assert ks_v.pvalue > 1e-3 and ks_w.pvalue > 1e-3
+    small = eng.dinvgamma_step(1, 1, np.array([[0.2, 0.0, 0.3, 0.0]] * N), (0.3, 1.0), (0.3, 1.0), iteration=0, seed=5)   # shape < 1 boost
+    assert sps.kstest(np.asarray(small[0]).reshape(-1), sps.invgamma(0.3, scale=1.1).cdf).pvalue > 1e-3
+    # end to end on the device: local level, V = 2, W = 0.5
+    T, Ns = 300, 64
+    mod = Dlm.polynomial(1)
+    x = np.cumsum(rng.standard_normal((Ns, T)) * np.sqrt(0.5), axis=1)
+    yy = torch.as_tensor((x + rng.standard_normal((Ns, T)) * np.sqrt(2.0))[:, :, None], device="cuda")
+    acc = []
+    gibbs_dinvgamma_device(mod, InverseGamma(3.0, 4.0), InverseGamma(3.0, 1.0), DlmParameters([[1.0]], [[1.0]], [0.0], [[10.0]]),
+                           np.arange(1, T + 1, dtype=np.float64), yy, eng, n_iter=150, seed=2,
+                           on_iteration=lambda it, V_, W_, s_: acc.append((V_.mean().item(), W_.mean().item())) if it >= 50 else None)
+    vm, wm = np.mean(acc, axis=0)
+    assert 1.6 < vm < 2.5 and 0.3 < wm < 0.8

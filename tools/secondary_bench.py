@@ -61,6 +61,19 @@ def main():
         dt = timeit(lambda: eng.loglik(mat, p, y))
         print(json.dumps({"config": "log-likelihood (prediction-error decomposition), d=13, N=10000, T=1000, no record output",
                           "variant": eng.last_variant, "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "c3gibbs" in which:
+        from bayesian_dlms_amd.gibbs import InverseGamma, gibbs_dinvgamma_device
+        mod, p = seasonal_c2(); N, T = 10000, 1000
+        times = np.arange(1, T + 1, dtype=np.float64)
+        mat = materialise(mod, times)
+        y = torch.as_tensor(simulate(mat, p, N, seed=1), device=dev)
+        for name, sim in (("simulation smoother", True), ("reference-form backward sampling", False)):
+            iters = 10 if sim else 2
+            run = lambda: gibbs_dinvgamma_device(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p, times, y, eng,
+                                                 n_iter=iters, seed=1, simulation_smoother=sim)
+            dt = timeit(run, reps=1) / iters
+            print(json.dumps({"config": f"C3 d-Inverse-Gamma Gibbs, per-series V and W, device-resident ({name}), d=13, N=10000, T=1000",
+                              "ms_per_iteration": dt * 1e3, "series_steps_per_s": N * T / dt}))
     if "ar1" in which:
         N, T = 100000, 1000
         rng = np.random.default_rng(3)
