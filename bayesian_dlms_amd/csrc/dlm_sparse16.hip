@@ -340,7 +340,9 @@ __device__ void wave_chol(double* img, int d, int g, int c) {
 // record 0), i = d for the observation noise; injected normals are z[N][T+1][d+1].
 // IRR: irregular time grid (several G tables, W dt, dt == 0) and/or time-varying F; the regular
 // instantiation keeps none of that.
-template <int K, bool SIM, bool IRR>
+// LL: also accumulate the prediction-error log-likelihood (its own instantiation: the expansion of log() in the loop
+// would cost the plain filter two waves per SIMD of occupancy).
+template <int K, bool SIM, bool IRR, bool LL = false>
 __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                      double* __restrict__ side, double* __restrict__ xplus) {
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS + (SIM ? 4 * IMG : 0)];
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
 #pragma unroll
       for (int r = 0; r < 3; ++r) cc[r] = fma(rfr[r], ngam, R[r]);
       cc[3] = (g == 3) ? fma(Kc, e, R[3]) : fma(rfr[3], ngam, R[3]);
-      if (a.loglik) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * erq);   // log(2 pi) = 1.83787...
+      if (LL) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * erq);   // -log N(y; f, Q); log(2 pi) = 1.83787...
       if (sd && lane == 0) { sd[2 * (t + 1)] = erq; sd[2 * (t + 1) + 1] = rq; }
     } else {
       cc = R;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : DLM_FI_WAVES) void k_filter_sp16(KAr
     for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], so, cc[r]);
     wave_sync();   // the images are rewritten at the top of the next step
   }
-  if (a.loglik && lane == 0) a.loglik[n] = ll;
+  if (LL && a.loglik && lane == 0) a.loglik[n] = ll;
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(cc[r]);
@@ -980,7 +982,10 @@ template <int K>
 static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, double* xplus, hipStream_t s) {
   const bool irr = a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride;
   const dim3 grid((a.N + 3) / 4), blk(256);
-  if (xplus && irr) hipLaunchKernelGGL((k_filter_sp16<K, true, true>), grid, blk, 0, s, a, sp, side, xplus);
+  if (a.loglik && !xplus) {
+    if (irr) hipLaunchKernelGGL((k_filter_sp16<K, false, true, true>), grid, blk, 0, s, a, sp, side, xplus);
+    else hipLaunchKernelGGL((k_filter_sp16<K, false, false, true>), grid, blk, 0, s, a, sp, side, xplus);
+  } else if (xplus && irr) hipLaunchKernelGGL((k_filter_sp16<K, true, true>), grid, blk, 0, s, a, sp, side, xplus);
   else if (xplus) hipLaunchKernelGGL((k_filter_sp16<K, true, false>), grid, blk, 0, s, a, sp, side, xplus);
   else if (irr) hipLaunchKernelGGL((k_filter_sp16<K, false, true>), grid, blk, 0, s, a, sp, side, xplus);
   else hipLaunchKernelGGL((k_filter_sp16<K, false, false>), grid, blk, 0, s, a, sp, side, xplus);
