@@ -272,3 +272,29 @@ class FilterOu:
         out = engine.ar1_ffbs(np.atleast_2d(np.asarray(ys, dtype=np.float64)), vs, FilterAr._sv(p), z=z, seed=seed,
                               series_offset=series_offset, want_filt=False, times=times)
         return np.asarray(out["theta"])
+
+
+def forecast(mod: Dlm, mt, ct, time: float, p: DlmParameters, engine: Engine, steps: int):
+    """Dlm.forecast (Dlm.scala:320-338) for a batch of filtering distributions: mt [N][d], ct [N][d][d] (the posterior at
+    `time`) -> (times [steps], f [N][steps][p], Q [N][steps][p][p]).  Element 0 is the one-step prediction at `time`
+    itself (no advance, as the reference's Stream starts), element k advances k unit steps: stepForecast (:296-307) is
+    the Kalman filter without an observation, so elements 1.. come from dlm_filter_batch on all-missing data with the
+    per-series (mt, ct) as initial state."""
+    mt = np.atleast_2d(np.asarray(mt, dtype=np.float64))
+    ct = np.asarray(ct, dtype=np.float64).reshape(mt.shape[0], mt.shape[1], mt.shape[1])
+    N, d = mt.shape
+    times = time + np.arange(steps, dtype=np.float64)
+    F0 = np.asarray(mod.f(time), dtype=np.float64)                      # d x p, used as F^T
+    q = F0.shape[1]
+    f = np.empty((N, steps, q)); Q = np.empty((N, steps, q, q))
+    v0 = p.v if p.v.ndim == 2 else p.v[0]
+    f[:, 0] = mt @ F0
+    Q[:, 0] = np.einsum("dp,ndD,Dq->npq", F0, ct, F0) + v0
+    if steps > 1:
+        mat = materialise(mod, times[1:])                               # first increment = 1: time -> time + 1
+        params = [DlmParameters(p.v, p.w, mt[n], ct[n]) for n in range(N)]
+        out = engine.filter(mat, params, np.full((N, steps - 1, q), np.nan), want_fq=True)
+        fq = np.asarray(out["fq"])[:, 1:]
+        f[:, 1:] = fq[..., :q]
+        Q[:, 1:] = np.transpose(fq[..., q:].reshape(N, steps - 1, q, q), (0, 1, 3, 2))
+    return times, f, Q

@@ -1095,3 +1095,24 @@ def test_device_dinvgamma_step_stream_distribution_and_gibbs(eng):
                            on_iteration=lambda it, V_, W_, s_: acc.append((V_.mean().item(), W_.mean().item())) if it >= 50 else None)
     vm, wm = np.mean(acc, axis=0)
     assert 1.6 < vm < 2.5 and 0.3 < wm < 0.8
+
+
+def test_forecast_is_the_filter_without_observations(eng):
+    """api.forecast = Dlm.forecast / stepForecast (Dlm.scala:296-338): checked against the plain recursion
+    a = G m, R = G C G^T + W, f = F^T a, Q = F^T R F + V for a batch of filtering distributions."""
+    from bayesian_dlms_amd.api import forecast
+    mod, mat, p = seasonal_model(T=30)
+    rng = np.random.default_rng(4)
+    y = simulate(mat, p, 3, seed=9)
+    filt = eng.filter(mat, p, y)["filt"]
+    mt, ct = filt[:, -1, :13], np.transpose(filt[:, -1, 13:].reshape(3, 13, 13), (0, 2, 1))
+    times, f, Q = forecast(mod, mt, ct, 30.0, p, eng, steps=12)
+    G = oracle.from_cm(mat.G[:169], 13, 13); F = np.asarray(mat.F[:13]).reshape(13, 1)
+    assert times[0] == 30.0 and times[-1] == 41.0
+    for n in range(3):
+        m, C = mt[n].copy(), ct[n].copy()
+        for k in range(12):
+            if k > 0:
+                m, C = G @ m, G @ C @ G.T + p.w
+            np.testing.assert_allclose(f[n, k], F.T @ m, rtol=1e-10, atol=1e-11)
+            np.testing.assert_allclose(Q[n, k], F.T @ C @ F + p.v, rtol=1e-10, atol=1e-11)
