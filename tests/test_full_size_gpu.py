@@ -1,0 +1,100 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle would need hours for a whole
+batch): (i) the batch is a set of independent series -- any series run on its own gives bit-identical records;
+(ii) the backward pass starts from the last filtered state; (iii) smoothing never increases a variance and every
+covariance stays symmetric with a positive diagonal; (iv) a few series are compared with the oracle at full length."""
+import numpy as np
+import pytest
+
+import oracle
+from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bayesian_dlms_amd.engine import Engine
+    return Engine(0)
+
+
+def _om(mat):
+    return oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+
+
+def _properties(eng, mat, p, y, pick, expect_variant, tol_f, tol_s):
+    import torch
+    d = mat.d
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == expect_variant
+    assert int((out["status"] != 0).sum().item()) == 0
+    filt, sm = out["filt"], out["smooth"]
+    N, T1, rec = filt.shape
+    # (ii) s_T = m_T, S_T = C_T
+    assert torch.equal(sm[:, -1], filt[:, -1])
+    # (iii) variances: positive, smoothing does not increase them; symmetry of S (on a slab of series, all records)
+    diag = torch.arange(d, device=filt.device) * (d + 1) + d
+    cd, sd = filt[:, :, diag], sm[:, :, diag]
+    assert bool((cd > 0).all()) and bool((sd > 0).all())
+    assert bool((sd <= cd * (1 + 1e-9) + 1e-12).all())
+    S = sm[:64, :, d:].reshape(64, T1, d, d)
+    assert float((S - S.transpose(-1, -2)).abs().max()) <= 1e-9 * float(S.abs().max())
+    # (i) independence: the picked series on their own, bit for bit
+    sub = eng.filter_smooth(mat, p, y[pick])
+    assert torch.equal(sub["filt"], filt[pick]) and torch.equal(sub["smooth"], sm[pick])
+    # (iv) oracle at full length
+    for n in pick[:2]:
+        f = oracle.kf_filter(_om(mat), p.v, p.w, p.m0, p.c0, y[n].cpu().numpy())
+        s = oracle.smoother(_om(mat), f)
+        fr, sr = filt[n].cpu().numpy(), sm[n].cpu().numpy()
+        np.testing.assert_allclose(fr[:, :d], f["m"], rtol=tol_f, atol=tol_f)
+        np.testing.assert_allclose(fr[:, d:], f["C"], rtol=tol_f, atol=tol_f)
+        np.testing.assert_allclose(sr[:, :d], s["s"], rtol=tol_s, atol=tol_s)
+        np.testing.assert_allclose(sr[:, d:], s["S"], rtol=tol_s, atol=tol_s)
+
+
+def test_c2_full_size_properties(eng):
+    """BASELINE configs[1]: seasonal d = 13, 10 000 series x T = 1000 (the bench workload, with 3 % missing values)."""
+    import torch
+    from bench import seasonal_c2, simulate
+    mod, p = seasonal_c2()
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    yh = simulate(mat, p, 10000, seed=20261004)
+    yh[np.random.default_rng(1).random(yh.shape) < 0.03] = np.nan
+    y = torch.as_tensor(yh, device="cuda")
+    _properties(eng, mat, p, y, [0, 4999, 9999, 1234, 7777], "sparse16", 1e-8, 1e-7)
+
+
+def test_c4_full_size_properties(eng):
+    """BASELINE configs[3]: |*| of 20 polynomial(2), d = 40, p = 20, 2000 series x T = 1000 (SURVEY 8d inputs)."""
+    import torch
+    mod = Dlm.polynomial(2)
+    for _ in range(19):
+        mod = mod * Dlm.polynomial(2)
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    rng = np.random.default_rng(40); A = rng.standard_normal((40, 40))
+    p = DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
+    yh = rng.standard_normal((2000, 1000, 20)).cumsum(axis=1)
+    yh[rng.random(yh.shape) < 0.02] = np.nan
+    y = torch.as_tensor(yh, device="cuda")
+    _properties(eng, mat, p, y, [0, 1999, 777], "tiled-mfma", 1e-7, 1e-6)
+
+
+def test_c5_full_size_svd_agrees_with_standard_filter(eng):
+    """BASELINE configs[4]: SVD filter, d = 13, 10 000 series: U D^2 U^T and the means equal the standard filter's
+    (the reference's own check, core/src/test/scala/SvdFilter.scala:102-158), on the whole batch."""
+    import torch
+    from bench import seasonal_c2, simulate
+    mod, p = seasonal_c2()
+    T = 200
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    y = torch.as_tensor(simulate(mat, p, 10000, seed=5), device="cuda")
+    kf = eng.filter(mat, p, y)["filt"]
+    sv = eng.svd_filter(mat, p, y)
+    assert int((sv["status"] != 0).sum().item()) == 0
+    rec = sv["svd"]
+    d = 13
+    m, dc, U = rec[..., :d], rec[..., d:2 * d], rec[..., 2 * d:].reshape(10000, T + 1, d, d).transpose(-1, -2)   # column-major
+    C = (U * (dc * dc).unsqueeze(-2)) @ U.transpose(-1, -2)
+    Ck = kf[..., d:].reshape(10000, T + 1, d, d)
+    assert float((m - kf[..., :d]).abs().max()) < 1e-7
+    assert float((C - Ck).abs().max()) < 1e-7
