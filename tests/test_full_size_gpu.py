@@ -98,3 +98,33 @@ def test_c5_full_size_svd_agrees_with_standard_filter(eng):
     Ck = kf[..., d:].reshape(10000, T + 1, d, d)
     assert float((m - kf[..., :d]).abs().max()) < 1e-7
     assert float((C - Ck).abs().max()) < 1e-7
+
+
+def test_c3_full_size_ffbs_properties(eng):
+    """BASELINE configs[2] (one rank's FFBS pass): 10 000 series x T = 1000, simulation smoother + statistics.  Properties:
+    the same seed reproduces the draw bit for bit; a shard [lo, hi) with series_offset = lo draws exactly the same states
+    (what makes an 8-GPU run reproduce the 1-GPU run); the statistics equal those recomputed from the states by the
+    oracle; the draws scatter around the smoothed means with the smoothed variances."""
+    import torch
+    from bayesian_dlms_amd import _lib
+    from bench import seasonal_c2, simulate
+    mod, p = seasonal_c2()
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    y = torch.as_tensor(simulate(mat, p, 10000, seed=77), device="cuda")
+    fl = _lib.OPT_FFBS_SIMSMOOTH
+    a = eng.ffbs(mat, p, y, seed=9, flags=fl)
+    assert eng.last_variant == "sparse16-simsmooth" and int((a["status"] != 0).sum().item()) == 0
+    b = eng.ffbs(mat, p, y, seed=9, flags=fl)
+    assert torch.equal(a["theta"], b["theta"]) and torch.equal(a["stats"], b["stats"])
+    lo, hi = 2500, 3750                                    # rank 2 of 8
+    c = eng.ffbs(mat, p, y[lo:hi], seed=9, series_offset=lo, flags=fl)
+    assert torch.equal(c["theta"], a["theta"][lo:hi]) and torch.equal(c["stats"], a["stats"][lo:hi])
+    for n in (0, 9999):
+        st = oracle.gibbs_stats(_om(mat), y[n].cpu().numpy(), a["theta"][n].cpu().numpy())
+        got = a["stats"][n].cpu().numpy()
+        np.testing.assert_allclose(got[0], st["ssy"][0], rtol=1e-9)
+        np.testing.assert_allclose(got[2:15], st["ss"], rtol=1e-9)
+        assert got[1] == st["n"][0] and got[-1] == 1000
+    sm = eng.filter_smooth(mat, p, y)["smooth"]
+    zsc = (a["theta"] - sm[..., :13]) / torch.sqrt(sm[..., 13:].reshape(10000, 1001, 13, 13).diagonal(dim1=-2, dim2=-1))
+    assert abs(float(zsc.mean())) < 2e-3 and abs(float(zsc.var()) - 1.0) < 5e-3   # 1.3e8 standardised draws
