@@ -314,8 +314,9 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   double V = a.V[(size_t)n * a.v_stride];   // V_0; reloaded every step when time-varying (IRR instantiation)
   const double* y = a.y + (size_t)n * T;
   // likelihood-only calls pass no record buffer: a zero-sized resource drops every store
-  char* bout = a.filt ? (char*)(a.filt + (size_t)n * (T + 1) * rec) : nullptr;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, a.filt ? (size_t)(T + 1) * rec * 8 : 0);
+  const int prec = SIM ? d + d * (d + 1) / 2 : rec;   // doubles per stored record (packed in SIM mode, see below)
+  char* bout = a.filt ? (char*)(a.filt + (size_t)n * (T + 1) * prec) : nullptr;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, a.filt ? (size_t)(T + 1) * prec * 8 : 0);
   double ll = 0.0;   // sum_t log N(y_t; f_t, Q_t) (KalmanFilter.conditionalLikelihood, KalmanFilter.scala:138-153)
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
   double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
@@ -336,7 +337,10 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   double Fr[4];
   bool vr[4], va[4];
   int offA[4];                                   // byte offset of this lane's element of register r inside a record
-  const int recb = rec * 8;
+  // SIM: the records only feed k_simsmooth_sp16 (the caller's filt buffer is a workspace), so the symmetric C_t is
+  // stored packed -- [m (d) | lower triangle by rows, d (d + 1) / 2] -- 832 B instead of 1456 B per step at d = 13:
+  // both simulation-smoother kernels are bound by exactly this stream.
+  const int recb = SIM ? (d + d * (d + 1) / 2) * 8 : rec * 8;
   double Fc = vc ? a.F[c] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -344,7 +348,8 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
     vr[r] = i < d;
     const bool ok = vr[r] && vc;
     va[r] = vr[r] && (vc || col15);
-    offA[r] = ok ? (d + i * d + c) * 8 : (vr[r] && col15 ? i * 8 : OOB);
+    offA[r] = SIM ? ((ok && c <= i) ? (d + i * (i + 1) / 2 + c) * 8 : (vr[r] && col15 ? i * 8 : OOB))
+                  : (ok ? (d + i * d + c) * 8 : (vr[r] && col15 ? i * 8 : OOB));
     w[r] = ok ? W[i * d + c] : 0.0;
     cc[r] = ok ? C0[i * d + c] : 0.0;
     if (!SIM) {                                  // SIM: y* is filtered from a zero prior mean
@@ -750,7 +755,7 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
   double* vR = vQ + 16;           // r
   double* vT = vR + 16;           // theta_t
   double* vD = vT + 16;           // theta_{t+1} - G theta_t
-  const int d = a.d, T = a.T, rec = d + d * d, recb = rec * 8;
+  const int d = a.d, T = a.T, rec = d + d * (d + 1) / 2, recb = rec * 8;   // packed records of the SIM forward pass
   const int g = lane >> 4, c = lane & 15;
   const bool vc = c < d;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
@@ -778,7 +783,8 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * r + g;
     Fr[r] = i < d ? a.F[i] : 0.0;
-    offC[r] = (i < d && vc) ? (d + i * d + c) * 8 : OOB;
+    const int hi = i > c ? i : c, lo = i > c ? c : i;   // C is symmetric: element (i, c) of the packed lower triangle
+    offC[r] = (i < d && vc) ? (d + hi * (hi + 1) / 2 + lo) * 8 : OOB;
   }
   double qcol = 0.0, thn = 0.0, ssy = 0.0, nob = 0.0, ssc = 0.0;
   d4 so = {0.0, 0.0, 0.0, 0.0};
