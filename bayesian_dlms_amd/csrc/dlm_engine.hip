@@ -27,6 +27,8 @@ struct dlm_engine {
   size_t spb_count = 0;
   size_t sp_count = 0;
   int sparse_k = 0;           // 0: some G is not structured (dense MFMA path, regular grids only)
+  double* fws = nullptr;      // filtered records of a fused call that does not want them (packed on the structured path)
+  size_t fws_bytes = 0;
   double* side = nullptr;     // forward->backward innovations buffer of the fused fast path
   size_t side_bytes = 0;
   double* xplus = nullptr;    // simulated states x+ of the simulation smoother [N][T+1][d]
@@ -205,6 +207,15 @@ int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   return DLM_OK;
 }
 
+int ensure_fws(dlm_engine* e, size_t need) {
+  if (need > e->fws_bytes) {
+    if (e->fws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->fws)); e->fws = nullptr; e->fws_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->fws, need));
+    e->fws_bytes = need;
+  }
+  return DLM_OK;
+}
+
 int ensure_side(dlm_engine* e, const KArgs& k) {
   const size_t need = sizeof(double) * 2 * (size_t)k.N * ((size_t)k.T + 1);
   if (need > e->side_bytes) {
@@ -312,6 +323,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->xplus) (void)hipFree(e->xplus);
   if (e->ystar) (void)hipFree(e->ystar);
   if (e->sp_dev) (void)hipFree(e->sp_dev);
+  if (e->fws) (void)hipFree(e->fws);
   if (e->spb_dev) (void)hipFree(e->spb_dev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -482,18 +494,23 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
                             int32_t* status) {
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
-  if (!y || !filt || !smooth) return fail(e, DLM_ERR_ARG, "y, filt and smooth are required");
+  if (!y || !smooth) return fail(e, DLM_ERR_ARG, "y and smooth are required");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, rec = d + d * d;
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
   st.in(&k.y, y, N * T * p);
-  st.out(&k.filt, filt, N * (T + 1) * rec);
+  st.out(&k.filt, filt, filt ? N * (T + 1) * rec : 0);
   st.out(&k.smooth, smooth, N * (T + 1) * rec);
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
   const bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
+  if (!filt) {   // smoothed moments only: the filtered records stay in an engine workspace, packed on the structured path
+    k.packed = (fast_smoother_ok(e, k) && e->sparse_k > 0) ? 1 : 0;
+    if ((rc = ensure_fws(e, k.packed ? N * (T + 1) * (size_t)dlm::packed_rec_bytes((int)d) : N * (T + 1) * rec * sizeof(double)))) return rc;
+    k.filt = e->fws;
+  }
   HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
   if ((rc = run_filter(e, k, fused_fast))) return rc;
   HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));

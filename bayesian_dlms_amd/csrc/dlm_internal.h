@@ -27,10 +27,15 @@ struct KArgs {
   double* stats;
   double* loglik;      // [N] prediction-error log-likelihood (nullable); with it, filt may be null (nothing stored)
   int* status;
+  int packed;          // structured d <= 15 fast path only: filt / filt_in hold PACKED records (engine-internal workspace)
   const struct SparseBig* spb;   // tiled path: [2 n_g] row / column tables of a structured G, or nullptr (dense G)
   unsigned flags;
   unsigned long long seed, series_offset;
 };
+
+// Packed record of the structured fast path's internal workspaces: [m (d) | lower triangle of C by rows], padded to a
+// multiple of 16 B (the backward pass fetches records by 16-byte LDS-DMA pieces).
+__host__ __device__ inline int packed_rec_bytes(int d) { return ((d + d * (d + 1) / 2) * 8 + 15) & ~15; }
 
 __host__ __device__ inline int stats_len(int d, int p, unsigned flags) {
   return 2 * p + ((flags & (1u << 4)) ? d * d : d) + 1;  // DLM_OPT_STATS_OUTER

@@ -314,9 +314,10 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   double V = a.V[(size_t)n * a.v_stride];   // V_0; reloaded every step when time-varying (IRR instantiation)
   const double* y = a.y + (size_t)n * T;
   // likelihood-only calls pass no record buffer: a zero-sized resource drops every store
-  const int prec = SIM ? d + d * (d + 1) / 2 : rec;   // doubles per stored record (packed in SIM mode, see below)
-  char* bout = a.filt ? (char*)(a.filt + (size_t)n * (T + 1) * prec) : nullptr;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, a.filt ? (size_t)(T + 1) * prec * 8 : 0);
+  const bool packed = SIM || a.packed;                // records go to an engine-internal workspace: packed (see below)
+  const int recb = packed ? packed_rec_bytes(d) : rec * 8;
+  char* bout = a.filt ? (char*)a.filt + (size_t)n * (T + 1) * recb : nullptr;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, a.filt ? (size_t)(T + 1) * recb : 0);
   double ll = 0.0;   // sum_t log N(y_t; f_t, Q_t) (KalmanFilter.conditionalLikelihood, KalmanFilter.scala:138-153)
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
   double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
@@ -337,10 +338,9 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   double Fr[4];
   bool vr[4], va[4];
   int offA[4];                                   // byte offset of this lane's element of register r inside a record
-  // SIM: the records only feed k_simsmooth_sp16 (the caller's filt buffer is a workspace), so the symmetric C_t is
-  // stored packed -- [m (d) | lower triangle by rows, d (d + 1) / 2] -- 832 B instead of 1456 B per step at d = 13:
-  // both simulation-smoother kernels are bound by exactly this stream.
-  const int recb = SIM ? (d + d * (d + 1) / 2) * 8 : rec * 8;
+  // packed (SIM, or a fused filter + smoother call that does not want the filtered records): the records only feed the
+  // backward kernel, so the symmetric C_t is stored as [m (d) | lower triangle by rows, d (d + 1) / 2] -- 832 B
+  // instead of 1456 B per step at d = 13; these kernels are bound by exactly this stream.
   double Fc = vc ? a.F[c] : 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
     vr[r] = i < d;
     const bool ok = vr[r] && vc;
     va[r] = vr[r] && (vc || col15);
-    offA[r] = SIM ? ((ok && c <= i) ? (d + i * (i + 1) / 2 + c) * 8 : (vr[r] && col15 ? i * 8 : OOB))
-                  : (ok ? (d + i * d + c) * 8 : (vr[r] && col15 ? i * 8 : OOB));
+    offA[r] = packed ? ((ok && c <= i) ? (d + i * (i + 1) / 2 + c) * 8 : (vr[r] && col15 ? i * 8 : OOB))
+                     : (ok ? (d + i * d + c) * 8 : (vr[r] && col15 ? i * 8 : OOB));
     w[r] = ok ? W[i * d + c] : 0.0;
     cc[r] = ok ? C0[i * d + c] : 0.0;
     if (!SIM) {                                  // SIM: y* is filtered from a zero prior mean
@@ -549,11 +549,12 @@ __global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const 
 
   const double V = a.V[(size_t)n * a.v_stride];
   double rV = 1.0 / V;   // 1 / V_t of the record's observation when time-varying (IRR instantiation)
-  const char* bin = (const char*)(a.filt_in + (size_t)n * (T + 1) * rec);
+  const int recb = rec * 8;                                       // smoothed records (output): always dense
+  const int rinb = a.packed ? packed_rec_bytes(d) : recb;         // filtered records (input): packed when engine-internal
+  const char* bin = (const char*)a.filt_in + (size_t)n * (T + 1) * rinb;
   char* bout = (char*)(a.smooth + (size_t)n * (T + 1) * rec);
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
   const double* sd = side + (size_t)n * (T + 1) * 2;
-  const int recb = rec * 8;
 
   int idx[K];
   double val[K];
@@ -571,20 +572,21 @@ __global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const 
     Fr[r] = i < d ? a.F[i] : 0.0;
     va[r] = i < d && (vc || col15);
     offA[r] = i < d ? (vc ? (d + i * d + c) * 8 : (col15 ? i * 8 : OOB)) : OOB;
-    ldsA[r] = va[r] ? offA[r] : recb;
+    if (a.packed) { const int hi = i > c ? i : c, lo = i > c ? c : i; ldsA[r] = va[r] ? (vc ? (d + hi * (hi + 1) / 2 + lo) * 8 : i * 8) : rinb; }
+    else ldsA[r] = va[r] ? offA[r] : rinb;
   }
   d4 P = {0.0, 0.0, 0.0, 0.0};
   double qcol = 0.0;
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
 
-  const int slotb = recb + 16;
+  const int slotb = rinb + 16;
   char* ring = ring_all + wave * 2 * slotb;
   const unsigned ring_lds = lds_addr_of(ring);
-  const i4 rdma = rsrc_words(bin, (unsigned)((size_t)(T + 1) * recb));
-  const int n16 = recb / 16;                          // d (d + 1) is even: a record is a whole number of 16 B
-  if (lane < 2) *(double*)(ring + lane * slotb + recb) = 0.0;
-  dma_record(rdma, ring_lds + (T & 1) * slotb, T * recb, lane, n16);
-  { const int t1 = T > 0 ? T - 1 : 0; dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * recb, lane, n16); }
+  const i4 rdma = rsrc_words(bin, (unsigned)((size_t)(T + 1) * rinb));
+  const int n16 = rinb / 16;                          // d (d + 1) is even (and packed records are padded): whole 16 B pieces
+  if (lane < 2) *(double*)(ring + lane * slotb + rinb) = 0.0;
+  dma_record(rdma, ring_lds + (T & 1) * slotb, T * rinb, lane, n16);
+  { const int t1 = T > 0 ? T - 1 : 0; dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * rinb, lane, n16); }
   double neq = sd[2 * T], niq = sd[2 * T + 1];
   vQ[c] = 0.0;
   d4 out = {0.0, 0.0, 0.0, 0.0};
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const 
     wave_sync();                                             // also publishes vQ of the last step
     // the slot just read is free again: request record t-2 into it (always issued, so that the operation
     // count behind every request is the same; below record 0 it re-reads record 0, which nobody uses)
-    { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * recb, lane, n16); }
+    { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rinb, lane, n16); }
     d4 kr, nqr;
     {
       const unsigned bk = lds_addr_of(vK + g), bq = lds_addr_of(vQ + g);
@@ -755,15 +757,15 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
   double* vR = vQ + 16;           // r
   double* vT = vR + 16;           // theta_t
   double* vD = vT + 16;           // theta_{t+1} - G theta_t
-  const int d = a.d, T = a.T, rec = d + d * (d + 1) / 2, recb = rec * 8;   // packed records of the SIM forward pass
+  const int d = a.d, T = a.T, recb = packed_rec_bytes(d);   // packed records of the SIM forward pass
   const int g = lane >> 4, c = lane & 15;
   const bool vc = c < d;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
 
   const double V = a.V[(size_t)n * a.v_stride];
   const double rV = 1.0 / V;
-  const char* bin = (const char*)(a.filt_in + (size_t)n * (T + 1) * rec);
-  const __amdgpu_buffer_rsrc_t rin = make_rsrc(bin, (size_t)(T + 1) * rec * 8);
+  const char* bin = (const char*)a.filt_in + (size_t)n * (T + 1) * recb;
+  const __amdgpu_buffer_rsrc_t rin = make_rsrc(bin, (size_t)(T + 1) * recb);
   const double* sd = side + (size_t)n * (T + 1) * 2;
   const double* xp = xplus + (size_t)n * (T + 1) * d;
   const double* y = a.y ? a.y + (size_t)n * T : nullptr;
@@ -953,7 +955,7 @@ static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* sid
 }
 template <int K>
 static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
-  const size_t ring = (size_t)4 * 2 * ((a.d + a.d * a.d) * 8 + 16);   // dynamic LDS: DMA ring, 2 slots per wave
+  const size_t ring = (size_t)4 * 2 * ((a.packed ? packed_rec_bytes(a.d) : (a.d + a.d * a.d) * 8) + 16);   // dynamic LDS: DMA ring, 2 slots per wave
   if (a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   return hipGetLastError();

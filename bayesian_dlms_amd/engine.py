@@ -249,12 +249,14 @@ class Engine:
         self._check(self.lib.dlm_smooth_batch(self.h, md, pd, be.ptr(fb), op, be.ptr(smooth), be.ptr(status)))
         return {"smooth": smooth, "status": status}
 
-    def filter_smooth(self, mat, params, y, *, flags=0, out=None):
+    def filter_smooth(self, mat, params, y, *, flags=0, out=None, want_filt=True):
+        """Fused filter + smoother.  want_filt=False keeps the filtered records inside the engine (packed on the
+        structured fast path) and returns only the smoothed moments."""
         be = self._backend(y)
         N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
         yb = be.put(y).reshape(N, T, p)
         md, pd, op, keep = self.prepare(mat, params, N, be, flags)
-        filt = out["filt"] if out else be.empty((N, T + 1, d + d * d))
+        filt = (out["filt"] if out else be.empty((N, T + 1, d + d * d))) if want_filt else None
         smooth = out["smooth"] if out else be.empty((N, T + 1, d + d * d))
         status = out["status"] if out else be.empty((N,), np.int32)
         self._check(self.lib.dlm_filter_smooth_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(filt),

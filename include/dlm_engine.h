@@ -168,7 +168,11 @@ int dlm_ou_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* times, 
 int dlm_loglik_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
                      const double* y, const dlm_options* opts, double* loglik, int32_t* status);
 
-/* ---- fused filter + smoother (the headline metric path) ---------------------------- */
+/* ---- fused filter + smoother (the headline metric path) ----------------------------
+ * KalmanFilter(...).filter followed by Smoothing.backwardsSmoother (KalmanFilter.scala:262-294, Smoothing.scala:57-64)
+ * in one call.  filt may be NULL when only the smoothed moments are wanted: the filtered records then stay in an
+ * engine workspace (stored packed -- mean + lower triangle -- on the structured d <= 15 path, which cuts the traffic
+ * of both passes). */
 int dlm_filter_smooth_batch(dlm_engine *e, const dlm_model_desc *model,
                             const dlm_params_desc *params, const double *y,
                             const dlm_options *opts, double *filt, double *smooth,

@@ -1116,3 +1116,33 @@ def test_forecast_is_the_filter_without_observations(eng):
                 m, C = G @ m, G @ C @ G.T + p.w
             np.testing.assert_allclose(f[n, k], F.T @ m, rtol=1e-10, atol=1e-11)
             np.testing.assert_allclose(Q[n, k], F.T @ C @ F + p.v, rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("case", ["sparse16_d13", "sparse16_d14_irregular", "tiled_d17", "generic_d8_p4"])
+def test_fused_call_without_filtered_output(eng, case):
+    """dlm_filter_smooth_batch with filt = NULL: identical smoothed moments, the filtered records stay in an engine
+    workspace (packed on the structured d <= 15 path; d = 14 exercises the 16-byte padding of a packed record)."""
+    rng = np.random.default_rng(21)
+    if case == "sparse16_d13":
+        mod, mat, p = seasonal_model(T=70); expect = "sparse16"
+    elif case == "sparse16_d14_irregular":
+        mod = Dlm.polynomial(2) + Dlm.seasonal(12, 6)
+        mat = materialise(mod, np.cumsum(np.array([1, 1, 3, 1, 2] * 10, dtype=np.float64)))
+        p = DlmParameters([[0.9]], np.diag(rng.uniform(0.05, 0.4, 14)), np.zeros(14), np.eye(14)); expect = "sparse16"
+    elif case == "tiled_d17":
+        A = rng.standard_normal((17, 17)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((17, 3))
+        mat = materialise(Dlm(lambda t: F, lambda dt: G1), np.arange(1, 31, dtype=np.float64))
+        p = DlmParameters(np.eye(3), np.eye(17) * 0.3, np.zeros(17), np.eye(17)); expect = "tiled-mfma"
+    else:
+        mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
+        mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
+        p = DlmParameters(np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8)); expect = "generic"
+    y = rng.standard_normal((5, mat.T, mat.p)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    full = eng.filter_smooth(mat, p, y)
+    only = eng.filter_smooth(mat, p, y, want_filt=False)
+    assert eng.last_variant == expect and only["filt"] is None and np.all(only["status"] == 0)
+    # not bit-identical on the packed path: it reads C_t as an exactly symmetric matrix from its lower triangle, the
+    # dense records carry the two triangles as the forward pass rounded them
+    np.testing.assert_allclose(only["smooth"], full["smooth"], rtol=1e-9, atol=1e-11)

@@ -54,6 +54,14 @@ def main():
             dt = timeit(lambda: eng.ffbs(mat, p, y, seed=1, want_theta=False, flags=_lib.OPT_STATS_OUTER | fl), reps=1)
             print(json.dumps({"config": f"C4 FFBS + outer-product stats ({name}), d=40, p=20, N=256, T=200", "variant": eng.last_variant,
                               "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "c2s" in which:
+        mod, p = seasonal_c2(); N, T = 10000, 1000
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        y = torch.as_tensor(simulate(mat, p, N, seed=1), device=dev)
+        dt = timeit(lambda: eng.filter_smooth(mat, p, y, want_filt=False))
+        fwd, bwd = eng.last_timing()
+        print(json.dumps({"config": "C2 filter+smooth, smoothed moments only (filt = NULL: packed internal records), d=13, N=10000, T=1000",
+                          "variant": eng.last_variant, "ms": dt * 1e3, "forward_ms": fwd, "backward_ms": bwd, "series_steps_per_s": N * T / dt}))
     if "ll" in which:
         mod, p = seasonal_c2(); N, T = 10000, 1000
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
