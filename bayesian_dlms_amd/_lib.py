@@ -55,6 +55,7 @@ SYMBOLS = [
     ("dlm_last_variant", ctypes.c_char_p, [_V]),
     ("dlm_filter_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V, _V, _V]),
     ("dlm_loglik_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V]),
+    ("dlm_simulate_batch", ctypes.c_int, [_V, _MP, _PP, _OP, _V, _V, _V]),
     ("dlm_dinvgamma_step_batch", ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _V, ctypes.c_double,
                                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, _OP, _V, _V]),
     ("dlm_ou_ffbs_batch", ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_int32, _V, _V, _V, ctypes.c_int64, _V, ctypes.c_int64,

@@ -298,3 +298,11 @@ def forecast(mod: Dlm, mt, ct, time: float, p: DlmParameters, engine: Engine, st
         f[:, 1:] = fq[..., :q]
         Q[:, 1:] = np.transpose(fq[..., q:].reshape(N, steps - 1, q, q), (0, 1, 3, 2))
     return times, f, Q
+
+
+def simulate(mod: Dlm, times, p: DlmParameters, engine: Engine, n_series: int = 1, *, seed: int = 0, series_offset: int = 0):
+    """Dlm.simulateRegular / Dlm.simulate (Dlm.scala:245-292) for a batch of independent realisations on the device
+    (dlm_simulate_batch): `times` are the observation times, the first increment is times[1] - times[0] like the
+    filter's.  Returns (x [N][T+1][d] with record 0 the initial state, y [N][T][p])."""
+    out = engine.simulate(materialise(mod, times), p, n_series, seed=seed, series_offset=series_offset)
+    return np.asarray(out["x"]), np.asarray(out["y"])

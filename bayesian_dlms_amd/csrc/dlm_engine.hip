@@ -379,6 +379,24 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
+int dlm_simulate_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                       const dlm_options* opts, double* x, double* y, int32_t* status) {
+  int rc = check_common(e, model, params, opts);
+  if (rc) return rc;
+  if (!y) return fail(e, DLM_ERR_ARG, "y is required");
+  const size_t d = model->d, p = model->p, T = model->T, N = model->N;
+  KArgs k{};
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  stage_model(st, k, model, params, opts);
+  st.out(&k.theta, x, x ? N * (T + 1) * d : 0);
+  st.out(&k.smooth, y, N * T * p);
+  st.zeroed_out(&k.status, (int*)status, status ? N : 0);
+  if ((rc = st.commit())) return rc;
+  e->variant = "generic-simulate";
+  HIP_TRY(e, dlm::launch_generic_simulate(k, e->stream));
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
+
 int dlm_dinvgamma_step_batch(dlm_engine* e, int32_t d, int32_t p, int32_t N, const double* stats, double alpha_v,
                              double beta_v, double alpha_w, double beta_w, uint64_t iteration, const dlm_options* opts,
                              double* V_out, double* W_out) {

@@ -485,6 +485,82 @@ __global__ void k_stats_pool(const double* stats, int N, int L, double* pooled) 
 }
 
 // ---------------------------------------------------------------------------------------
+// Simulation from the model (Dlm.simulateRegular / simStep / stepState / observation, Dlm.scala:245-292):
+//   x_0 ~ N(m0, C0);  x_t = G_t x_{t-1} + w_t, w_t ~ N(0, W dt_t);  y_t = F_t^T x_t + v_t, v_t ~ N(0, V)
+// over the model's time grid (the reference's regular grid is the special case dt = const).  Draws: lower
+// Cholesky factors (the reference draws through an eigen-factor, MultivariateGaussianSvd.scala:13-22 -- the same
+// distribution; its generator cannot be seeded) on the Philox stream (seed, series, record t, i):
+// i < d the state noise (record 0: the initial state), d <= i < d + p the observation noise -- the convention of the
+// simulation smoother.  a.theta = x [N][T+1][d] (nullable), a.smooth = y [N][T][p].
+// ---------------------------------------------------------------------------------------
+size_t generic_simulate_lds_bytes(int d, int p) { return sizeof(double) * (size_t)(2 * d * d + p * p + 3 * d + p + d + p) + 16; }
+
+__global__ __launch_bounds__(64) void k_simulate_generic(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d;
+  double* Lw = sm;           double* Lc = Lw + dd;     double* Lv = Lc + dd;
+  double* x = Lv + p * p;    double* xn = x + d;       double* gx = xn + d;      double* fy = gx + d;
+  double* z = fy + p;        // d + p normals of the current record
+  const double* V0 = a.V + (size_t)n * a.v_stride;
+  const double* W0 = a.W + (size_t)n * a.w_stride;
+  const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+  const double* C0 = a.C0 + (size_t)n * a.c0_stride;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  double* xo = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  double* yo = a.smooth + (size_t)n * T * p;
+  int st = 0;
+  for (int i = lane; i < dd; i += 64) { Lw[i] = W0[i]; Lc[i] = C0[i]; }
+  for (int i = lane; i < p * p; i += 64) Lv[i] = V0[i];
+  wsync();
+  if (chol_lds(lane, d, Lw)) st |= DLM_ST_NOT_PD;
+  if (chol_lds(lane, d, Lc)) st |= DLM_ST_NOT_PD;
+  if (chol_lds(lane, p, Lv)) st |= DLM_ST_NOT_PD;
+  for (int i = lane; i < d; i += 64) z[i] = philox_normal(a.seed, series, 0u, (unsigned)i);
+  wsync();
+  for (int i = lane; i < d; i += 64) {   // initialiseState (:268-273): x0 = m0 + chol(C0) z
+    double acc = m0[i];
+    for (int k = 0; k <= i; ++k) acc = fma(Lc[CM(i, k, d)], z[k], acc);
+    x[i] = acc;
+    if (xo) xo[i] = acc;
+  }
+  for (int t = 0; t < T; ++t) {
+    const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
+    const double* Ft = a.F + (size_t)t * a.f_stride;
+    const double dt = a.dt ? a.dt[t] : 1.0, sdt = sqrt(dt);
+    if (a.w_tstride || a.v_tstride) {   // time-varying variances: factor this step's matrices
+      wsync();
+      if (a.w_tstride) for (int i = lane; i < dd; i += 64) Lw[i] = (W0 + (size_t)t * a.w_tstride)[i];
+      if (a.v_tstride) for (int i = lane; i < p * p; i += 64) Lv[i] = (V0 + (size_t)t * a.v_tstride)[i];
+      wsync();
+      if (a.w_tstride && chol_lds(lane, d, Lw)) st |= DLM_ST_NOT_PD;
+      if (a.v_tstride && chol_lds(lane, p, Lv)) st |= DLM_ST_NOT_PD;
+    }
+    wsync();
+    for (int i = lane; i < d + p; i += 64) z[i] = philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)i);
+    gemm<false, false>(lane, d, 1, d, Gt, d, x, d, gx, d);      // G x
+    wsync();
+    for (int i = lane; i < d; i += 64) {                          // stepState (:245-255)
+      double acc = gx[i];
+      for (int k = 0; k <= i; ++k) acc = fma(Lw[CM(i, k, d)] * sdt, z[k], acc);
+      xn[i] = acc;
+    }
+    wsync();
+    gemm<true, false>(lane, p, 1, d, Ft, d, xn, d, fy, p);        // F^T x
+    wsync();
+    for (int j = lane; j < p; j += 64) {                          // observation (:257-266)
+      double acc = fy[j];
+      for (int k = 0; k <= j; ++k) acc = fma(Lv[CM(j, k, p)], z[d + k], acc);
+      yo[(size_t)t * p + j] = acc;
+    }
+    for (int i = lane; i < d; i += 64) { x[i] = xn[i]; if (xo) xo[(size_t)(t + 1) * d + i] = xn[i]; }
+  }
+  wsync();
+  if (any_nonfinite(lane, d, x)) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0) a.status[n] |= st;
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 static hipError_t check_lds(const void* fn, size_t bytes) {
@@ -514,6 +590,14 @@ hipError_t launch_generic_sampler(const KArgs& a, hipStream_t s) {
   hipError_t e = check_lds((const void*)k_sampler_generic, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_sampler_generic, dim3(a.N), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_generic_simulate(const KArgs& a, hipStream_t s) {
+  const size_t lds = generic_simulate_lds_bytes(a.d, a.p);
+  hipError_t e = check_lds((const void*)k_simulate_generic, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_simulate_generic, dim3(a.N), dim3(64), lds, s, a);
   return hipGetLastError();
 }
 

@@ -239,6 +239,17 @@ class Engine:
                                                       int(iteration), op, be.ptr(V), be.ptr(W)))
         return V, W
 
+    def simulate(self, mat, params, N, *, seed=0, series_offset=0, device=False, want_x=True):
+        """Dlm.simulateRegular over the model's time grid for N series (dlm_simulate_batch): (x [N][T+1][d], y [N][T][p])."""
+        be = _Device(self.device) if device else _Host()
+        d, p, T = mat.d, mat.p, mat.T
+        md, pd, op, keep = self.prepare(mat, params, N, be, 0, seed, series_offset)
+        x = be.empty((N, T + 1, d)) if want_x else None
+        y = be.empty((N, T, p))
+        status = be.empty((N,), np.int32)
+        self._check(self.lib.dlm_simulate_batch(self.h, md, pd, op, be.ptr(x), be.ptr(y), be.ptr(status)))
+        return {"x": x, "y": y, "status": status}
+
     def smooth(self, mat, params, filt, *, flags=0):
         be = self._backend(filt)
         N = int(filt.shape[0]); d, T = mat.d, mat.T

@@ -127,6 +127,14 @@ int dlm_filter_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_param
 int dlm_smooth_batch(dlm_engine *e, const dlm_model_desc *model, const dlm_params_desc *params,
                      const double *filt, const dlm_options *opts, double *smooth, int32_t *status);
 
+/* Simulation from the model on the device: Dlm.simulateRegular / simStep (Dlm.scala:245-292) over the model's time grid,
+ *   x_0 ~ N(m0, C0);  x_t = G_t x_{t-1} + w_t, w_t ~ N(0, W dt_t);  y_t = F_t^T x_t + v_t, v_t ~ N(0, V).
+ * Lower-Cholesky factors of C0, W, V (the reference draws through an eigen-factor: same distribution) on the Philox
+ * stream (opts->seed, opts->series_offset + n, record t, i), i < d state noise, d <= i < d + p observation noise.
+ * x [N][T+1][d] (record 0 = x_0) nullable; y [N][T][p]; status [N] nullable. */
+int dlm_simulate_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
+                       const dlm_options* opts, double* x, double* y, int32_t* status);
+
 /* GibbsSampling.dinvGammaStep on the device (Gibbs.scala:23-78, :134-151) for per-series parameters: from the
  * statistics [N][2p + d + 1] = [ssy | n | ss | T] of an FFBS call (without DLM_OPT_STATS_OUTER) draw
  *   V_jj ~ InverseGamma(alpha_v + n_j / 2, beta_v + ssy_j / 2),   W_ii ~ InverseGamma(alpha_w + T / 2, beta_w + ss_i / 2)

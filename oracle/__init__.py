@@ -234,6 +234,16 @@ def dinvgamma_step(d, p, stats, av, bv, aw, bw, seed, series, iteration):
     return v, w
 
 
+def simulate(M, V, W, m0, C0, seed, series):
+    """Dlm.simulateRegular on the engine's Philox convention: (x [T+1][d], y [T][p])."""
+    d, p, T = M.d, M.p, M.T
+    x = np.empty((T + 1, d)); y = np.empty((T, p))
+    V, W, m0, C0 = cm(V), cm(W), cm(m0), cm(C0)
+    lib().oracle_simulate(d, p, T, _p(M.F), ctypes.c_long(M.f_stride), _p(M.G), _pi(M.g_index), _p(M.dt),
+                          _p(V), _p(W), _p(m0), _p(C0), ctypes.c_uint64(seed), ctypes.c_uint64(series), _p(x), _p(y))
+    return x, y
+
+
 def normals(seed, series, T1, d):
     z = np.empty((T1, d))
     lib().oracle_normals(ctypes.c_uint64(seed), ctypes.c_uint64(series), T1, d, _p(z))

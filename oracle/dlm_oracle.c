@@ -939,6 +939,40 @@ void oracle_dinvgamma_step(int d, int p, const double *stats, double av, double 
     wdiag[i] = (bw + 0.5 * stats[2 * p + i]) / oracle_gamma_unit(aw + 0.5 * stats[L - 1], seed, series, iteration, (uint32_t)(p + i));
 }
 
+/* Dlm.simulateRegular / simStep (Dlm.scala:245-292) with lower-Cholesky draws on the engine's Philox convention
+ * (record t, component i: i < d state noise, d <= i < d + p observation noise; record 0 = the initial state). */
+int oracle_simulate(int d, int p, int T, const double *F, long f_stride, const double *G, const int *g_index,
+                    const double *dts, const double *V, const double *W, const double *m0, const double *C0,
+                    uint64_t seed, uint64_t series, double *x_out /* [T+1][d] */, double *y_out /* [T][p] */) {
+  model_t M = {d, p, T, F, f_stride, G, g_index, dts};
+  double *Lw = malloc(sizeof(double) * d * d), *Lc = malloc(sizeof(double) * d * d), *Lv = malloc(sizeof(double) * p * p);
+  int rc = chol_lower(d, W, Lw) | chol_lower(d, C0, Lc) | chol_lower(p, V, Lv);
+  for (int i = 0; i < d; ++i) {
+    double acc = m0[i];
+    for (int k = 0; k <= i; ++k) acc = fma(Lc[i + k * d], oracle_normal(seed, series, 0u, (uint32_t)k), acc);
+    x_out[i] = acc;
+  }
+  for (int t = 0; t < T; ++t) {
+    const double *Gt = G_at(&M, t), *Ft = F_at(&M, t), *x = x_out + (size_t)t * d;
+    double *xn = x_out + (size_t)(t + 1) * d;
+    const double sdt = sqrt(dt_at(&M, t));
+    for (int i = 0; i < d; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < d; ++k) acc = fma(Gt[i + k * d], x[k], acc);
+      for (int k = 0; k <= i; ++k) acc = fma(Lw[i + k * d] * sdt, oracle_normal(seed, series, (uint32_t)(t + 1), (uint32_t)k), acc);
+      xn[i] = acc;
+    }
+    for (int j = 0; j < p; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < d; ++k) acc = fma(Ft[k + j * d], xn[k], acc);
+      for (int k = 0; k <= j; ++k) acc = fma(Lv[j + k * p], oracle_normal(seed, series, (uint32_t)(t + 1), (uint32_t)(d + k)), acc);
+      y_out[(size_t)t * p + j] = acc;
+    }
+  }
+  free(Lw); free(Lc); free(Lv);
+  return rc;
+}
+
 void oracle_normals(uint64_t seed, uint64_t series, int T1, int d, double *z) {
   for (int t = 0; t < T1; ++t)
     for (int i = 0; i < d; ++i) z[(size_t)t * d + i] = oracle_normal(seed, series, (uint32_t)t, (uint32_t)i);

@@ -1146,3 +1146,24 @@ def test_fused_call_without_filtered_output(eng, case):
     # not bit-identical on the packed path: it reads C_t as an exactly symmetric matrix from its lower triangle, the
     # dense records carry the two triangles as the forward pass rounded them
     np.testing.assert_allclose(only["smooth"], full["smooth"], rtol=1e-9, atol=1e-11)
+
+
+def test_simulate_on_device_matches_oracle_and_model(eng):
+    """dlm_simulate_batch (Dlm.simulateRegular, Dlm.scala:245-292): equals the oracle's restatement on the same Philox
+    stream (irregular grid, dense W and V, p = 2) and has the model's moments."""
+    rng = np.random.default_rng(6)
+    mod = Dlm.polynomial(2) * Dlm.polynomial(1)
+    mat = materialise(mod, np.cumsum(np.array([1, 2, 1, 0.5, 3] * 8, dtype=np.float64)))
+    B = rng.standard_normal((2, 2)); A = rng.standard_normal((3, 3))
+    p = DlmParameters(B @ B.T + np.eye(2), A @ A.T / 3 + 0.1 * np.eye(3), rng.standard_normal(3), np.eye(3) * 2.0)
+    out = eng.simulate(mat, p, 4, seed=21, series_offset=10)
+    assert eng.last_variant == "generic-simulate" and np.all(out["status"] == 0)
+    for n in range(4):
+        x, y = oracle.simulate(omodel(mat), p.v, p.w, p.m0, p.c0, 21, 10 + n)
+        np.testing.assert_allclose(out["x"][n], x, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(out["y"][n], y, rtol=1e-12, atol=1e-12)
+    # moments on a local level: Var(y_1) = C0 + W + V, Var(x_0) = C0
+    ll = materialise(Dlm.polynomial(1), np.arange(1, 4, dtype=np.float64))
+    big = eng.simulate(ll, DlmParameters([[2.0]], [[0.5]], [1.0], [[3.0]]), 20000, seed=3)
+    assert abs(big["x"][:, 0, 0].mean() - 1.0) < 0.05 and abs(big["x"][:, 0, 0].var() - 3.0) < 0.1
+    assert abs(big["y"][:, 0, 0].var() - 5.5) < 0.2

@@ -397,3 +397,24 @@ def test_ou_filter_closed_forms():
         else:
             k = r / (r + 0.7); m, c = a + k * (y[t] - a), k * 0.7
         assert f["m"][t + 1] == pytest.approx(m, rel=1e-13) and f["c"][t + 1] == pytest.approx(c, rel=1e-13)
+
+
+def test_simulate_moments_and_consistency():
+    """oracle.simulate (Dlm.simulateRegular, Dlm.scala:245-292): the recursion x_t = G x_{t-1} + L_w sqrt(dt) z,
+    y_t = F^T x_t + L_v z holds record by record against the Philox normals, and the moments are the model's."""
+    mod = Dlm.polynomial(2)
+    mat = materialise(mod, np.cumsum([1.0, 2.0, 0.5, 1.0, 3.0]))
+    W = np.array([[0.5, 0.1], [0.1, 0.3]]); V = np.array([[0.7]]); C0 = np.array([[2.0, 0.3], [0.3, 1.0]])
+    x, y = oracle.simulate(_omodel(mat), V, W, np.array([1.0, -1.0]), C0, 9, 4)
+    z = oracle.normals(9, 4, mat.T + 1, 3)       # [T+1][d+p]
+    np.testing.assert_allclose(x[0], np.array([1.0, -1.0]) + np.linalg.cholesky(C0) @ z[0, :2], atol=1e-13)
+    Lw, Lv = np.linalg.cholesky(W), np.linalg.cholesky(V)
+    for t in range(mat.T):
+        G = np.asarray(mat.G).reshape(-1, 2, 2)[mat.g_index[t] if mat.g_index is not None else 0].T   # column-major
+        xn = G @ x[t] + np.sqrt(mat.dt[t]) * (Lw @ z[t + 1, :2])
+        np.testing.assert_allclose(x[t + 1], xn, atol=1e-12)
+        Ft = mat.F.reshape(-1)[t * mat.f_stride:t * mat.f_stride + 2]
+        np.testing.assert_allclose(y[t], Ft @ xn + Lv @ z[t + 1, 2:3], atol=1e-12)
+    ll = materialise(Dlm.polynomial(1), np.arange(1, 3, dtype=np.float64))
+    ys = np.array([oracle.simulate(_omodel(ll), [[2.0]], [[0.5]], [1.0], [[3.0]], 1, n)[1][0, 0] for n in range(4000)])
+    assert abs(ys.mean() - 1.0) < 0.15 and abs(ys.var() - 5.5) < 0.5
