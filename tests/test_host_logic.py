@@ -196,3 +196,39 @@ def test_pooled_gibbs_two_ranks_gloo(tmp_path):
                                     n_iter=3, seed=11, pooled=True, ffbs=oracle_ffbs))
     ref = np.array([np.concatenate([np.diag(s.p.v), np.diag(s.p.w)]) for s in one])
     np.testing.assert_allclose(r0, ref, rtol=1e-9)
+
+
+def test_chain_and_data_csv_round_trip(tmp_path, golden_dir):
+    """streaming.py (Streaming.scala:25-78; FirstOrderDlm.scala:31-50): chains and simulated data survive the disk."""
+    from bayesian_dlms_amd import streaming
+    from bayesian_dlms_amd.dlm import DlmParameters
+    rng = np.random.default_rng(0)
+    chain = [DlmParameters(np.diag(rng.uniform(1, 2, 2)), np.diag(rng.uniform(1, 2, 3)), rng.standard_normal(3),
+                           np.diag(rng.uniform(1, 2, 3))) for _ in range(7)]
+    f = str(tmp_path / "chain.csv")
+    assert streaming.write_chain(lambda p: p.to_list(), f, iter(chain), header=["v1", "v2", "w1", "w2", "w3", "m1", "m2", "m3", "c1", "c2", "c3"]) == 7
+    rows = list(streaming.read_mcmc_chain(f))
+    assert len(rows) == 7
+    for p, row in zip(chain, rows):
+        assert row == [float(x) for x in p.to_list()]          # repr round-trips doubles exactly
+        q = DlmParameters.from_list(2, 3, row)
+        assert np.array_equal(q.v, p.v) and np.array_equal(q.w, p.w) and np.array_equal(q.c0, p.c0)
+    means = streaming.col_means(rows)
+    assert np.allclose(means, np.mean(rows, axis=0))
+    assert streaming.quantile([5.0, 1.0, 3.0, 2.0, 4.0], 0.5) == 3.0 and streaming.quantile([5.0, 1.0, 3.0, 2.0], 0.0) == 1.0
+    # parseDiagonalParameters keeps the full c0, column-major
+    c0 = np.array([[2.0, 0.5], [0.25, 1.0]])
+    p = streaming.parse_diagonal_parameters(1, 2, [3.0, 1.0, 2.0, 0.1, 0.2] + list(c0.T.reshape(-1)))
+    assert np.array_equal(p.c0, c0) and np.array_equal(p.w, np.diag([1.0, 2.0])) and p.v[0, 0] == 3.0
+    # the reference's fold starts from the empty parameter set with count 1: sum / (n + 1)
+    m = streaming.mean_parameters(iter(chain), 2, 3)
+    assert np.allclose(m.w, sum(c.w for c in chain) / 8)
+    # the examples' data file reads back as Data, and a written file has the same layout
+    data = streaming.read_data(os.path.join(golden_dir, "first_order_dlm.csv"))
+    assert len(data) == 1000 and data[0].time == 1.0 and data[0].observation[0] == -3.941883011167026
+    g = str(tmp_path / "sim.csv")
+    ys = np.array([[1.5], [np.nan], [2.5]]); xs = np.array([[0.1], [0.2], [0.3]])
+    streaming.write_simulated(g, [1.0, 2.0, 3.0], xs, ys)
+    assert open(g).readline().strip() == "time,observation,state"
+    back = streaming.read_data(g)
+    assert back[0].observation[0] == 1.5 and np.isnan(back[1].observation[0]) and back[2].time == 3.0
