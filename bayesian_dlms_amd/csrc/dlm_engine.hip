@@ -174,6 +174,7 @@ int analyse_g_tiled(dlm_engine* e, KArgs& k, const double* G_user, bool host_mod
   HIP_TRY(e, hipMemcpyAsync(e->spb_dev, tabs.data(), tabs.size() * sizeof(dlm::SparseBig), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));  // tabs lives on this stack frame
   k.spb = e->spb_dev;
+  k.spb_k = K;
   return DLM_OK;
 }
 

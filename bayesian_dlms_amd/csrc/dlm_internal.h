@@ -29,6 +29,7 @@ struct KArgs {
   int* status;
   int packed;          // structured d <= 15 fast path only: filt / filt_in hold PACKED records (engine-internal workspace)
   const struct SparseBig* spb;   // tiled path: [2 n_g] row / column tables of a structured G, or nullptr (dense G)
+  int spb_k;           // largest nonzero count per row / column over those tables (1..4)
   unsigned flags;
   unsigned long long seed, series_offset;
 };
@@ -78,6 +79,9 @@ bool tiled_supported(const KArgs& a);
 // innov [N][T][p] (nullable for the filter): innovations y_t - f_t (NaN = missing) handed from the forward to the backward pass
 hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s);
 hipError_t launch_tiled_smoother(const KArgs& a, const double* innov, hipStream_t s);
+// ---- one wavefront per series, register-resident tiles (structured G, 16 <= d <= 48), dlm_wave48.hip ----
+bool wave48_filter_supported(const KArgs& a);
+hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_t s);
 // simulation-smoother FFBS (forward SIM pass + mean-only backward pass); xplus [N][T+1][d], ystar [N][T][p]
 hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s);
 

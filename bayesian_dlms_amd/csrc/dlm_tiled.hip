@@ -19,6 +19,7 @@
 //   q_{t-1} = G^T [ q + F (u - K^T q) ],
 //   P_{t-1} = G^T [ P + F (Qm^-1 + K^T P K) F^T - F (P K)^T - (P K) F^T ] G,
 //   which needs no d x d solve and no R_{t+1}; only a p x p SPD inverse per distinct mask.
+#include <cstdlib>
 #include "dlm_internal.h"
 #include "../../include/dlm_engine.h"
 
@@ -1161,6 +1162,7 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 }
 
 hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s) {
+  if (wave48_filter_supported(a) && !getenv("DLM_NO_WAVE48")) return launch_wave48_filter(a, a.spb_k, innov, s);
   const size_t lds = tiled_filter_lds_bytes();
   hipError_t e = set_lds((const void*)k_filter_tiled<false>, lds);
   if (e != hipSuccess) return e;

@@ -1,0 +1,524 @@
+// One WAVEFRONT per series for 16 <= d <= 48, p <= 32 with a structured G: the whole step lives in the registers of one
+// wave, in the fp64 MFMA accumulator layout, tile by tile.
+//
+// dlm_tiled.hip gives a series a workgroup of 8 waves that cooperate through LDS operands: 10-14 barrier-separated
+// phases per step, each as long as its busiest SIMD (19 % of the fp64 MFMA peak at d = 40, p = 20,
+// profiles/r01_pmc_notes.md).  Here a matrix is an array of 16 x 16 tiles held by ONE wave (a 48 x 48 matrix is 72
+// VGPRs), and every product is X^T Y over tiles:  Z[a][b] = sum_k X[k][a]^T Y[k][b], where one
+// v_mfma_f64_16x16x4_f64 takes register r of an X tile as its A operand and register r of a Y tile as its B operand
+// (lane 16 g + c, register r holds element (4 r + g, c): as an A operand that is (rows 4r..4r+3)^T, as a B operand
+// rows 4r..4r+3).  No operand ever goes through LDS and no barrier is needed: four series per CU advance independently,
+// one per SIMD, and the matrix pipe sees back-to-back independent accumulators.  All matrices of the recursion are
+// symmetric or appear next to a symmetric factor, so X^T Y covers every product; the few genuine transposes (mirroring
+// the upper tiles of a symmetric result, S = R F -> S^T) and the gather congruence G C G^T go through one wave-private
+// LDS image with an odd leading dimension.
+//
+// Recursion (KalmanFilter.scala:64-118, 262-294), per step, with Fm = F with the columns of missing observations zeroed:
+//   a = G m, R = G C G^T + W dt        two gather passes with the row tables of G (sparse48_analyse)
+//   S = R Fm, f = F^T a, Q = Fm^T S + Vm   (Vm: V with unit rows/columns for the missing observations)
+//   Qi = Qm^-1                          Newton-Schulz from the previous step's inverse, direct Cholesky otherwise
+//   K^T = Qi S^T,  m' = a + K e,  C' = R - K S^T   (upper tiles, mirrored: exactly symmetric)
+#include "dlm_internal.h"
+#include "../../include/dlm_engine.h"
+
+namespace dlm {
+namespace w48 {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+constexpr int IL = 49;          // leading dimension of the LDS image (odd: row-wise and transposed reads both spread over the banks)
+constexpr int IMG = 48 * IL;
+constexpr int QL = 33;          // leading dimension of the p x p scratch of the direct inverse
+constexpr int OOB = 0x7ffffff0;
+constexpr int LDS_DOUBLES = IMG + 5 * 48;
+
+__device__ __forceinline__ void wave_sync() {   // LDS hand-off between lanes of one wave (in-order LDS queue)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double sum_g(double v) {   // sum over lanes c, c+16, c+32, c+48; all get it
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+  l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return __hiloint2double((int)v[1], (int)v[0]);
+}
+__device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x) {
+  const u2 v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+// Z[a][b] = sum_k X[k][a]^T Y[k][b] over the first `rows` rows of the operands (MFMAs of all-padding k-blocks are
+// skipped).  UP: only the tiles a <= b.  Consecutive MFMAs go to different accumulators.
+template <int KT, int MT, int NT, bool UP>
+__device__ __forceinline__ void mmT(const d4 (&X)[KT][MT], const d4 (&Y)[KT][NT], d4 (&Z)[MT][NT], int rows) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) Z[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * k + 4 * r < rows) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b)
+            if (!UP || a <= b) Z[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[k][a][r], Y[k][b][r], Z[a][b], 0, 0, 0);
+      }
+}
+
+// Complete a symmetric matrix from its upper tiles: lower tiles by transposition through the image, diagonal tiles
+// averaged with their own transposes (exactly symmetric result).  FULL: all tiles are given; every tile is averaged
+// with the transpose of its mirror tile instead.
+template <int MT, bool FULL>
+__device__ __forceinline__ void mirror(d4 (&Z)[MT][MT], double* img, int g, int c) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+      if (FULL || a <= b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) img[(16 * a + 4 * r + g) * IL + 16 * b + c] = Z[a][b][r];
+      }
+  wave_sync();
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      // element (4r+g, c) of tile (b, a) of the transpose = element (c, 4r+g) of tile (a, b)
+      if (FULL || a == b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[b][a][r] = 0.5 * (Z[b][a][r] + img[(16 * a + c) * IL + 16 * b + 4 * r + g]);
+      } else if (a < b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[b][a][r] = img[(16 * a + c) * IL + 16 * b + 4 * r + g];
+      }
+    }
+  wave_sync();
+}
+
+// ST = S^T for an (MT x NT)-tile matrix
+template <int MT, int NT>
+__device__ __forceinline__ void transpose(const d4 (&S)[MT][NT], d4 (&ST)[NT][MT], double* img, int g, int c) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(16 * a + 4 * r + g) * IL + 16 * b + c] = S[a][b][r];
+  wave_sync();
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ST[b][a][r] = img[(16 * a + c) * IL + 16 * b + 4 * r + g];
+  wave_sync();
+}
+
+// y[j] = sum_i M[i][j] x[i] for the lanes' columns j = 16 b + c (every g gets it); x is an LDS vector, zero beyond its length
+template <int KT, int NT>
+__device__ __forceinline__ void matTvec(const d4 (&M)[KT][NT], const double* x, int g, double (&y)[NT]) {
+  double xr[KT][4];
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xr[k][r] = x[16 * k + 4 * r + g];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = fma(M[k][b][r], xr[k][r], acc);
+    y[b] = sum_g(acc);
+  }
+}
+
+// Direct inverse of the SPD n x n matrix given as tiles (n <= 16 PT): Cholesky and n triangular solves by ONE wave in
+// the LDS image (fallback of the Newton-Schulz refinement: first step, changed missingness pattern).  Returns whether
+// a non-positive pivot was met.
+template <int PT>
+__device__ __forceinline__ bool direct_inverse(const d4 (&Q)[PT][PT], d4 (&X)[PT][PT], int n, double* img, int lane, int g, int c) {
+  double* L = img;              // n x n, row-major, leading dimension QL
+  double* B = img + 32 * QL;    // the inverse, column j by lane j
+#pragma unroll
+  for (int a = 0; a < PT; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[(16 * a + 4 * r + g) * QL + 16 * b + c] = Q[a][b][r];
+  wave_sync();
+  bool bad = false;
+  for (int k = 0; k < n; ++k) {
+    double akk = L[k * QL + k];
+    if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
+    const double lkk = sqrt(akk), inv = 1.0 / lkk;
+    wave_sync();
+    if (lane >= k && lane < n) L[lane * QL + k] = (lane == k) ? lkk : L[lane * QL + k] * inv;
+    wave_sync();
+    const int rr = n - k - 1;
+    for (int idx = lane; idx < rr * rr; idx += 64) {
+      const int i = k + 1 + idx % rr, j = k + 1 + idx / rr;
+      if (i >= j) L[i * QL + j] = fma(-L[i * QL + k], L[j * QL + k], L[i * QL + j]);
+    }
+    wave_sync();
+  }
+  if (lane < n) {   // (L L^T) x = e_lane
+    double* x = B + lane;   // x[i] at B[i * QL + lane]
+    for (int i = 0; i < n; ++i) {
+      double s = (i == lane) ? 1.0 : 0.0;
+      for (int l = 0; l < i; ++l) s = fma(-L[i * QL + l], x[l * QL], s);
+      x[i * QL] = s / L[i * QL + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = x[i * QL];
+      for (int l = i + 1; l < n; ++l) s = fma(-L[l * QL + i], x[l * QL], s);
+      x[i * QL] = s / L[i * QL + i];
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int a = 0; a < PT; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * a + 4 * r + g, j = 16 * b + c;
+        // symmetric by construction up to rounding: average the two triangles
+        X[a][b][r] = (i < n && j < n) ? 0.5 * (B[i * QL + j] + B[j * QL + i]) : 0.0;
+      }
+  wave_sync();
+  return bad;
+}
+
+// X <- (SPD Q)^-1 by Newton-Schulz refinement of the warm start X (E = I - Q X, X <- X + X E, kept exactly symmetric:
+// the antisymmetric part of the iterate is a neutral mode, see dlm_tiled.hip), direct inverse when the start is too far
+// off or 6 iterations do not reach max|E| <= 2e-10.  Returns whether the direct path met a non-positive pivot.
+template <int PT>
+__device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[PT][PT], int n, bool warm, double* img,
+                                                 int lane, int g, int c) {
+  const double tol = 2e-10;
+  bool done = false;
+  if (warm) {
+    for (int it = 0; it < 6 && !done; ++it) {
+      d4 E[PT][PT];
+      mmT<PT, PT, PT, false>(Q, X, E, n);
+      bool big = false, far = false;
+#pragma unroll
+      for (int a = 0; a < PT; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * a + 4 * r + g, j = 16 * b + c;
+            const double e = ((i == j) ? 1.0 : 0.0) - E[a][b][r];
+            E[a][b][r] = e;
+            if (i < n && j < n) { big |= !(fabs(e) <= tol); far |= !(fabs(e) * n < 0.5); }
+          }
+      const bool any_big = __ballot(big) != 0ull, any_far = __ballot(far) != 0ull;
+      if (any_far && any_big) break;
+      if (!any_big) done = true;   // the update below squares the residual: it lands on the fp64 floor
+      d4 D[PT][PT];
+      mmT<PT, PT, PT, false>(X, E, D, n);
+#pragma unroll
+      for (int a = 0; a < PT; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) X[a][b] += D[a][b];
+      mirror<PT, true>(X, img, g, c);
+    }
+  }
+  if (done) return false;
+  return direct_inverse<PT>(Q, X, n, img, lane, g, c);
+}
+
+// ---------------------------------------------------------------------------------------
+// forward pass
+// ---------------------------------------------------------------------------------------
+template <int DT, int PT, int K>
+__global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__ innov) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* img = sm;
+  double* mv = sm + IMG;   double* av = mv + 48;   double* ev = av + 48;   double* ob = ev + 48;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  int st = 0;
+  for (int i = lane; i < 5 * 48; i += 64) mv[i] = 0.0;
+
+  bool jd[DT], jp[PT];      // this lane's column 16 b + c lies inside d / p
+  int cpart[DT];            // byte offset of C[0][16 b + c] inside a record
+#pragma unroll
+  for (int b = 0; b < DT; ++b) { jd[b] = 16 * b + c < d; cpart[b] = (d + (16 * b + c) * d) * 8; }
+#pragma unroll
+  for (int b = 0; b < PT; ++b) jp[b] = 16 * b + c < p;
+
+  const double* V = a.V + (size_t)n * a.v_stride;
+  const double* W = a.W + (size_t)n * a.w_stride;
+  const double* C0 = a.C0 + (size_t)n * a.c0_stride;
+  d4 C[DT][DT], Wt[DT][DT], Vt[PT][PT], Ft[DT][PT], Qi[PT][PT];
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+        const bool in = i < d && jd[b];
+        C[aa][b][r] = in ? C0[i + j * d] : 0.0;
+        Wt[aa][b][r] = (in && aa <= b) ? W[i + j * d] : 0.0;
+      }
+#pragma unroll
+  for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+        Vt[aa][b][r] = (i < p && jp[b] && aa <= b) ? V[i + j * p] : 0.0;
+        Qi[aa][b][r] = 0.0;
+      }
+  auto load_F = [&](const double* F) {
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < PT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+          Ft[aa][b][r] = (i < d && jp[b]) ? F[i + j * d] : 0.0;
+        }
+  };
+  load_F(a.F);
+  int tix[DT][K];
+  double tvl[DT][K];
+  int gcur = -1;
+  auto load_tables = [&](int gi) {
+    const SparseBig* tab = a.spb + 2 * gi;     // the ROWS of G
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int s = 0; s < K; ++s) { tix[b][s] = tab->idx[16 * b + c][s]; tvl[b][s] = tab->val[16 * b + c][s]; }
+    gcur = gi;
+  };
+  load_tables(a.g_index ? a.g_index[0] : 0);
+  if (lane < d) mv[lane] = (a.m0 + (size_t)n * a.m0_stride)[lane];
+
+  double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;
+  const __amdgpu_buffer_rsrc_t rfo = mk_rsrc(out, out ? (size_t)(T + 1) * recb : 0);   // zero-sized: stores are dropped
+  const double* y = a.y + (size_t)n * T * p;
+  const __amdgpu_buffer_rsrc_t ry = mk_rsrc(y, (size_t)T * p * 8);
+  double* es = innov ? innov + (size_t)n * T * p : nullptr;
+  const __amdgpu_buffer_rsrc_t res = mk_rsrc(es, es ? (size_t)T * p * 8 : 0);
+  int yoff[PT], moff[DT];
+#pragma unroll
+  for (int b = 0; b < PT; ++b) yoff[b] = jp[b] ? (16 * b + c) * 8 : OOB;
+#pragma unroll
+  for (int b = 0; b < DT; ++b) moff[b] = (jd[b] && g == 0) ? (16 * b + c) * 8 : OOB;
+  wave_sync();
+
+  auto store_record = [&](int t) {
+    const int so = t * recb;
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g;
+          bst(rfo, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so, C[aa][b][r]);
+        }
+#pragma unroll
+    for (int b = 0; b < DT; ++b) bst(rfo, moff[b], so, mv[16 * b + c]);
+  };
+  store_record(0);
+
+  double ynext[PT];
+#pragma unroll
+  for (int b = 0; b < PT; ++b) ynext[b] = bld(ry, T > 0 ? yoff[b] : OOB, 0);
+  bool warm = false;
+
+  for (int t = 0; t < T; ++t) {
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    const int gi = a.g_index ? a.g_index[t] : 0;
+    if (gi != gcur) load_tables(gi);
+    if (a.f_stride) load_F(a.F + (size_t)t * a.f_stride);
+    double ycur[PT];
+#pragma unroll
+    for (int b = 0; b < PT; ++b) { ycur[b] = ynext[b]; ynext[b] = bld(ry, t + 1 < T ? yoff[b] : OOB, (t + 1 < T ? t + 1 : 0) * p * 8); }
+
+    // ---- advance: a = G m, R = G C G^T + W dt (into C's registers), dt == 0: identity
+    if (dt != 0.0) {
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = C[aa][b][r];
+      wave_sync();
+      {   // a[j] = sum_s m[idx_s(j)] val_s(j)
+        double an[DT];
+#pragma unroll
+        for (int b = 0; b < DT; ++b) {
+          double s_ = 0.0;
+#pragma unroll
+          for (int s = 0; s < K; ++s) s_ = fma(mv[tix[b][s]], tvl[b][s], s_);
+          an[b] = s_;
+        }
+#pragma unroll
+        for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) av[16 * b + c] = an[b];
+      }
+      // pass 1: Y[i][j] = sum_s C[i][idx_s(j)] val_s(j)   (= C G^T)
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double* row = img + (16 * aa + 4 * r + g) * IL;
+            double s_ = 0.0;
+#pragma unroll
+            for (int s = 0; s < K; ++s) s_ = fma(row[tix[b][s]], tvl[b][s], s_);
+            C[aa][b][r] = s_;
+          }
+      wave_sync();
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = C[aa][b][r];
+      wave_sync();
+      // pass 2 (upper tiles): R[i][j] = sum_s Y[idx_s(j)][i] val_s(j) + W[i][j] dt   (= (G Y)^T = G C G^T)
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = aa; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g;
+            double s_ = Wt[aa][b][r] * dt;
+#pragma unroll
+            for (int s = 0; s < K; ++s) s_ = fma(img[tix[b][s] * IL + i], tvl[b][s], s_);
+            C[aa][b][r] = s_;
+          }
+      wave_sync();
+      mirror<DT, false>(C, img, g, c);
+    } else {
+      if (lane < d) av[lane] = mv[lane];
+      wave_sync();
+    }
+    // (C now holds R)
+
+    // ---- forecast
+    double obs[PT];   // 1.0: component 16 b + c observed
+    bool anyobs = false;
+#pragma unroll
+    for (int b = 0; b < PT; ++b) { const bool o = jp[b] && (ycur[b] == ycur[b]); obs[b] = o ? 1.0 : 0.0; anyobs |= o; }
+    const bool any = __ballot(anyobs) != 0ull;
+    double fcol[PT];
+    matTvec<DT, PT>(Ft, av, g, fcol);
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const double e = ycur[b] - fcol[b];                       // NaN = missing
+      bst(res, g == 0 ? yoff[b] : OOB, t * p * 8, e);
+      if (g == 0) { ev[16 * b + c] = obs[b] != 0.0 ? e : 0.0; ob[16 * b + c] = obs[b]; }
+    }
+    wave_sync();
+
+    if (!any) {   // updateState without an observation: m = a, C = R
+      if (lane < d) mv[lane] = av[lane];
+    } else {
+      d4 Fm[DT][PT];
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) Fm[aa][b] = Ft[aa][b] * obs[b];
+      d4 S[DT][PT];
+      mmT<DT, DT, PT, false>(C, Fm, S, d);                       // R Fm (R symmetric)
+      d4 Q[PT][PT];
+      mmT<DT, PT, PT, true>(Fm, S, Q, d);                        // Fm^T R Fm, upper tiles
+#pragma unroll
+      for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+        for (int b = aa; b < PT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+            const double oi = ob[i];
+            Q[aa][b][r] += (oi != 0.0 && obs[b] != 0.0) ? Vt[aa][b][r] : ((i == j && jp[b]) ? 1.0 : 0.0);
+          }
+      mirror<PT, false>(Q, img, g, c);
+      // a warm start from a different missingness pattern is too far off anyway: the residual test sends it to the
+      // direct inverse
+      if (spd_inverse_warm<PT>(Q, Qi, p, warm, img, lane, g, c)) st |= DLM_ST_NOT_PD;
+      warm = true;
+      d4 ST[PT][DT];
+      transpose<DT, PT>(S, ST, img, g, c);
+      d4 KT[PT][DT];
+      mmT<PT, PT, DT, false>(Qi, ST, KT, p);                     // K^T = Qi S^T (Qi symmetric)
+      double kcol[DT];
+      matTvec<PT, DT>(KT, ev, g, kcol);                          // K e
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) mv[16 * b + c] = av[16 * b + c] + kcol[b];
+      d4 U[DT][DT];
+      mmT<PT, DT, DT, true>(KT, ST, U, p);                       // K S^T, upper tiles
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = aa; b < DT; ++b) C[aa][b] -= U[aa][b];
+      mirror<DT, false>(C, img, g, c);
+    }
+    wave_sync();
+    store_record(t + 1);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bad |= !isfinite(C[aa][b][r]);
+  if (lane < d) bad |= !isfinite(mv[lane]);
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+}  // namespace w48
+
+// The per-wave kernels take the structured-G models without per-step variance streams; the rest of the tiled feature
+// set (dense G, forecast / prior outputs, log-likelihood, V_t / W_t, simulation smoother) stays on dlm_tiled.hip.
+bool wave48_filter_supported(const KArgs& a) {
+  return tiled_supported(a) && a.spb && !a.fq && !a.prior && !a.loglik && !a.v_tstride && !a.w_tstride;
+}
+
+template <int DT, int PT>
+static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, hipStream_t s) {
+  const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
+  if (K <= 2) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, innov);
+  else hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
+  return hipGetLastError();
+}
+
+hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_t s) {
+  const bool d2 = a.d <= 32, p1 = a.p <= 16;
+  if (d2 && p1) return launch_w48_filter_k<2, 1>(a, K, innov, s);
+  if (d2) return launch_w48_filter_k<2, 2>(a, K, innov, s);
+  if (p1) return launch_w48_filter_k<3, 1>(a, K, innov, s);
+  return launch_w48_filter_k<3, 2>(a, K, innov, s);
+}
+
+}  // namespace dlm
