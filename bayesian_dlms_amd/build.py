@@ -8,8 +8,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdlm_engine.so")
 SOURCES = ["dlm_engine.hip", "dlm_generic.hip", "dlm_mfma16.hip", "dlm_sparse16.hip", "dlm_tiled.hip", "dlm_wave48.hip", "dlm_svd.hip", "dlm_ar1.hip", "dlm_gibbs.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# dlm_wave48.hip keeps whole matrices in registers (up to the 512-register budget of a wave): its accumulators may live
+# in AGPRs, and the VGPR-form rewrite pass of this compiler crashes on it
+FILE_FLAGS = {"dlm_wave48.hip": BASE_FLAGS}
 
 
 def _stale(target, deps):
@@ -22,9 +25,13 @@ def _stale(target, deps):
 def build_variant(name, defines):
     """Experimental build with extra -D flags -> bayesian_dlms_amd/libdlm_engine_<name>.so."""
     out = os.path.join(HERE, f"libdlm_engine_{name}.so")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-shared", "-o", out] + srcs + ["-L/opt/rocm/lib", "-lrccl"]
-    subprocess.check_call(cmd)
+    objs = []
+    os.makedirs(os.path.join(HERE, "build", name), exist_ok=True)
+    for src in SOURCES:
+        o = os.path.join(HERE, "build", name, src.replace(".hip", ".o"))
+        subprocess.check_call([HIPCC] + FILE_FLAGS.get(src, FLAGS) + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, src), "-o", o])
+        objs.append(o)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrccl"])
     return out
 
 
@@ -37,7 +44,7 @@ def build(force=False, verbose=False):
         o = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FILE_FLAGS.get(src, FLAGS) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

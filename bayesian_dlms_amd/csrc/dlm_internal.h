@@ -82,6 +82,8 @@ hipError_t launch_tiled_smoother(const KArgs& a, const double* innov, hipStream_
 // ---- one wavefront per series, register-resident tiles (structured G, 16 <= d <= 48), dlm_wave48.hip ----
 bool wave48_filter_supported(const KArgs& a);
 hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_t s);
+bool wave48_smoother_supported(const KArgs& a);
+hipError_t launch_wave48_smoother(const KArgs& a, int K, const double* innov, hipStream_t s);
 // simulation-smoother FFBS (forward SIM pass + mean-only backward pass); xplus [N][T+1][d], ystar [N][T][p]
 hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s);
 

@@ -31,7 +31,9 @@ constexpr int IL = 49;          // leading dimension of the LDS image (odd: row-
 constexpr int IMG = 48 * IL;
 constexpr int QL = 33;          // leading dimension of the p x p scratch of the direct inverse
 constexpr int OOB = 0x7ffffff0;
-constexpr int LDS_DOUBLES = IMG + 5 * 48;
+constexpr int FLD = 33;         // leading dimension of the LDS copy of F (d x p, row-major)
+constexpr int FIMG = 48 * FLD;
+constexpr int LDS_DOUBLES = IMG + FIMG + 10 * 48;
 
 __device__ __forceinline__ void wave_sync() {   // LDS hand-off between lanes of one wave (in-order LDS queue)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -149,6 +151,109 @@ __device__ __forceinline__ void matTvec(const d4 (&M)[KT][NT], const double* x, 
   }
 }
 
+
+// F (d x p) is kept in LDS, row-major with leading dimension FLD; both operand forms are read from there when a product
+// needs them (they would otherwise hold 96 registers for the whole step)
+template <int DT, int PT>
+__device__ __forceinline__ void f_tiles(const double* Fl, d4 (&Ft)[DT][PT], int g, int c) {      // F as [d-tiles][p-tiles]
+#pragma unroll
+  for (int a = 0; a < DT; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ft[a][b][r] = Fl[(16 * a + 4 * r + g) * FLD + 16 * b + c];
+}
+template <int DT, int PT>
+__device__ __forceinline__ void ft_tiles(const double* Fl, d4 (&FT)[PT][DT], int g, int c) {     // F^T as [p-tiles][d-tiles]
+#pragma unroll
+  for (int a = 0; a < PT; ++a)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) FT[a][b][r] = Fl[(16 * b + c) * FLD + 16 * a + 4 * r + g];
+}
+template <int DT, int PT>
+__device__ __forceinline__ void load_f_lds(double* Fl, const double* F, int d, int p, int lane) {   // F column-major d x p in global memory
+  for (int idx = lane; idx < 48 * 32; idx += 64) {
+    const int i = idx % 48, j = idx / 48;
+    Fl[i * FLD + j] = (i < d && j < p) ? F[i + j * d] : 0.0;
+  }
+}
+
+// Z = T X T^T (+ Wt dt on the upper tiles) for symmetric X, T given by the row tables (tix, tvl) of the lanes' columns:
+//   pass 1   Y[i][j] = sum_s X[i][idx_s(j)] val_s(j)          (= X T^T)
+//   pass 2   Z[i][j] = sum_s Y[idx_s(j)][i] val_s(j)          (= (T Y)^T = T X T^T), upper tiles, then mirrored
+template <int DT, int K, bool ADDW>
+__device__ __forceinline__ void congruence(d4 (&C)[DT][DT], const d4 (&Wt)[DT][DT], double dt, const int (&tix)[DT][K],
+                                           const double (&tvl)[DT][K], double* img, int g, int c) {
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = C[aa][b][r];
+  wave_sync();
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* row = img + (16 * aa + 4 * r + g) * IL;
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) s_ = fma(row[tix[b][s]], tvl[b][s], s_);
+        C[aa][b][r] = s_;
+      }
+  wave_sync();
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = C[aa][b][r];
+  wave_sync();
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = aa; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * aa + 4 * r + g;
+        double s_ = ADDW ? Wt[aa][b][r] * dt : 0.0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) s_ = fma(img[tix[b][s] * IL + i], tvl[b][s], s_);
+        C[aa][b][r] = s_;
+      }
+  wave_sync();
+  mirror<DT, false>(C, img, g, c);
+}
+// y[j] = sum_s x[idx_s(j)] val_s(j) for the lanes' columns (x: LDS vector)
+template <int DT, int K>
+__device__ __forceinline__ void gather_vec(const double* x, const int (&tix)[DT][K], const double (&tvl)[DT][K], double (&y)[DT]) {
+#pragma unroll
+  for (int b = 0; b < DT; ++b) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int s = 0; s < K; ++s) s_ = fma(x[tix[b][s]], tvl[b][s], s_);
+    y[b] = s_;
+  }
+}
+// Z[a][b] += sum_k X[k][a]^T Y[k][b] on the upper tiles
+template <int KT, int MT>
+__device__ __forceinline__ void mmT_acc_up(const d4 (&X)[KT][MT], const d4 (&Y)[KT][MT], d4 (&Z)[MT][MT], int rows) {
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * k + 4 * r < rows) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = a; b < MT; ++b) Z[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[k][a][r], Y[k][b][r], Z[a][b], 0, 0, 0);
+      }
+}
+
 // Direct inverse of the SPD n x n matrix given as tiles (n <= 16 PT): Cholesky and n triangular solves by ONE wave in
 // the LDS image (fallback of the Newton-Schulz refinement: first step, changed missingness pattern).  Returns whether
 // a non-positive pivot was met.
@@ -252,12 +357,12 @@ __device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[
 template <int DT, int PT, int K>
 __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* img = sm;
-  double* mv = sm + IMG;   double* av = mv + 48;   double* ev = av + 48;   double* ob = ev + 48;
+  double* img = sm;        double* Fl = sm + IMG;
+  double* mv = Fl + FIMG;  double* av = mv + 48;   double* ev = av + 48;   double* ob = ev + 48;
   const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
   int st = 0;
-  for (int i = lane; i < 5 * 48; i += 64) mv[i] = 0.0;
+  for (int i = lane; i < 10 * 48; i += 64) mv[i] = 0.0;
 
   bool jd[DT], jp[PT];      // this lane's column 16 b + c lies inside d / p
   int cpart[DT];            // byte offset of C[0][16 b + c] inside a record
@@ -269,7 +374,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
   const double* V = a.V + (size_t)n * a.v_stride;
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* C0 = a.C0 + (size_t)n * a.c0_stride;
-  d4 C[DT][DT], Wt[DT][DT], Vt[PT][PT], Ft[DT][PT], Qi[PT][PT];
+  d4 C[DT][DT], Wt[DT][DT], Vt[PT][PT], Qi[PT][PT];
 #pragma unroll
   for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
@@ -291,18 +396,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
         Vt[aa][b][r] = (i < p && jp[b] && aa <= b) ? V[i + j * p] : 0.0;
         Qi[aa][b][r] = 0.0;
       }
-  auto load_F = [&](const double* F) {
-#pragma unroll
-    for (int aa = 0; aa < DT; ++aa)
-#pragma unroll
-      for (int b = 0; b < PT; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
-          Ft[aa][b][r] = (i < d && jp[b]) ? F[i + j * d] : 0.0;
-        }
-  };
-  load_F(a.F);
+  load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
   int tix[DT][K];
   double tvl[DT][K];
   int gcur = -1;
@@ -330,7 +424,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
   for (int b = 0; b < DT; ++b) moff[b] = (jd[b] && g == 0) ? (16 * b + c) * 8 : OOB;
   wave_sync();
 
-  auto store_record = [&](int t) {
+  auto store_record = [&](int t, int g, int c) {
     const int so = t * recb;
 #pragma unroll
     for (int aa = 0; aa < DT; ++aa)
@@ -344,7 +438,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
 #pragma unroll
     for (int b = 0; b < DT; ++b) bst(rfo, moff[b], so, mv[16 * b + c]);
   };
-  store_record(0);
+  store_record(0, g, c);
 
   double ynext[PT];
 #pragma unroll
@@ -352,71 +446,27 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
   bool warm = false;
 
   for (int t = 0; t < T; ++t) {
+    // opaque copies of the lane coordinates: the compiler would otherwise hoist the few dozen address computations of
+    // the step out of the time loop and hold them in registers the matrices need
+    int g_ = g, c_ = c;
+    asm volatile("" : "+v"(g_), "+v"(c_));
+    {
+    const int g = g_, c = c_;
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
-    if (a.f_stride) load_F(a.F + (size_t)t * a.f_stride);
+    if (a.f_stride) { wave_sync(); load_f_lds<DT, PT>(Fl, a.F + (size_t)t * a.f_stride, d, p, lane); wave_sync(); }
     double ycur[PT];
 #pragma unroll
     for (int b = 0; b < PT; ++b) { ycur[b] = ynext[b]; ynext[b] = bld(ry, t + 1 < T ? yoff[b] : OOB, (t + 1 < T ? t + 1 : 0) * p * 8); }
 
     // ---- advance: a = G m, R = G C G^T + W dt (into C's registers), dt == 0: identity
     if (dt != 0.0) {
+      double an[DT];
+      gather_vec<DT, K>(mv, tix, tvl, an);                         // a = G m
 #pragma unroll
-      for (int aa = 0; aa < DT; ++aa)
-#pragma unroll
-        for (int b = 0; b < DT; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = C[aa][b][r];
-      wave_sync();
-      {   // a[j] = sum_s m[idx_s(j)] val_s(j)
-        double an[DT];
-#pragma unroll
-        for (int b = 0; b < DT; ++b) {
-          double s_ = 0.0;
-#pragma unroll
-          for (int s = 0; s < K; ++s) s_ = fma(mv[tix[b][s]], tvl[b][s], s_);
-          an[b] = s_;
-        }
-#pragma unroll
-        for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) av[16 * b + c] = an[b];
-      }
-      // pass 1: Y[i][j] = sum_s C[i][idx_s(j)] val_s(j)   (= C G^T)
-#pragma unroll
-      for (int aa = 0; aa < DT; ++aa)
-#pragma unroll
-        for (int b = 0; b < DT; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double* row = img + (16 * aa + 4 * r + g) * IL;
-            double s_ = 0.0;
-#pragma unroll
-            for (int s = 0; s < K; ++s) s_ = fma(row[tix[b][s]], tvl[b][s], s_);
-            C[aa][b][r] = s_;
-          }
-      wave_sync();
-#pragma unroll
-      for (int aa = 0; aa < DT; ++aa)
-#pragma unroll
-        for (int b = 0; b < DT; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = C[aa][b][r];
-      wave_sync();
-      // pass 2 (upper tiles): R[i][j] = sum_s Y[idx_s(j)][i] val_s(j) + W[i][j] dt   (= (G Y)^T = G C G^T)
-#pragma unroll
-      for (int aa = 0; aa < DT; ++aa)
-#pragma unroll
-        for (int b = aa; b < DT; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * aa + 4 * r + g;
-            double s_ = Wt[aa][b][r] * dt;
-#pragma unroll
-            for (int s = 0; s < K; ++s) s_ = fma(img[tix[b][s] * IL + i], tvl[b][s], s_);
-            C[aa][b][r] = s_;
-          }
-      wave_sync();
-      mirror<DT, false>(C, img, g, c);
+      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) av[16 * b + c] = an[b];
+      congruence<DT, K, true>(C, Wt, dt, tix, tvl, img, g, c);    // R = G C G^T + W dt
     } else {
       if (lane < d) av[lane] = mv[lane];
       wave_sync();
@@ -429,8 +479,10 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
 #pragma unroll
     for (int b = 0; b < PT; ++b) { const bool o = jp[b] && (ycur[b] == ycur[b]); obs[b] = o ? 1.0 : 0.0; anyobs |= o; }
     const bool any = __ballot(anyobs) != 0ull;
+    d4 Fm[DT][PT];
+    f_tiles<DT, PT>(Fl, Fm, g, c);
     double fcol[PT];
-    matTvec<DT, PT>(Ft, av, g, fcol);
+    matTvec<DT, PT>(Fm, av, g, fcol);
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
       const double e = ycur[b] - fcol[b];                       // NaN = missing
@@ -442,11 +494,10 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
     if (!any) {   // updateState without an observation: m = a, C = R
       if (lane < d) mv[lane] = av[lane];
     } else {
-      d4 Fm[DT][PT];
 #pragma unroll
       for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
-        for (int b = 0; b < PT; ++b) Fm[aa][b] = Ft[aa][b] * obs[b];
+        for (int b = 0; b < PT; ++b) Fm[aa][b] *= obs[b];
       d4 S[DT][PT];
       mmT<DT, DT, PT, false>(C, Fm, S, d);                       // R Fm (R symmetric)
       d4 Q[PT][PT];
@@ -483,7 +534,8 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
       mirror<DT, false>(C, img, g, c);
     }
     wave_sync();
-    store_record(t + 1);
+    store_record(t + 1, g, c);
+    }
   }
   bool bad = false;
 #pragma unroll
@@ -493,6 +545,234 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) bad |= !isfinite(C[aa][b][r]);
   if (lane < d) bad |= !isfinite(mv[lane]);
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// backward pass (information form, general p; Smoothing.scala:31-64 restated as in dlm_tiled.hip k_smoother_tiled):
+//   K = C F Vm^-1,  Qm^-1 = Vm^-1 - Vm^-1 F^T K                         (Vm^-1 cached while the missingness pattern repeats)
+//   s_t = m + C q,  S_t = C - C P C
+//   r = q + F (Qm^-1 e - K^T q),  M = P + F X F^T - F (P K)^T - (P K) F^T,  X = Qm^-1 + K^T P K
+//   q_{t-1} = G^T r,  P_{t-1} = G^T M G                                   (gathers with the COLUMN tables of G)
+// innov: e_t = y_t - f_t of the forward pass (NaN = missing), the observation of record t at innov[(t-1) p ..].
+// ---------------------------------------------------------------------------------------
+template <int DT, int PT, int K>
+__global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __restrict__ innov) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* img = sm;        double* Fl = sm + IMG;
+  double* mv = Fl + FIMG;  double* qv = mv + 48;   double* rv = qv + 48;   double* ev = rv + 48;   double* ob = ev + 48;
+  double* tv = ob + 48;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  int st = 0;
+  for (int i = lane; i < 10 * 48; i += 64) mv[i] = 0.0;
+
+  bool jd[DT], jp[PT];
+  int cpart[DT];
+#pragma unroll
+  for (int b = 0; b < DT; ++b) { jd[b] = 16 * b + c < d; cpart[b] = (d + (16 * b + c) * d) * 8; }
+#pragma unroll
+  for (int b = 0; b < PT; ++b) jp[b] = 16 * b + c < p;
+  const double* V = a.V + (size_t)n * a.v_stride;
+  load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
+
+  int tix[DT][K];
+  double tvl[DT][K];
+  int gcur = -1;
+  auto load_tables = [&](int gi) {
+    const SparseBig* tab = a.spb + 2 * gi + 1;     // the COLUMNS of G: rows of G^T
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int s = 0; s < K; ++s) { tix[b][s] = tab->idx[16 * b + c][s]; tvl[b][s] = tab->val[16 * b + c][s]; }
+    gcur = gi;
+  };
+
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rout = mk_rsrc(a.smooth + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rinn = mk_rsrc(innov + (size_t)n * T * p, (size_t)T * p * 8);
+  int eoff[PT], moff[DT];
+#pragma unroll
+  for (int b = 0; b < PT; ++b) eoff[b] = jp[b] ? (16 * b + c) * 8 : OOB;
+#pragma unroll
+  for (int b = 0; b < DT; ++b) moff[b] = jd[b] ? (16 * b + c) * 8 : OOB;
+
+  d4 C[DT][DT], P[DT][DT], Vi[PT][PT];
+  double mcol[DT], ecol[PT], obsP[PT];
+  auto request = [&](int t, int g, int c) {   // record t into C / mcol, the innovation of record t into ecol
+    const int so = t * recb;
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g;
+          C[aa][b][r] = bld(rin, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so);
+        }
+#pragma unroll
+    for (int b = 0; b < DT; ++b) mcol[b] = bld(rin, moff[b], so);
+#pragma unroll
+    for (int b = 0; b < PT; ++b) ecol[b] = bld(rinn, t > 0 ? eoff[b] : OOB, (t > 0 ? t - 1 : 0) * p * 8);
+  };
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b) P[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+    for (int b = 0; b < PT; ++b) Vi[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int b = 0; b < PT; ++b) obsP[b] = -1.0;
+  request(T, g, c);
+  wave_sync();
+
+  for (int t = T; t >= 0; --t) {
+    int g_ = g, c_ = c;   // opaque copies, see k_filter_w48
+    asm volatile("" : "+v"(g_), "+v"(c_));
+    {
+    const int g = g_, c = c_;
+    if (a.f_stride && t > 0) { wave_sync(); load_f_lds<DT, PT>(Fl, a.F + (size_t)(t - 1) * a.f_stride, d, p, lane); }
+    double obs[PT];
+    bool anyobs = false, changed = false;
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const bool o = t > 0 && jp[b] && (ecol[b] == ecol[b]);
+      obs[b] = o ? 1.0 : 0.0; anyobs |= o; changed |= jp[b] && obs[b] != obsP[b];
+      if (g == 0) { ev[16 * b + c] = o ? ecol[b] : 0.0; ob[16 * b + c] = obs[b]; }
+    }
+#pragma unroll
+    for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) mv[16 * b + c] = mcol[b];
+    const bool any = __ballot(anyobs) != 0ull;
+    wave_sync();
+
+    d4 Kg[DT][PT];
+    if (any) {
+      if (__ballot(changed) != 0ull) {   // Vm^-1 for this missingness pattern
+        d4 Vm[PT][PT];
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+              Vm[aa][b][r] = (i < p && jp[b]) ? ((ob[i] != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
+            }
+        if (direct_inverse<PT>(Vm, Vi, p, img, lane, g, c)) st |= DLM_ST_NOT_PD;
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (!(ob[16 * aa + 4 * r + g] != 0.0 && obs[b] != 0.0)) Vi[aa][b][r] = 0.0;
+#pragma unroll
+        for (int b = 0; b < PT; ++b) obsP[b] = obs[b];
+      }
+      d4 Ft[DT][PT], CFT[PT][DT];
+      f_tiles<DT, PT>(Fl, Ft, g, c);
+      mmT<DT, PT, DT, false>(Ft, C, CFT, d);                    // F^T C
+      mmT<PT, DT, PT, false>(CFT, Vi, Kg, p);                   // K = C F Vm^-1
+    }
+    // the products that need C come first: C, x1 and x2 are gone before the p-sized quantities are built
+    double cq[DT];
+    matTvec<DT, DT>(C, qv, g, cq);                              // C q
+    {
+      d4 x1[DT][DT], x2[DT][DT];
+      mmT<DT, DT, DT, false>(P, C, x1, d);                      // P C
+      mmT<DT, DT, DT, true>(C, x1, x2, d);                      // C P C, upper tiles
+      // s_t = m + C q ; S_t = C - C P C: an upper tile goes to both triangles of the record
+      const int so = t * recb;
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = aa; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+            const double v = C[aa][b][r] - x2[aa][b][r];
+            const bool in = i < d && jd[b];
+            bst(rout, in ? cpart[b] + i * 8 : OOB, so, v);
+            if (aa != b) bst(rout, in ? (d + j + i * d) * 8 : OOB, so, v);
+          }
+#pragma unroll
+      for (int b = 0; b < DT; ++b) bst(rout, g == 0 ? moff[b] : OOB, so, mcol[b] + cq[b]);
+    }
+    if (t == 0) break;
+    request(t - 1, g, c);   // C is free: the next record travels during the rest of the step
+
+    const int gi = a.g_index ? a.g_index[t - 1] : 0;   // G of the step INTO record t
+    if (gi != gcur) load_tables(gi);
+    if (any) {
+      d4 X[PT][PT], NPKT[PT][DT];
+      {
+        d4 Qi[PT][PT];
+        {
+          d4 Ft[DT][PT], X0[PT][PT];
+          f_tiles<DT, PT>(Fl, Ft, g, c);
+          mmT<DT, PT, PT, false>(Ft, Kg, X0, d);                // F^T K
+          mmT<PT, PT, PT, true>(Vi, X0, Qi, p);                 // Vm^-1 F^T K, upper tiles
+        }
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = aa; b < PT; ++b) Qi[aa][b] = Vi[aa][b] - Qi[aa][b];
+        mirror<PT, false>(Qi, img, g, c);                       // Qm^-1
+        double ucol[PT], ktq[PT];
+        matTvec<PT, PT>(Qi, ev, g, ucol);                       // u = Qm^-1 e
+        matTvec<DT, PT>(Kg, qv, g, ktq);                        // K^T q
+#pragma unroll
+        for (int b = 0; b < PT; ++b) if (g == 0) tv[16 * b + c] = jp[b] ? ucol[b] - ktq[b] : 0.0;
+        d4 PK[DT][PT];
+        mmT<DT, DT, PT, false>(P, Kg, PK, d);                   // P K
+        mmT<DT, PT, PT, true>(Kg, PK, X, d);                    // K^T P K, upper tiles
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = aa; b < PT; ++b) X[aa][b] += Qi[aa][b];
+        mirror<PT, false>(X, img, g, c);
+        transpose<DT, PT>(PK, NPKT, img, g, c);                 // (also publishes tv)
+      }
+#pragma unroll
+      for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b) NPKT[aa][b] = -NPKT[aa][b];
+      d4 FT[PT][DT];
+      ft_tiles<DT, PT>(Fl, FT, g, c);
+      double ftv[DT];
+      matTvec<PT, DT>(FT, tv, g, ftv);                          // F (u - K^T q)
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) rv[16 * b + c] = qv[16 * b + c] + ftv[b];
+      d4 FXT[PT][DT];
+      mmT<PT, PT, DT, false>(X, FT, FXT, p);                    // X F^T = (F X)^T
+      mmT_acc_up<PT, DT>(FXT, FT, P, p);                        // + (F X) F^T
+      mmT_acc_up<PT, DT>(FT, NPKT, P, p);                       // - F (P K)^T
+      mmT_acc_up<PT, DT>(NPKT, FT, P, p);                       // - (P K) F^T
+      // P's lower tiles are stale now: the congruence below reads the image written from the mirrored matrix
+      mirror<DT, false>(P, img, g, c);
+    } else {
+      if (lane < d) rv[lane] = qv[lane];
+    }
+    wave_sync();
+    double qn[DT];
+    gather_vec<DT, K>(rv, tix, tvl, qn);                        // q = G^T r
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) qv[16 * b + c] = qn[b];
+    congruence<DT, K, false>(P, P, 0.0, tix, tvl, img, g, c);   // P = G^T M G
+    }
+  }
+  bool bad = false;
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bad |= !isfinite(P[aa][b][r]);
+  if (lane < d) bad |= !isfinite(qv[lane]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
@@ -511,6 +791,24 @@ static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, hipS
   if (K <= 2) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, innov);
   else hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
   return hipGetLastError();
+}
+
+bool wave48_smoother_supported(const KArgs& a) { return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride; }
+
+template <int DT, int PT>
+static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {
+  const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
+  if (K <= 2) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, innov);
+  else hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
+  return hipGetLastError();
+}
+
+hipError_t launch_wave48_smoother(const KArgs& a, int K, const double* innov, hipStream_t s) {
+  const bool d2 = a.d <= 32, p1 = a.p <= 16;
+  if (d2 && p1) return launch_w48_smoother_k<2, 1>(a, K, innov, s);
+  if (d2) return launch_w48_smoother_k<2, 2>(a, K, innov, s);
+  if (p1) return launch_w48_smoother_k<3, 1>(a, K, innov, s);
+  return launch_w48_smoother_k<3, 2>(a, K, innov, s);
 }
 
 hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_t s) {
