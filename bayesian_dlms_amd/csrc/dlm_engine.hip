@@ -260,7 +260,7 @@ int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
       HIP_TRY(e, dlm::launch_mfma16_filter(k, side, e->stream));
     }
   } else if (use_tiled(k)) {
-    e->variant = "tiled-mfma";
+    e->variant = dlm::wave48_filter_supported(k) ? "wave-mfma" : "tiled-mfma";
     if (want_side) { int rc = ensure_ystar(e, k); if (rc) return rc; }
     HIP_TRY(e, dlm::launch_tiled_filter(k, want_side ? e->ystar : nullptr, e->stream));
   } else {
@@ -283,7 +283,7 @@ int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
       HIP_TRY(e, dlm::launch_mfma16_smoother(k, e->side, e->stream));
     }
   } else if (have_side && use_tiled(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1)) {
-    e->variant = "tiled-mfma";   // fused call only: the information-form pass takes the innovations of the forward pass
+    e->variant = dlm::wave48_smoother_supported(k) ? "wave-mfma" : "tiled-mfma";   // fused call only: the information-form pass takes the innovations of the forward pass
     HIP_TRY(e, dlm::launch_tiled_smoother(k, e->ystar, e->stream));
   } else {
     e->variant = "generic";

@@ -1162,7 +1162,7 @@ static hipError_t set_lds(const void* fn, size_t bytes) {
 }
 
 hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s) {
-  if (wave48_filter_supported(a) && !getenv("DLM_NO_WAVE48")) return launch_wave48_filter(a, a.spb_k, innov, s);
+  if (wave48_filter_supported(a)) return launch_wave48_filter(a, a.spb_k, innov, s);
   const size_t lds = tiled_filter_lds_bytes();
   hipError_t e = set_lds((const void*)k_filter_tiled<false>, lds);
   if (e != hipSuccess) return e;
@@ -1187,7 +1187,7 @@ hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, 
 }
 
 hipError_t launch_tiled_smoother(const KArgs& a, const double* innov, hipStream_t s) {
-  if (wave48_smoother_supported(a) && !getenv("DLM_NO_WAVE48")) return launch_wave48_smoother(a, a.spb_k, innov, s);
+  if (wave48_smoother_supported(a)) return launch_wave48_smoother(a, a.spb_k, innov, s);
   const size_t lds = tiled_smoother_lds_bytes();
   hipError_t e = set_lds((const void*)k_smoother_tiled, lds);
   if (e != hipSuccess) return e;

@@ -18,6 +18,7 @@
 //   S = R Fm, f = F^T a, Q = Fm^T S + Vm   (Vm: V with unit rows/columns for the missing observations)
 //   Qi = Qm^-1                          Newton-Schulz from the previous step's inverse, direct Cholesky otherwise
 //   K^T = Qi S^T,  m' = a + K e,  C' = R - K S^T   (upper tiles, mirrored: exactly symmetric)
+#include <cstdlib>
 #include "dlm_internal.h"
 #include "../../include/dlm_engine.h"
 
@@ -781,8 +782,9 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 
 // The per-wave kernels take the structured-G models without per-step variance streams; the rest of the tiled feature
 // set (dense G, forecast / prior outputs, log-likelihood, V_t / W_t, simulation smoother) stays on dlm_tiled.hip.
+// DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip (A/B measurements and the parity test of the two paths).
 bool wave48_filter_supported(const KArgs& a) {
-  return tiled_supported(a) && a.spb && !a.fq && !a.prior && !a.loglik && !a.v_tstride && !a.w_tstride;
+  return tiled_supported(a) && a.spb && !a.fq && !a.prior && !a.loglik && !a.v_tstride && !a.w_tstride && !getenv("DLM_NO_WAVE48");
 }
 
 template <int DT, int PT>
@@ -793,7 +795,7 @@ static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, hipS
   return hipGetLastError();
 }
 
-bool wave48_smoother_supported(const KArgs& a) { return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride; }
+bool wave48_smoother_supported(const KArgs& a) { return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && !getenv("DLM_NO_WAVE48"); }
 
 template <int DT, int PT>
 static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {

@@ -76,7 +76,7 @@ def test_c4_full_size_properties(eng):
     yh = rng.standard_normal((2000, 1000, 20)).cumsum(axis=1)
     yh[rng.random(yh.shape) < 0.02] = np.nan
     y = torch.as_tensor(yh, device="cuda")
-    _properties(eng, mat, p, y, [0, 1999, 777], "tiled-mfma", 1e-7, 1e-6)
+    _properties(eng, mat, p, y, [0, 1999, 777], "wave-mfma", 1e-7, 1e-6)
 
 
 def test_c5_full_size_svd_agrees_with_standard_filter(eng):
