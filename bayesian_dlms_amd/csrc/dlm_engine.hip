@@ -579,7 +579,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     }
     if (simflag && use_tiled(k)) {
       if ((rc = ensure_xplus(e, k)) || (rc = ensure_ystar(e, k))) return rc;
-      e->variant = "tiled-simsmooth";
+      e->variant = dlm::wave48_simsmooth_supported(k) ? "wave-simsmooth" : "tiled-simsmooth";
       HIP_TRY(e, dlm::launch_tiled_simsmooth(k, e->xplus, e->ystar, e->stream));
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }

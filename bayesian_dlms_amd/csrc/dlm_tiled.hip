@@ -1171,6 +1171,7 @@ hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s) {
 }
 
 hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s) {
+  if (wave48_simsmooth_supported(a)) return launch_wave48_simsmooth(a, a.spb_k, xplus, ystar, s);
   size_t lds = sizeof(double) * FILT_SIM_DOUBLES + 16;
   hipError_t e = set_lds((const void*)k_filter_tiled<true>, lds);
   if (e != hipSuccess) return e;

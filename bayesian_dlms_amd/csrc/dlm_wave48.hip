@@ -356,7 +356,7 @@ __device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[
 // forward pass
 // ---------------------------------------------------------------------------------------
 template <int DT, int PT, int K>
-__global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__ innov) {
+__global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int zero_m0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* img = sm;        double* Fl = sm + IMG;
   double* mv = Fl + FIMG;  double* av = mv + 48;   double* ev = av + 48;   double* ob = ev + 48;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* __restrict__
     gcur = gi;
   };
   load_tables(a.g_index ? a.g_index[0] : 0);
-  if (lane < d) mv[lane] = (a.m0 + (size_t)n * a.m0_stride)[lane];
+  if (lane < d) mv[lane] = zero_m0 ? 0.0 : (a.m0 + (size_t)n * a.m0_stride)[lane];   // zero_m0: the simulation smoother filters y* from a zero prior mean
 
   double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;
   const __amdgpu_buffer_rsrc_t rfo = mk_rsrc(out, out ? (size_t)(T + 1) * recb : 0);   // zero-sized: stores are dropped
@@ -778,24 +778,295 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// second half of the simulation smoother: mean-only backward pass on y*, theta = s* + x+, Gibbs statistics
+// (Gibbs.scala:23-78, GibbsWishart.scala:16-35) on the fly.  No covariance recursion:
+//   theta_t = m*_t + C_t q_t + x+_t
+//   q_{t-1} = G^T [ q + F (Qm^-1 e - K^T q) ],  K = C F Vm^-1,  Qm^-1 = Vm^-1 - Vm^-1 F^T K
+// innov: the innovations of the forward pass on y* (NaN = missing), record t at innov[(t-1) p ..].
+// ---------------------------------------------------------------------------------------
+template <int DT, int PT, int K>
+__global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __restrict__ xplus, const double* __restrict__ innov) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* img = sm;        double* Fl = sm + IMG;
+  double* qv = Fl + FIMG;  double* rv = qv + 48;   double* ev = rv + 48;   double* ob = ev + 48;
+  double* tv = ob + 48;    double* thc = tv + 48;  double* thn = thc + 48; double* dfv = thn + 48;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0, stats = a.stats != nullptr;
+  int st = 0;
+  for (int i = lane; i < 10 * 48; i += 64) qv[i] = 0.0;
+
+  bool jd[DT], jp[PT];
+  int cpart[DT];
+#pragma unroll
+  for (int b = 0; b < DT; ++b) { jd[b] = 16 * b + c < d; cpart[b] = (d + (16 * b + c) * d) * 8; }
+#pragma unroll
+  for (int b = 0; b < PT; ++b) jp[b] = 16 * b + c < p;
+  const double* V = a.V + (size_t)n * a.v_stride;
+  load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
+
+  int tix[DT][K], rix[DT][K];       // columns of G (q = G^T r) / rows of G (the system residual of the statistics)
+  double tvl[DT][K], rvl[DT][K];
+  int gcur = -1, rcur = -1;
+  auto load_cols = [&](int gi) {
+    const SparseBig* tab = a.spb + 2 * gi + 1;
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int s = 0; s < K; ++s) { tix[b][s] = tab->idx[16 * b + c][s]; tvl[b][s] = tab->val[16 * b + c][s]; }
+    gcur = gi;
+  };
+  auto load_rows = [&](int gi) {
+    const SparseBig* tab = a.spb + 2 * gi;
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int s = 0; s < K; ++s) { rix[b][s] = tab->idx[16 * b + c][s]; rvl[b][s] = tab->val[16 * b + c][s]; }
+    rcur = gi;
+  };
+#pragma unroll
+  for (int b = 0; b < DT; ++b)
+#pragma unroll
+    for (int s = 0; s < K; ++s) { rix[b][s] = 0; rvl[b][s] = 0.0; }
+
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rinn = mk_rsrc(innov + (size_t)n * T * p, (size_t)T * p * 8);
+  const __amdgpu_buffer_rsrc_t rxp = mk_rsrc(xplus + (size_t)n * (T + 1) * d, (size_t)(T + 1) * d * 8);
+  const __amdgpu_buffer_rsrc_t ryo = mk_rsrc(a.y + (size_t)n * T * p, (size_t)T * p * 8);
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  const __amdgpu_buffer_rsrc_t rth = mk_rsrc(thout, thout ? (size_t)(T + 1) * d * 8 : 0);
+  int eoff[PT], moff[DT];
+#pragma unroll
+  for (int b = 0; b < PT; ++b) eoff[b] = jp[b] ? (16 * b + c) * 8 : OOB;
+#pragma unroll
+  for (int b = 0; b < DT; ++b) moff[b] = jd[b] ? (16 * b + c) * 8 : OOB;
+
+  d4 C[DT][DT], Vi[PT][PT], OUT[DT][DT];
+  double mcol[DT], xcol[DT], ecol[PT], ycol[PT], obsP[PT], ssd[DT], ssy[PT], nob[PT];
+  auto request = [&](int t, int g, int c) {   // record t, x+_t, innovation and original observation of record t
+    const int so = t * recb;
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g;
+          C[aa][b][r] = bld(rin, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so);
+        }
+#pragma unroll
+    for (int b = 0; b < DT; ++b) { mcol[b] = bld(rin, moff[b], so); xcol[b] = bld(rxp, moff[b], t * d * 8); }
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      ecol[b] = bld(rinn, t > 0 ? eoff[b] : OOB, (t > 0 ? t - 1 : 0) * p * 8);
+      ycol[b] = bld(ryo, t > 0 ? eoff[b] : OOB, (t > 0 ? t - 1 : 0) * p * 8);
+    }
+  };
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b) OUT[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+    for (int b = 0; b < PT; ++b) Vi[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int b = 0; b < PT; ++b) { obsP[b] = -1.0; ssy[b] = 0.0; nob[b] = 0.0; }
+#pragma unroll
+  for (int b = 0; b < DT; ++b) ssd[b] = 0.0;
+  request(T, g, c);
+  wave_sync();
+
+  for (int t = T; t >= 0; --t) {
+    int g_ = g, c_ = c;   // opaque copies, see k_filter_w48
+    asm volatile("" : "+v"(g_), "+v"(c_));
+    {
+    const int g = g_, c = c_;
+    if (a.f_stride && t > 0) { wave_sync(); load_f_lds<DT, PT>(Fl, a.F + (size_t)(t - 1) * a.f_stride, d, p, lane); }
+    double obs[PT];
+    bool anyobs = false, changed = false;
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const bool o = t > 0 && jp[b] && (ecol[b] == ecol[b]);
+      obs[b] = o ? 1.0 : 0.0; anyobs |= o; changed |= jp[b] && obs[b] != obsP[b];
+      if (g == 0) { ev[16 * b + c] = o ? ecol[b] : 0.0; ob[16 * b + c] = obs[b]; }
+    }
+    const bool any = __ballot(anyobs) != 0ull;
+    // theta_t = m*_t + C_t q_t + x+_t
+    double cq[DT], th[DT];
+    matTvec<DT, DT>(C, qv, g, cq);
+#pragma unroll
+    for (int b = 0; b < DT; ++b) {
+      th[b] = mcol[b] + cq[b] + xcol[b];
+      bst(rth, g == 0 ? moff[b] : OOB, t * d * 8, th[b]);
+      if (g == 0 && jd[b]) thc[16 * b + c] = th[b];
+    }
+    wave_sync();
+    d4 Ft[DT][PT];
+    if (any || stats) f_tiles<DT, PT>(Fl, Ft, g, c);
+    if (stats) {
+      if (t < T) {   // system residual theta_{t+1} - G_{t+1} theta_t, scaled by 1 / sqrt(dt)
+        const int gn = a.g_index ? a.g_index[t] : 0;
+        const double dtn = a.dt ? a.dt[t] : 1.0;
+        if (gn != rcur) load_rows(gn);
+        double gth[DT];
+        gather_vec<DT, K>(thc, rix, rvl, gth);
+        const double dts = (dtn == 0.0) ? 1.0 : dtn, isd = 1.0 / sqrt(dts);
+#pragma unroll
+        for (int b = 0; b < DT; ++b) {
+          const double s_ = jd[b] ? thn[16 * b + c] - (dtn == 0.0 ? th[b] : gth[b]) : 0.0;
+          ssd[b] = fma(s_, s_ / dts, ssd[b]);
+          if (g == 0) dfv[16 * b + c] = s_ * isd;
+        }
+        if (outer) {
+          wave_sync();
+#pragma unroll
+          for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double di = dfv[16 * aa + 4 * r + g];
+#pragma unroll
+              for (int b = 0; b < DT; ++b) OUT[aa][b][r] = fma(di, dfv[16 * b + c], OUT[aa][b][r]);
+            }
+        }
+      }
+      if (t > 0) {   // observation residual of theta_t against the ORIGINAL y_t
+        double fth[PT];
+        matTvec<DT, PT>(Ft, thc, g, fth);
+#pragma unroll
+        for (int b = 0; b < PT; ++b)
+          if (jp[b] && ycol[b] == ycol[b]) { const double r_ = ycol[b] - fth[b]; ssy[b] = fma(r_, r_, ssy[b]); nob[b] += 1.0; }
+      }
+    }
+    wave_sync();
+    if (lane < d) thn[lane] = thc[lane];
+    if (t == 0) break;
+
+    const int gi = a.g_index ? a.g_index[t - 1] : 0;   // G of the step INTO record t
+    const double dtt = a.dt ? a.dt[t - 1] : 1.0;
+    if (gi != gcur) load_cols(gi);
+    if (any) {
+      if (__ballot(changed) != 0ull) {   // Vm^-1 for this missingness pattern
+        d4 Vm[PT][PT];
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+              Vm[aa][b][r] = (i < p && jp[b]) ? ((ob[i] != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
+            }
+        if (direct_inverse<PT>(Vm, Vi, p, img, lane, g, c)) st |= DLM_ST_NOT_PD;
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (!(ob[16 * aa + 4 * r + g] != 0.0 && obs[b] != 0.0)) Vi[aa][b][r] = 0.0;
+#pragma unroll
+        for (int b = 0; b < PT; ++b) obsP[b] = obs[b];
+      }
+      d4 Kg[DT][PT];
+      {
+        d4 CFT[PT][DT];
+        mmT<DT, PT, DT, false>(Ft, C, CFT, d);                  // F^T C
+        request(t - 1, g, c);                                   // C is free
+        mmT<PT, DT, PT, false>(CFT, Vi, Kg, p);                 // K = C F Vm^-1
+      }
+      d4 Qi[PT][PT];
+      {
+        d4 X0[PT][PT];
+        mmT<DT, PT, PT, false>(Ft, Kg, X0, d);                  // F^T K
+        mmT<PT, PT, PT, true>(Vi, X0, Qi, p);
+      }
+#pragma unroll
+      for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+        for (int b = aa; b < PT; ++b) Qi[aa][b] = Vi[aa][b] - Qi[aa][b];
+      mirror<PT, false>(Qi, img, g, c);                         // Qm^-1
+      double ucol[PT], ktq[PT];
+      matTvec<PT, PT>(Qi, ev, g, ucol);                         // Qm^-1 e
+      matTvec<DT, PT>(Kg, qv, g, ktq);                          // K^T q
+#pragma unroll
+      for (int b = 0; b < PT; ++b) if (g == 0) tv[16 * b + c] = jp[b] ? ucol[b] - ktq[b] : 0.0;
+      wave_sync();
+      d4 FT[PT][DT];
+      ft_tiles<DT, PT>(Fl, FT, g, c);
+      double ftv[DT];
+      matTvec<PT, DT>(FT, tv, g, ftv);                          // F (Qm^-1 e - K^T q)
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) rv[16 * b + c] = qv[16 * b + c] + ftv[b];
+    } else {
+      request(t - 1, g, c);
+      if (lane < d) rv[lane] = qv[lane];
+    }
+    wave_sync();
+    if (dtt != 0.0) {
+      double qn[DT];
+      gather_vec<DT, K>(rv, tix, tvl, qn);                      // q = G^T r
+      wave_sync();
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) qv[16 * b + c] = qn[b];
+    } else {
+      if (lane < d) qv[lane] = rv[lane];
+    }
+    wave_sync();
+    }
+  }
+  bool bad = (lane < d) && !isfinite(thn[lane]);
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (stats) {
+    const int L = stats_len(d, p, a.flags);
+    double* so = a.stats + (size_t)n * L;
+#pragma unroll
+    for (int b = 0; b < PT; ++b) if (g == 0 && jp[b]) { so[16 * b + c] = ssy[b]; so[p + 16 * b + c] = nob[b]; }
+    if (outer) {
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+            if (i < d && jd[b]) so[2 * p + i + j * d] = OUT[aa][b][r];
+          }
+    } else {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) so[2 * p + 16 * b + c] = ssd[b];
+    }
+    if (lane == 0) so[L - 1] = (double)T;
+  }
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
 }  // namespace w48
 
 // The per-wave kernels take the structured-G models without per-step variance streams; the rest of the tiled feature
 // set (dense G, forecast / prior outputs, log-likelihood, V_t / W_t, simulation smoother) stays on dlm_tiled.hip.
-// DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip (A/B measurements and the parity test of the two paths).
+// One wave per series needs more series than the chip has SIMDs to pay off: up to one series per CU (N <= 256) the
+// workgroup-per-series kernels of dlm_tiled.hip finish a step sooner (10.8 against 13 us at d = 40, p = 20).
+// DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip, DLM_FORCE_WAVE48 lifts the batch-size rule (A/B
+// measurements and the parity tests of the two paths).
+static bool wave48_wanted(const KArgs& a) {
+  if (getenv("DLM_NO_WAVE48")) return false;
+  return a.N > 256 || getenv("DLM_FORCE_WAVE48");
+}
 bool wave48_filter_supported(const KArgs& a) {
-  return tiled_supported(a) && a.spb && !a.fq && !a.prior && !a.loglik && !a.v_tstride && !a.w_tstride && !getenv("DLM_NO_WAVE48");
+  return tiled_supported(a) && a.spb && !a.fq && !a.prior && !a.loglik && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
 }
 
 template <int DT, int PT>
-static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, hipStream_t s) {
+static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, int zero_m0, hipStream_t s) {
   const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
-  if (K <= 2) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, innov);
-  else hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
+  if (K <= 2) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
+  else hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
   return hipGetLastError();
 }
 
-bool wave48_smoother_supported(const KArgs& a) { return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && !getenv("DLM_NO_WAVE48"); }
+bool wave48_smoother_supported(const KArgs& a) { return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a); }
 
 template <int DT, int PT>
 static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {
@@ -813,12 +1084,44 @@ hipError_t launch_wave48_smoother(const KArgs& a, int K, const double* innov, hi
   return launch_w48_smoother_k<3, 2>(a, K, innov, s);
 }
 
-hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_t s) {
+static hipError_t launch_wave48_filter_z(const KArgs& a, int K, double* innov, int zero_m0, hipStream_t s) {
   const bool d2 = a.d <= 32, p1 = a.p <= 16;
-  if (d2 && p1) return launch_w48_filter_k<2, 1>(a, K, innov, s);
-  if (d2) return launch_w48_filter_k<2, 2>(a, K, innov, s);
-  if (p1) return launch_w48_filter_k<3, 1>(a, K, innov, s);
-  return launch_w48_filter_k<3, 2>(a, K, innov, s);
+  if (d2 && p1) return launch_w48_filter_k<2, 1>(a, K, innov, zero_m0, s);
+  if (d2) return launch_w48_filter_k<2, 2>(a, K, innov, zero_m0, s);
+  if (p1) return launch_w48_filter_k<3, 1>(a, K, innov, zero_m0, s);
+  return launch_w48_filter_k<3, 2>(a, K, innov, zero_m0, s);
+}
+hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_t s) { return launch_wave48_filter_z(a, K, innov, 0, s); }
+
+// Durbin-Koopman simulation smoother (FFBS draw + Gibbs statistics): the prologue simulates (x+, y+) and leaves
+// y* = y - y+ in `ystar`; the forward pass filters y* from a zero prior mean and overwrites y*_t by its innovation (it has
+// read y*_{t+1} by then); the mean-only backward pass adds x+.
+bool wave48_simsmooth_supported(const KArgs& a) {
+  return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && !a.cond && wave48_wanted(a);
+}
+
+template <int DT, int PT>
+static hipError_t launch_w48_sims_k(const KArgs& a, int K, const double* xplus, const double* innov, hipStream_t s) {
+  const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
+  if (K <= 2) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+  else hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+  return hipGetLastError();
+}
+
+hipError_t launch_wave48_simsmooth(const KArgs& a, int K, double* xplus, double* ystar, hipStream_t s) {
+  hipError_t e = launch_simsmooth_prologue(a, xplus, ystar, s);
+  if (e != hipSuccess) return e;
+  KArgs f = a;
+  f.y = ystar; f.z = nullptr; f.theta = nullptr; f.stats = nullptr; f.fq = nullptr; f.prior = nullptr; f.loglik = nullptr;
+  e = launch_wave48_filter_z(f, K, ystar, 1, s);
+  if (e != hipSuccess) return e;
+  KArgs b = a;
+  b.filt_in = a.filt;
+  const bool d2 = a.d <= 32, p1 = a.p <= 16;
+  if (d2 && p1) return launch_w48_sims_k<2, 1>(b, K, xplus, ystar, s);
+  if (d2) return launch_w48_sims_k<2, 2>(b, K, xplus, ystar, s);
+  if (p1) return launch_w48_sims_k<3, 1>(b, K, xplus, ystar, s);
+  return launch_w48_sims_k<3, 2>(b, K, xplus, ystar, s);
 }
 
 }  // namespace dlm

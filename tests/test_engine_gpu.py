@@ -753,7 +753,15 @@ def test_ffbs_simulation_smoother_multivariate(eng):
     om = omodel(mat)
     for flags in (_lib.OPT_FFBS_SIMSMOOTH, _lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_STATS_OUTER):
         out = eng.ffbs(mat, p, y, z=z, flags=flags)
-        assert eng.last_variant == "tiled-simsmooth" and np.all(out["status"] == 0)
+        assert eng.last_variant == "wave-simsmooth" and np.all(out["status"] == 0)   # structured G: dlm_wave48.hip
+        os.environ["DLM_NO_WAVE48"] = "1"
+        try:
+            old = eng.ffbs(mat, p, y, z=z, flags=flags)
+            assert eng.last_variant == "tiled-simsmooth"
+        finally:
+            del os.environ["DLM_NO_WAVE48"]
+        np.testing.assert_allclose(out["theta"], old["theta"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(out["stats"], old["stats"], rtol=1e-7, atol=1e-8)
         for n in range(N):
             ref = dk_reference_draw_mv(mat, p, y[n], z[n])
             np.testing.assert_allclose(out["theta"][n], ref, rtol=1e-6, atol=1e-7)
@@ -767,6 +775,19 @@ def test_ffbs_simulation_smoother_multivariate(eng):
     out = eng.ffbs(mat, p, y, seed=11, series_offset=4, flags=_lib.OPT_FFBS_SIMSMOOTH)
     zz = oracle.normals(11, 4 + 2, T + 1, d + q)
     np.testing.assert_allclose(out["theta"][2], dk_reference_draw_mv(mat, p, y[2], zz), rtol=1e-6, atol=1e-7)
+    # irregular grid with a repeated time (several G tables, W dt, the dt = 0 identity advance): both implementations
+    mat2 = materialise(mod, np.cumsum(np.array([1, 1, 2, 0, 3, 1] * 8, dtype=np.float64)) + 1.0)
+    y2 = rng.standard_normal((N, mat2.T, q)).cumsum(axis=1)
+    y2[rng.random(y2.shape) < 0.1] = np.nan
+    new2 = eng.ffbs(mat2, p, y2, seed=5, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_STATS_OUTER)
+    assert eng.last_variant == "wave-simsmooth"
+    os.environ["DLM_NO_WAVE48"] = "1"
+    try:
+        old2 = eng.ffbs(mat2, p, y2, seed=5, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_STATS_OUTER)
+    finally:
+        del os.environ["DLM_NO_WAVE48"]
+    np.testing.assert_allclose(new2["theta"], old2["theta"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(new2["stats"], old2["stats"], rtol=1e-7, atol=1e-8)
 
 
 # ------------------------------------------------------------------------------------------

@@ -54,6 +54,18 @@ def main():
             dt = timeit(lambda: eng.ffbs(mat, p, y, seed=1, want_theta=False, flags=_lib.OPT_STATS_OUTER | fl), reps=1)
             print(json.dumps({"config": f"C4 FFBS + outer-product stats ({name}), d=40, p=20, N=256, T=200", "variant": eng.last_variant,
                               "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "c4gibbs" in which:   # the named C4 configuration: 2000 series, simulation-smoother FFBS + Inverse-Wishart statistics
+        from bayesian_dlms_amd import _lib
+        mod = Dlm.polynomial(2)
+        for _ in range(19): mod = mod * Dlm.polynomial(2)
+        N, T = 2000, 1000
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        rng = np.random.default_rng(40); A = rng.standard_normal((40, 40))
+        p = DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
+        y = torch.as_tensor(rng.standard_normal((N, T, 20)).cumsum(axis=1), device=dev)
+        dt = timeit(lambda: eng.ffbs(mat, p, y, seed=1, want_theta=False, flags=_lib.OPT_STATS_OUTER | _lib.OPT_FFBS_SIMSMOOTH), reps=2)
+        print(json.dumps({"config": "C4 FFBS + outer-product stats (simulation smoother), d=40, p=20, N=2000, T=1000", "variant": eng.last_variant,
+                          "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
     if "c2s" in which:
         mod, p = seasonal_c2(); N, T = 10000, 1000
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
