@@ -24,6 +24,7 @@ struct dlm_engine {
   bool timed = false;
   dlm::SparseT* sp_dev = nullptr;  // [2 n_g]: row table, column table of every G (structured fast path)
   dlm::SparseBig* spb_dev = nullptr;   // the same for the tiled path (d up to 48)
+  dlm::SparseF* spf_dev = nullptr;     // tables of a structured F (tiled path)
   size_t spb_count = 0;
   size_t sp_count = 0;
   int sparse_k = 0;           // 0: some G is not structured (dense MFMA path, regular grids only)
@@ -175,6 +176,20 @@ int analyse_g_tiled(dlm_engine* e, KArgs& k, const double* G_user, bool host_mod
   HIP_TRY(e, hipStreamSynchronize(e->stream));  // tabs lives on this stack frame
   k.spb = e->spb_dev;
   k.spb_k = K;
+  k.spf = nullptr;
+  if (!k.f_stride) {   // a time-invariant F: its few nonzeros per column / row turn the products with F into gathers
+    std::vector<double> f((size_t)k.d * k.p);
+    HIP_TRY(e, hipMemcpyAsync(f.data(), k.F, f.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    dlm::SparseF tf;
+    const int kf = dlm::sparsef_analyse(f.data(), k.d, k.p, &tf);
+    if (kf <= 4) {
+      if (!e->spf_dev) HIP_TRY(e, hipMalloc((void**)&e->spf_dev, sizeof(dlm::SparseF)));
+      HIP_TRY(e, hipMemcpyAsync(e->spf_dev, &tf, sizeof(tf), hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      k.spf = e->spf_dev; k.spf_k = kf;
+    }
+  }
   return DLM_OK;
 }
 
@@ -326,6 +341,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->sp_dev) (void)hipFree(e->sp_dev);
   if (e->fws) (void)hipFree(e->fws);
   if (e->spb_dev) (void)hipFree(e->spb_dev);
+  if (e->spf_dev) (void)hipFree(e->spf_dev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;

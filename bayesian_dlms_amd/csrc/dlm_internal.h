@@ -30,6 +30,8 @@ struct KArgs {
   int packed;          // structured d <= 15 fast path only: filt / filt_in hold PACKED records (engine-internal workspace)
   const struct SparseBig* spb;   // tiled path: [2 n_g] row / column tables of a structured G, or nullptr (dense G)
   int spb_k;           // largest nonzero count per row / column over those tables (1..4)
+  const struct SparseF* spf;     // structured (time-invariant) F of the tiled path: column / row tables, or nullptr
+  int spf_k;           // largest nonzero count per column / row of F (1..4)
   unsigned flags;
   unsigned long long seed, series_offset;
 };
@@ -77,6 +79,11 @@ hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_d
 // dense MFMA products.  sparse48_analyse returns the largest count, or 99 if G is not that sparse.
 struct SparseBig { int K; int pad; int idx[48][4]; double val[48][4]; };
 int sparse48_analyse(const double* G_host, int d, SparseBig* rows, SparseBig* cols);
+// The same for the observation matrix F (d x p): block models composed with |*| (Dlm.scala:197-208) have one component's
+// few nonzeros in every column.  cidx/cval: nonzeros of column j (states loading on observation j); ridx/rval: nonzeros of
+// row i (observations state i loads on).  sparsef_analyse returns the largest count, or 99 if F is not that sparse.
+struct SparseF { int K; int pad; int cidx[32][4]; double cval[32][4]; int ridx[48][4]; double rval[48][4]; };
+int sparsef_analyse(const double* F_host, int d, int p, SparseF* out);
 bool tiled_supported(const KArgs& a);
 // innov [N][T][p] (nullable for the filter): innovations y_t - f_t (NaN = missing) handed from the forward to the backward pass
 hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s);

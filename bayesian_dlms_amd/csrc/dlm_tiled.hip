@@ -579,6 +579,30 @@ int sparse48_analyse(const double* G /* d x d column-major, host */, int d, Spar
   return kmax;
 }
 
+int sparsef_analyse(const double* F /* d x p column-major, host */, int d, int p, SparseF* out) {
+  int kmax = 1;
+  for (int j = 0; j < 32; ++j) for (int s = 0; s < 4; ++s) { out->cidx[j][s] = 0; out->cval[j][s] = 0.0; }
+  for (int i = 0; i < 48; ++i) for (int s = 0; s < 4; ++s) { out->ridx[i][s] = 0; out->rval[i][s] = 0.0; }
+  for (int j = 0; j < p; ++j) {
+    int cnt = 0;
+    for (int i = 0; i < d; ++i) {
+      const double v = F[i + j * d];
+      if (v != 0.0) { if (cnt == 4) return 99; out->cidx[j][cnt] = i; out->cval[j][cnt] = v; ++cnt; }
+    }
+    if (cnt > kmax) kmax = cnt;
+  }
+  for (int i = 0; i < d; ++i) {
+    int cnt = 0;
+    for (int j = 0; j < p; ++j) {
+      const double v = F[i + j * d];
+      if (v != 0.0) { if (cnt == 4) return 99; out->ridx[i][cnt] = j; out->rval[i][cnt] = v; ++cnt; }
+    }
+    if (cnt > kmax) kmax = cnt;
+  }
+  out->K = kmax; out->pad = 0;
+  return kmax;
+}
+
 bool tiled_supported(const KArgs& a) {   // records are addressed through 32-bit buffer offsets: < 2 GiB per series
   return a.d >= 16 && a.d <= 48 && a.p <= 32 && ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);
 }

@@ -87,7 +87,7 @@ __device__ __forceinline__ void mmT(const d4 (&X)[KT][MT], const d4 (&Y)[KT][NT]
 // Complete a symmetric matrix from its upper tiles: lower tiles by transposition through the image, diagonal tiles
 // averaged with their own transposes (exactly symmetric result).  FULL: all tiles are given; every tile is averaged
 // with the transpose of its mirror tile instead.
-template <int MT, bool FULL>
+template <int MT, bool FULL, bool KEEP = false>   // KEEP: leave the completed matrix in the image
 __device__ __forceinline__ void mirror(d4 (&Z)[MT][MT], double* img, int g, int c) {
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -112,6 +112,15 @@ __device__ __forceinline__ void mirror(d4 (&Z)[MT][MT], double* img, int g, int 
       }
     }
   wave_sync();
+  if (KEEP) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) img[(16 * a + 4 * r + g) * IL + 16 * b + c] = Z[a][b][r];
+    wave_sync();
+  }
 }
 
 // ST = S^T for an (MT x NT)-tile matrix
@@ -184,7 +193,7 @@ __device__ __forceinline__ void load_f_lds(double* Fl, const double* F, int d, i
 // Z = T X T^T (+ Wt dt on the upper tiles) for symmetric X, T given by the row tables (tix, tvl) of the lanes' columns:
 //   pass 1   Y[i][j] = sum_s X[i][idx_s(j)] val_s(j)          (= X T^T)
 //   pass 2   Z[i][j] = sum_s Y[idx_s(j)][i] val_s(j)          (= (T Y)^T = T X T^T), upper tiles, then mirrored
-template <int DT, int K, bool ADDW>
+template <int DT, int K, bool ADDW, bool KEEP = false>
 __device__ __forceinline__ void congruence(d4 (&C)[DT][DT], const d4 (&Wt)[DT][DT], double dt, const int (&tix)[DT][K],
                                            const double (&tvl)[DT][K], double* img, int g, int c) {
 #pragma unroll
@@ -227,7 +236,7 @@ __device__ __forceinline__ void congruence(d4 (&C)[DT][DT], const d4 (&Wt)[DT][D
         C[aa][b][r] = s_;
       }
   wave_sync();
-  mirror<DT, false>(C, img, g, c);
+  mirror<DT, false, KEEP>(C, img, g, c);
 }
 // y[j] = sum_s x[idx_s(j)] val_s(j) for the lanes' columns (x: LDS vector)
 template <int DT, int K>
@@ -253,6 +262,66 @@ __device__ __forceinline__ void mmT_acc_up(const d4 (&X)[KT][MT], const d4 (&Y)[
 #pragma unroll
           for (int b = a; b < MT; ++b) Z[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[k][a][r], Y[k][b][r], Z[a][b], 0, 0, 0);
       }
+}
+
+// Products with a structured F as gathers through the image (tables: SparseF).
+// Z[j][i] = sum_s val_s(j) X[idx_s(j)][i] (= F^T X) for the rows j = 16 a + 4 r + g of a p-row result; the column
+// tables of F are read from LDS (ci: [32][4] ints, cv: [32][4] doubles), X is in the image.
+template <int PT, int NT, int KF>
+__device__ __forceinline__ void ft_times_image(d4 (&Z)[PT][NT], const double* img, const int* ci, const double* cv, int g, int c) {
+#pragma unroll
+  for (int a = 0; a < PT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * a + 4 * r + g;
+      double acc[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[b] = 0.0;
+#pragma unroll
+      for (int s = 0; s < KF; ++s) {
+        const double* row = img + ci[4 * j + s] * IL;
+        const double v = cv[4 * j + s];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[b] = fma(row[16 * b + c], v, acc[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b) Z[a][b][r] = acc[b];
+    }
+}
+// Z[i][i'] = sum_s X[i][idx_s(i')] val_s(i') (= X F^T) for an (MT x .)-tile X in the image; (ri, rv): the row tables of F
+// of the lanes' columns i' = 16 b + c.
+template <int MT, int DT, int KF>
+__device__ __forceinline__ void image_times_ft(d4 (&Z)[MT][DT], const double* img, const int (&ri)[DT][KF], const double (&rv)[DT][KF], int g) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* row = img + (16 * a + 4 * r + g) * IL;
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < KF; ++s) s_ = fma(row[ri[b][s]], rv[b][s], s_);
+        Z[a][b][r] = s_;
+      }
+}
+template <int MT, int NT>
+__device__ __forceinline__ void to_image(const d4 (&X)[MT][NT], double* img, int g, int c) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(16 * a + 4 * r + g) * IL + 16 * b + c] = X[a][b][r];
+}
+// The tables of a structured F: column tables into LDS (for the row-indexed gathers), row tables of the lanes' columns into registers
+template <int DT, int KF>
+__device__ __forceinline__ void load_f_tables(const SparseF* spf, int* ci, double* cv, int (&ri)[DT][KF], double (&rv)[DT][KF], int lane, int c) {
+  for (int idx = lane; idx < 32 * 4; idx += 64) { ci[idx] = spf->cidx[idx >> 2][idx & 3]; cv[idx] = spf->cval[idx >> 2][idx & 3]; }
+#pragma unroll
+  for (int b = 0; b < DT; ++b)
+#pragma unroll
+    for (int s = 0; s < KF; ++s) { ri[b][s] = spf->ridx[16 * b + c][s]; rv[b][s] = spf->rval[16 * b + c][s]; }
 }
 
 // Direct inverse of the SPD n x n matrix given as tiles (n <= 16 PT): Cholesky and n triangular solves by ONE wave in
@@ -355,7 +424,9 @@ __device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[
 // ---------------------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------------------
-template <int DT, int PT, int K>
+// KF > 0: F is structured (at most KF nonzeros per column, SparseF): S = R F, f = F^T a and Q = F^T S are gathers through
+// the image instead of MFMA products (90 of the 190 MFMAs of a step at d = 40, p = 20).
+template <int DT, int PT, int K, int KF>
 __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int zero_m0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* img = sm;        double* Fl = sm + IMG;
@@ -410,6 +481,16 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
     gcur = gi;
   };
   load_tables(a.g_index ? a.g_index[0] : 0);
+  constexpr int KFA = KF > 0 ? KF : 1;
+  int fix[PT][KFA];          // nonzeros of the lanes' columns of F
+  double fvl[PT][KFA];
+#pragma unroll
+  for (int b = 0; b < PT; ++b)
+#pragma unroll
+    for (int s = 0; s < KFA; ++s) {
+      fix[b][s] = KF > 0 ? a.spf->cidx[16 * b + c][s] : 0;
+      fvl[b][s] = KF > 0 ? a.spf->cval[16 * b + c][s] : 0.0;
+    }
   if (lane < d) mv[lane] = zero_m0 ? 0.0 : (a.m0 + (size_t)n * a.m0_stride)[lane];   // zero_m0: the simulation smoother filters y* from a zero prior mean
 
   double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;
@@ -467,9 +548,17 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       gather_vec<DT, K>(mv, tix, tvl, an);                         // a = G m
 #pragma unroll
       for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) av[16 * b + c] = an[b];
-      congruence<DT, K, true>(C, Wt, dt, tix, tvl, img, g, c);    // R = G C G^T + W dt
+      congruence<DT, K, true, (KF > 0)>(C, Wt, dt, tix, tvl, img, g, c);    // R = G C G^T + W dt (KF: R stays in the image)
     } else {
       if (lane < d) av[lane] = mv[lane];
+      if (KF > 0) {
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = C[aa][b][r];
+      }
       wave_sync();
     }
     // (C now holds R)
@@ -481,9 +570,19 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
     for (int b = 0; b < PT; ++b) { const bool o = jp[b] && (ycur[b] == ycur[b]); obs[b] = o ? 1.0 : 0.0; anyobs |= o; }
     const bool any = __ballot(anyobs) != 0ull;
     d4 Fm[DT][PT];
-    f_tiles<DT, PT>(Fl, Fm, g, c);
     double fcol[PT];
-    matTvec<DT, PT>(Fm, av, g, fcol);
+    if (KF > 0) {
+#pragma unroll
+      for (int b = 0; b < PT; ++b) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < KFA; ++s) s_ = fma(av[fix[b][s]], fvl[b][s], s_);
+        fcol[b] = s_;
+      }
+    } else {
+      f_tiles<DT, PT>(Fl, Fm, g, c);
+      matTvec<DT, PT>(Fm, av, g, fcol);
+    }
 #pragma unroll
     for (int b = 0; b < PT; ++b) {
       const double e = ycur[b] - fcol[b];                       // NaN = missing
@@ -495,14 +594,57 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
     if (!any) {   // updateState without an observation: m = a, C = R
       if (lane < d) mv[lane] = av[lane];
     } else {
+      d4 S[DT][PT], Q[PT][PT], ST[PT][DT];
+      if (KF > 0) {
+        // S[i][j] = sum_s R[i][idx_s(j)] val_s(j), observed columns only; R is in the image
 #pragma unroll
-      for (int aa = 0; aa < DT; ++aa)
+        for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
-        for (int b = 0; b < PT; ++b) Fm[aa][b] *= obs[b];
-      d4 S[DT][PT];
-      mmT<DT, DT, PT, false>(C, Fm, S, d);                       // R Fm (R symmetric)
-      d4 Q[PT][PT];
-      mmT<DT, PT, PT, true>(Fm, S, Q, d);                        // Fm^T R Fm, upper tiles
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double* row = img + (16 * aa + 4 * r + g) * IL;
+              double s_ = 0.0;
+#pragma unroll
+              for (int s = 0; s < KFA; ++s) s_ = fma(row[fix[b][s]], fvl[b][s], s_);
+              S[aa][b][r] = s_ * obs[b];
+            }
+        wave_sync();
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = S[aa][b][r];
+        wave_sync();
+        // Q[l][j] = sum_s S[idx_s(j)][l] val_s(j) (= (S^T Fm)[l][j], symmetric), upper tiles; S^T read from the same image
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = aa; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int l = 16 * aa + 4 * r + g;
+              double s_ = 0.0;
+#pragma unroll
+              for (int s = 0; s < KFA; ++s) s_ = fma(img[fix[b][s] * IL + l], fvl[b][s], s_);
+              Q[aa][b][r] = s_ * obs[b];
+            }
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ST[b][aa][r] = img[(16 * aa + c) * IL + 16 * b + 4 * r + g];
+        wave_sync();
+      } else {
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b) Fm[aa][b] *= obs[b];
+        mmT<DT, DT, PT, false>(C, Fm, S, d);                     // R Fm (R symmetric)
+        mmT<DT, PT, PT, true>(Fm, S, Q, d);                      // Fm^T R Fm, upper tiles
+      }
 #pragma unroll
       for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
@@ -518,8 +660,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       // direct inverse
       if (spd_inverse_warm<PT>(Q, Qi, p, warm, img, lane, g, c)) st |= DLM_ST_NOT_PD;
       warm = true;
-      d4 ST[PT][DT];
-      transpose<DT, PT>(S, ST, img, g, c);
+      if (KF == 0) transpose<DT, PT>(S, ST, img, g, c);
       d4 KT[PT][DT];
       mmT<PT, PT, DT, false>(Qi, ST, KT, p);                     // K^T = Qi S^T (Qi symmetric)
       double kcol[DT];
@@ -559,7 +700,9 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 //   q_{t-1} = G^T r,  P_{t-1} = G^T M G                                   (gathers with the COLUMN tables of G)
 // innov: e_t = y_t - f_t of the forward pass (NaN = missing), the observation of record t at innov[(t-1) p ..].
 // ---------------------------------------------------------------------------------------
-template <int DT, int PT, int K>
+// KF > 0: structured F -- F^T C, F^T K, X F^T and the three F-products of the update of P are gathers (220 of the 505 MFMAs
+// of a step at d = 40, p = 20).
+template <int DT, int PT, int K, int KF>
 __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* img = sm;        double* Fl = sm + IMG;
@@ -577,7 +720,13 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 #pragma unroll
   for (int b = 0; b < PT; ++b) jp[b] = 16 * b + c < p;
   const double* V = a.V + (size_t)n * a.v_stride;
-  load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
+  constexpr int KFA = KF > 0 ? KF : 1;
+  int* fci = (int*)Fl;            // structured F: its column tables live where the dense copy of F would
+  double* fcv = Fl + 64;
+  int frix[DT][KFA];
+  double frvl[DT][KFA];
+  if (KF > 0) load_f_tables<DT, KFA>(a.spf, fci, fcv, frix, frvl, lane, c);
+  else load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
 
   int tix[DT][K];
   double tvl[DT][K];
@@ -673,9 +822,17 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 #pragma unroll
         for (int b = 0; b < PT; ++b) obsP[b] = obs[b];
       }
-      d4 Ft[DT][PT], CFT[PT][DT];
-      f_tiles<DT, PT>(Fl, Ft, g, c);
-      mmT<DT, PT, DT, false>(Ft, C, CFT, d);                    // F^T C
+      d4 CFT[PT][DT];
+      if (KF > 0) {
+        to_image<DT, DT>(C, img, g, c);
+        wave_sync();
+        ft_times_image<PT, DT, KFA>(CFT, img, fci, fcv, g, c);  // F^T C
+        wave_sync();
+      } else {
+        d4 Ft[DT][PT];
+        f_tiles<DT, PT>(Fl, Ft, g, c);
+        mmT<DT, PT, DT, false>(Ft, C, CFT, d);                  // F^T C
+      }
       mmT<PT, DT, PT, false>(CFT, Vi, Kg, p);                   // K = C F Vm^-1
     }
     // the products that need C come first: C, x1 and x2 are gone before the p-sized quantities are built
@@ -712,9 +869,17 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
       {
         d4 Qi[PT][PT];
         {
-          d4 Ft[DT][PT], X0[PT][PT];
-          f_tiles<DT, PT>(Fl, Ft, g, c);
-          mmT<DT, PT, PT, false>(Ft, Kg, X0, d);                // F^T K
+          d4 X0[PT][PT];
+          if (KF > 0) {
+            to_image<DT, PT>(Kg, img, g, c);
+            wave_sync();
+            ft_times_image<PT, PT, KFA>(X0, img, fci, fcv, g, c);   // F^T K
+            wave_sync();
+          } else {
+            d4 Ft[DT][PT];
+            f_tiles<DT, PT>(Fl, Ft, g, c);
+            mmT<DT, PT, PT, false>(Ft, Kg, X0, d);              // F^T K
+          }
           mmT<PT, PT, PT, true>(Vi, X0, Qi, p);                 // Vm^-1 F^T K, upper tiles
         }
 #pragma unroll
@@ -735,23 +900,68 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 #pragma unroll
           for (int b = aa; b < PT; ++b) X[aa][b] += Qi[aa][b];
         mirror<PT, false>(X, img, g, c);
-        transpose<DT, PT>(PK, NPKT, img, g, c);                 // (also publishes tv)
+        if (KF > 0) {
+          // T2 = (P K) F^T (all tiles), then P -= T2 + T2^T on the upper tiles
+          to_image<DT, PT>(PK, img, g, c);
+          wave_sync();                                          // (also publishes tv)
+          d4 T2[DT][DT];
+          image_times_ft<DT, DT, KFA>(T2, img, frix, frvl, g);
+          wave_sync();
+          to_image<DT, DT>(T2, img, g, c);
+          wave_sync();
+#pragma unroll
+          for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+            for (int b = aa; b < DT; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) P[aa][b][r] -= T2[aa][b][r] + img[(16 * b + c) * IL + 16 * aa + 4 * r + g];
+          wave_sync();
+        } else {
+          transpose<DT, PT>(PK, NPKT, img, g, c);               // (also publishes tv)
+        }
       }
-#pragma unroll
-      for (int aa = 0; aa < PT; ++aa)
-#pragma unroll
-        for (int b = 0; b < DT; ++b) NPKT[aa][b] = -NPKT[aa][b];
-      d4 FT[PT][DT];
-      ft_tiles<DT, PT>(Fl, FT, g, c);
       double ftv[DT];
-      matTvec<PT, DT>(FT, tv, g, ftv);                          // F (u - K^T q)
+      if (KF > 0) {
+        gather_vec<DT, KFA>(tv, frix, frvl, ftv);               // F (u - K^T q)
 #pragma unroll
-      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) rv[16 * b + c] = qv[16 * b + c] + ftv[b];
-      d4 FXT[PT][DT];
-      mmT<PT, PT, DT, false>(X, FT, FXT, p);                    // X F^T = (F X)^T
-      mmT_acc_up<PT, DT>(FXT, FT, P, p);                        // + (F X) F^T
-      mmT_acc_up<PT, DT>(FT, NPKT, P, p);                       // - F (P K)^T
-      mmT_acc_up<PT, DT>(NPKT, FT, P, p);                       // - (P K) F^T
+        for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) rv[16 * b + c] = qv[16 * b + c] + ftv[b];
+        // T1 = F X F^T: (X F^T) by columns, then F (X F^T) read as its own transpose (symmetric), upper tiles
+        to_image<PT, PT>(X, img, g, c);
+        wave_sync();
+        d4 FXT[PT][DT];
+        image_times_ft<PT, DT, KFA>(FXT, img, frix, frvl, g);  // X F^T
+        wave_sync();
+        to_image<PT, DT>(FXT, img, g, c);
+        wave_sync();
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = aa; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * aa + 4 * r + g;
+              double s_ = 0.0;
+#pragma unroll
+              for (int s2 = 0; s2 < KFA; ++s2) s_ = fma(img[frix[b][s2] * IL + i], frvl[b][s2], s_);
+              P[aa][b][r] += s_;
+            }
+        wave_sync();
+      } else {
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b) NPKT[aa][b] = -NPKT[aa][b];
+        d4 FT[PT][DT];
+        ft_tiles<DT, PT>(Fl, FT, g, c);
+        matTvec<PT, DT>(FT, tv, g, ftv);                        // F (u - K^T q)
+#pragma unroll
+        for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) rv[16 * b + c] = qv[16 * b + c] + ftv[b];
+        d4 FXT[PT][DT];
+        mmT<PT, PT, DT, false>(X, FT, FXT, p);                  // X F^T = (F X)^T
+        mmT_acc_up<PT, DT>(FXT, FT, P, p);                      // + (F X) F^T
+        mmT_acc_up<PT, DT>(FT, NPKT, P, p);                     // - F (P K)^T
+        mmT_acc_up<PT, DT>(NPKT, FT, P, p);                     // - (P K) F^T
+      }
       // P's lower tiles are stale now: the congruence below reads the image written from the mirrored matrix
       mirror<DT, false>(P, img, g, c);
     } else {
@@ -1061,8 +1271,15 @@ bool wave48_filter_supported(const KArgs& a) {
 template <int DT, int PT>
 static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, int zero_m0, hipStream_t s) {
   const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
-  if (K <= 2) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
-  else hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
+  const int kf = (a.spf && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
+  if (K <= 2) {
+    if (kf == 1) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
+    else if (kf > 1) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2, 4>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
+    else hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2, 0>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
+  } else {
+    if (kf >= 1) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 4, 4>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
+    else hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 4, 0>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
+  }
   return hipGetLastError();
 }
 
@@ -1071,8 +1288,15 @@ bool wave48_smoother_supported(const KArgs& a) { return tiled_supported(a) && a.
 template <int DT, int PT>
 static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {
   const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
-  if (K <= 2) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, innov);
-  else hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
+  const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
+  if (K <= 2) {
+    if (kf == 1) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, innov);
+    else if (kf > 1) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
+    else hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2, 0>), dim3(a.N), dim3(64), lds, s, a, innov);
+  } else {
+    if (kf >= 1) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 4, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
+    else hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 4, 0>), dim3(a.N), dim3(64), lds, s, a, innov);
+  }
   return hipGetLastError();
 }
 
