@@ -495,11 +495,7 @@ __global__ void k_stats_pool(const double* stats, int N, int L, double* pooled) 
 // ---------------------------------------------------------------------------------------
 size_t generic_simulate_lds_bytes(int d, int p) { return sizeof(double) * (size_t)(2 * d * d + p * p + 3 * d + p + d + p) + 16; }
 
-// PRO: the prologue of the Durbin-Koopman simulation smoother for 16 <= d <= 48 (dlm_wave48.hip): the same simulation
-// with the FILTER's convention for a zero time increment (identity advance, no noise), normals from a.z when given,
-// x+ -> xplus [N][T+1][d] and y* = y - y+ -> ystar [N][T][p] (a missing observation stays NaN).
-template <bool PRO>
-__global__ __launch_bounds__(64) void k_simulate_generic(KArgs a, double* __restrict__ xplus, double* __restrict__ ystar) {
+__global__ __launch_bounds__(64) void k_simulate_generic(KArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d;
@@ -511,10 +507,8 @@ __global__ __launch_bounds__(64) void k_simulate_generic(KArgs a, double* __rest
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
   const double* C0 = a.C0 + (size_t)n * a.c0_stride;
   const unsigned long long series = a.series_offset + (unsigned long long)n;
-  double* xo = PRO ? xplus + (size_t)n * (T + 1) * d : (a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr);
-  double* yo = (PRO ? ystar : a.smooth) + (size_t)n * T * p;
-  const double* yin = PRO ? a.y + (size_t)n * T * p : nullptr;
-  const double* zin = (PRO && a.z) ? a.z + (size_t)n * (T + 1) * (d + p) : nullptr;
+  double* xo = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  double* yo = a.smooth + (size_t)n * T * p;
   int st = 0;
   for (int i = lane; i < dd; i += 64) { Lw[i] = W0[i]; Lc[i] = C0[i]; }
   for (int i = lane; i < p * p; i += 64) Lv[i] = V0[i];
@@ -522,7 +516,7 @@ __global__ __launch_bounds__(64) void k_simulate_generic(KArgs a, double* __rest
   if (chol_lds(lane, d, Lw)) st |= DLM_ST_NOT_PD;
   if (chol_lds(lane, d, Lc)) st |= DLM_ST_NOT_PD;
   if (chol_lds(lane, p, Lv)) st |= DLM_ST_NOT_PD;
-  for (int i = lane; i < d; i += 64) z[i] = zin ? zin[i] : philox_normal(a.seed, series, 0u, (unsigned)i);
+  for (int i = lane; i < d; i += 64) z[i] = philox_normal(a.seed, series, 0u, (unsigned)i);
   wsync();
   for (int i = lane; i < d; i += 64) {   // initialiseState (:268-273): x0 = m0 + chol(C0) z
     double acc = m0[i];
@@ -543,13 +537,13 @@ __global__ __launch_bounds__(64) void k_simulate_generic(KArgs a, double* __rest
       if (a.v_tstride && chol_lds(lane, p, Lv)) st |= DLM_ST_NOT_PD;
     }
     wsync();
-    for (int i = lane; i < d + p; i += 64) z[i] = zin ? zin[(size_t)(t + 1) * (d + p) + i] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)i);
+    for (int i = lane; i < d + p; i += 64) z[i] = philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)i);
     gemm<false, false>(lane, d, 1, d, Gt, d, x, d, gx, d);      // G x
     wsync();
     for (int i = lane; i < d; i += 64) {                          // stepState (:245-255)
       double acc = gx[i];
       for (int k = 0; k <= i; ++k) acc = fma(Lw[CM(i, k, d)] * sdt, z[k], acc);
-      xn[i] = (PRO && dt == 0.0) ? x[i] : acc;
+      xn[i] = acc;
     }
     wsync();
     gemm<true, false>(lane, p, 1, d, Ft, d, xn, d, fy, p);        // F^T x
@@ -557,7 +551,7 @@ __global__ __launch_bounds__(64) void k_simulate_generic(KArgs a, double* __rest
     for (int j = lane; j < p; j += 64) {                          // observation (:257-266)
       double acc = fy[j];
       for (int k = 0; k <= j; ++k) acc = fma(Lv[CM(j, k, p)], z[d + k], acc);
-      yo[(size_t)t * p + j] = PRO ? yin[(size_t)t * p + j] - acc : acc;
+      yo[(size_t)t * p + j] = acc;
     }
     for (int i = lane; i < d; i += 64) { x[i] = xn[i]; if (xo) xo[(size_t)(t + 1) * d + i] = xn[i]; }
   }
@@ -601,17 +595,9 @@ hipError_t launch_generic_sampler(const KArgs& a, hipStream_t s) {
 
 hipError_t launch_generic_simulate(const KArgs& a, hipStream_t s) {
   const size_t lds = generic_simulate_lds_bytes(a.d, a.p);
-  hipError_t e = check_lds((const void*)k_simulate_generic<false>, lds);
+  hipError_t e = check_lds((const void*)k_simulate_generic, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_simulate_generic<false>, dim3(a.N), dim3(64), lds, s, a, (double*)nullptr, (double*)nullptr);
-  return hipGetLastError();
-}
-
-hipError_t launch_simsmooth_prologue(const KArgs& a, double* xplus, double* ystar, hipStream_t s) {
-  const size_t lds = generic_simulate_lds_bytes(a.d, a.p);
-  hipError_t e = check_lds((const void*)k_simulate_generic<true>, lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_simulate_generic<true>, dim3(a.N), dim3(64), lds, s, a, xplus, ystar);
+  hipLaunchKernelGGL(k_simulate_generic, dim3(a.N), dim3(64), lds, s, a);
   return hipGetLastError();
 }
 

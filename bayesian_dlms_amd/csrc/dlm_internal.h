@@ -51,9 +51,7 @@ size_t generic_sampler_lds_bytes(int d, int p);
 hipError_t launch_generic_filter(const KArgs& a, hipStream_t s);
 hipError_t launch_generic_smoother(const KArgs& a, hipStream_t s);
 hipError_t launch_generic_sampler(const KArgs& a, hipStream_t s);
-hipError_t launch_generic_simulate(const KArgs& a, hipStream_t s);
-// x+ [N][T+1][d] and y* = y - y+ [N][T][p] for the simulation smoother of dlm_wave48.hip (normals from a.z when given)
-hipError_t launch_simsmooth_prologue(const KArgs& a, double* xplus, double* ystar, hipStream_t s);   // a.theta = x (nullable), a.smooth = y
+hipError_t launch_generic_simulate(const KArgs& a, hipStream_t s);   // a.theta = x (nullable), a.smooth = y
 hipError_t launch_stats_pool(const double* stats, int N, int L, double* pooled, hipStream_t s);
 
 // ---- specialised d <= 16, p == 1 kernels on the fp64 MFMA layout, dlm_mfma16.hip ------

@@ -996,7 +996,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 //   q_{t-1} = G^T [ q + F (Qm^-1 e - K^T q) ],  K = C F Vm^-1,  Qm^-1 = Vm^-1 - Vm^-1 F^T K
 // innov: the innovations of the forward pass on y* (NaN = missing), record t at innov[(t-1) p ..].
 // ---------------------------------------------------------------------------------------
-template <int DT, int PT, int K>
+template <int DT, int PT, int K, int KF>
 __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __restrict__ xplus, const double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* img = sm;        double* Fl = sm + IMG;
@@ -1015,7 +1015,18 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
 #pragma unroll
   for (int b = 0; b < PT; ++b) jp[b] = 16 * b + c < p;
   const double* V = a.V + (size_t)n * a.v_stride;
-  load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
+  constexpr int KFA = KF > 0 ? KF : 1;
+  int* fci = (int*)Fl;            // structured F: its column tables live where the dense copy of F would
+  double* fcv = Fl + 64;
+  int frix[DT][KFA], fix[PT][KFA];
+  double frvl[DT][KFA], fvl[PT][KFA];
+  if (KF > 0) {
+    load_f_tables<DT, KFA>(a.spf, fci, fcv, frix, frvl, lane, c);
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int s = 0; s < KFA; ++s) { fix[b][s] = a.spf->cidx[16 * b + c][s]; fvl[b][s] = a.spf->cval[16 * b + c][s]; }
+  } else load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
 
   int tix[DT][K], rix[DT][K];       // columns of G (q = G^T r) / rows of G (the system residual of the statistics)
   double tvl[DT][K], rvl[DT][K];
@@ -1115,7 +1126,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
     }
     wave_sync();
     d4 Ft[DT][PT];
-    if (any || stats) f_tiles<DT, PT>(Fl, Ft, g, c);
+    if (KF == 0 && (any || stats)) f_tiles<DT, PT>(Fl, Ft, g, c);
     if (stats) {
       if (t < T) {   // system residual theta_{t+1} - G_{t+1} theta_t, scaled by 1 / sqrt(dt)
         const int gn = a.g_index ? a.g_index[t] : 0;
@@ -1144,7 +1155,8 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
       }
       if (t > 0) {   // observation residual of theta_t against the ORIGINAL y_t
         double fth[PT];
-        matTvec<DT, PT>(Ft, thc, g, fth);
+        if (KF > 0) gather_vec<PT, KFA>(thc, fix, fvl, fth);
+        else matTvec<DT, PT>(Ft, thc, g, fth);
 #pragma unroll
         for (int b = 0; b < PT; ++b)
           if (jp[b] && ycol[b] == ycol[b]) { const double r_ = ycol[b] - fth[b]; ssy[b] = fma(r_, r_, ssy[b]); nob[b] += 1.0; }
@@ -1182,14 +1194,29 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
       d4 Kg[DT][PT];
       {
         d4 CFT[PT][DT];
-        mmT<DT, PT, DT, false>(Ft, C, CFT, d);                  // F^T C
-        request(t - 1, g, c);                                   // C is free
+        if (KF > 0) {
+          to_image<DT, DT>(C, img, g, c);
+          wave_sync();
+          request(t - 1, g, c);                                 // C is free
+          ft_times_image<PT, DT, KFA>(CFT, img, fci, fcv, g, c);   // F^T C
+          wave_sync();
+        } else {
+          mmT<DT, PT, DT, false>(Ft, C, CFT, d);                // F^T C
+          request(t - 1, g, c);                                 // C is free
+        }
         mmT<PT, DT, PT, false>(CFT, Vi, Kg, p);                 // K = C F Vm^-1
       }
       d4 Qi[PT][PT];
       {
         d4 X0[PT][PT];
-        mmT<DT, PT, PT, false>(Ft, Kg, X0, d);                  // F^T K
+        if (KF > 0) {
+          to_image<DT, PT>(Kg, img, g, c);
+          wave_sync();
+          ft_times_image<PT, PT, KFA>(X0, img, fci, fcv, g, c);    // F^T K
+          wave_sync();
+        } else {
+          mmT<DT, PT, PT, false>(Ft, Kg, X0, d);                // F^T K
+        }
         mmT<PT, PT, PT, true>(Vi, X0, Qi, p);
       }
 #pragma unroll
@@ -1203,10 +1230,13 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
 #pragma unroll
       for (int b = 0; b < PT; ++b) if (g == 0) tv[16 * b + c] = jp[b] ? ucol[b] - ktq[b] : 0.0;
       wave_sync();
-      d4 FT[PT][DT];
-      ft_tiles<DT, PT>(Fl, FT, g, c);
       double ftv[DT];
-      matTvec<PT, DT>(FT, tv, g, ftv);                          // F (Qm^-1 e - K^T q)
+      if (KF > 0) gather_vec<DT, KFA>(tv, frix, frvl, ftv);      // F (Qm^-1 e - K^T q)
+      else {
+        d4 FT[PT][DT];
+        ft_tiles<DT, PT>(Fl, FT, g, c);
+        matTvec<PT, DT>(FT, tv, g, ftv);
+      }
 #pragma unroll
       for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) rv[16 * b + c] = qv[16 * b + c] + ftv[b];
     } else {
@@ -1248,6 +1278,115 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
       for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) so[2 * p + 16 * b + c] = ssd[b];
     }
     if (lane == 0) so[L - 1] = (double)T;
+  }
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// prologue of the simulation smoother: simulate (x+, y+) from the model and leave y* = y - y+ (Dlm.simulateRegular,
+// Dlm.scala:245-292, on the filter's time grid: a zero increment is an identity advance without noise).  One wave per
+// series; chol(W), chol(V) row-major in LDS with odd leading dimensions, G x by the row tables of G, F^T x by the column
+// tables of a structured F (KF > 0) or from the LDS copy of F.  Normals: (seed, series, record t, i), i < d state noise
+// (record 0: the initial state), d <= i < d + p observation noise, or a.z [N][T+1][d+p] when given.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool chol_rows(double* L, int n, int ld, int lane) {   // in-place lower Cholesky, row-major
+  bool bad = false;
+  for (int k = 0; k < n; ++k) {
+    double akk = L[k * ld + k];
+    if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
+    const double lkk = sqrt(akk), inv = 1.0 / lkk;
+    wave_sync();
+    if (lane >= k && lane < n) L[lane * ld + k] = (lane == k) ? lkk : L[lane * ld + k] * inv;
+    wave_sync();
+    const int rr = n - k - 1;
+    for (int idx = lane; idx < rr * rr; idx += 64) {
+      const int i = k + 1 + idx % rr, j = k + 1 + idx / rr;
+      if (i >= j) L[i * ld + j] = fma(-L[i * ld + k], L[j * ld + k], L[i * ld + j]);
+    }
+    wave_sync();
+  }
+  return bad;
+}
+
+template <int K, int KF>
+__global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __restrict__ xplus, double* __restrict__ ystar) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int d = a.d, p = a.p, T = a.T;
+  const int ldw = d | 1, ldv = p | 1;
+  double* Lw = sm;               double* Lv = Lw + 48 * 49;     double* Fl = Lv + 32 * 33;
+  double* x = Fl + (KF > 0 ? 0 : FIMG);   double* xn = x + 48;   double* z = xn + 48;   // z: d + p <= 80 normals
+  const double* V = a.V + (size_t)n * a.v_stride;
+  const double* W = a.W + (size_t)n * a.w_stride;
+  const double* C0 = a.C0 + (size_t)n * a.c0_stride;
+  const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * (d + p) : nullptr;
+  const double* yin = a.y + (size_t)n * T * p;
+  double* xo = xplus + (size_t)n * (T + 1) * d;
+  double* yo = ystar + (size_t)n * T * p;
+  int st = 0;
+  // x+_0 = m0 + chol(C0) z_0 (chol(C0) built where chol(W) goes afterwards)
+  for (int idx = lane; idx < d * d; idx += 64) { const int i = idx % d, j = idx / d; Lw[i * ldw + j] = C0[idx]; }
+  for (int i = lane; i < d; i += 64) z[i] = zin ? zin[i] : philox_normal(a.seed, series, 0u, (unsigned)i);
+  wave_sync();
+  if (chol_rows(Lw, d, ldw, lane)) st |= DLM_ST_NOT_PD;
+  if (lane < d) {
+    double acc = m0[lane];
+    for (int k = 0; k <= lane; ++k) acc = fma(Lw[lane * ldw + k], z[k], acc);
+    x[lane] = acc; xo[lane] = acc;
+  }
+  wave_sync();
+  for (int idx = lane; idx < d * d; idx += 64) { const int i = idx % d, j = idx / d; Lw[i * ldw + j] = W[idx]; }
+  for (int idx = lane; idx < p * p; idx += 64) { const int i = idx % p, j = idx / p; Lv[i * ldv + j] = V[idx]; }
+  if (KF == 0) load_f_lds<3, 2>(Fl, a.F, d, p, lane);
+  wave_sync();
+  if (chol_rows(Lw, d, ldw, lane)) st |= DLM_ST_NOT_PD;
+  if (chol_rows(Lv, p, ldv, lane)) st |= DLM_ST_NOT_PD;
+  // tables of this lane's state row / observation column
+  int gix[K], fix[KF > 0 ? KF : 1];
+  double gvl[K], fvl[KF > 0 ? KF : 1];
+  int gcur = -1;
+  const int li = lane < 48 ? lane : 0, lj = lane < 32 ? lane : 0;
+#pragma unroll
+  for (int s = 0; s < (KF > 0 ? KF : 1); ++s) { fix[s] = KF > 0 ? a.spf->cidx[lj][s] : 0; fvl[s] = KF > 0 ? a.spf->cval[lj][s] : 0.0; }
+  for (int t = 0; t < T; ++t) {
+    const double dt = a.dt ? a.dt[t] : 1.0, sdt = sqrt(dt);
+    const int gi = a.g_index ? a.g_index[t] : 0;
+    if (gi != gcur) {
+      const SparseBig* tab = a.spb + 2 * gi;
+#pragma unroll
+      for (int s = 0; s < K; ++s) { gix[s] = tab->idx[li][s]; gvl[s] = tab->val[li][s]; }
+      gcur = gi;
+    }
+    if (KF == 0 && a.f_stride) { wave_sync(); load_f_lds<3, 2>(Fl, a.F + (size_t)t * a.f_stride, d, p, lane); }
+    for (int i = lane; i < d + p; i += 64)
+      z[i] = zin ? zin[(size_t)(t + 1) * (d + p) + i] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)i);
+    wave_sync();
+    if (lane < d) {
+      double acc = 0.0;
+#pragma unroll
+      for (int s = 0; s < K; ++s) acc = fma(x[gix[s]], gvl[s], acc);                    // G x
+      double nz = 0.0;
+      for (int k = 0; k <= lane; ++k) nz = fma(Lw[lane * ldw + k], z[k], nz);          // chol(W) z
+      const double v = (dt == 0.0) ? x[lane] : fma(nz, sdt, acc);
+      xn[lane] = v;
+      xo[(size_t)(t + 1) * d + lane] = v;
+    }
+    wave_sync();
+    if (lane < p) {
+      double acc = 0.0;
+      if (KF > 0) {
+#pragma unroll
+        for (int s = 0; s < (KF > 0 ? KF : 1); ++s) acc = fma(xn[fix[s]], fvl[s], acc);   // F^T x
+      } else {
+        for (int k = 0; k < d; ++k) acc = fma(Fl[k * FLD + lane], xn[k], acc);
+      }
+      for (int k = 0; k <= lane; ++k) acc = fma(Lv[lane * ldv + k], z[d + k], acc);     // + chol(V) z
+      yo[(size_t)t * p + lane] = yin[(size_t)t * p + lane] - acc;                        // NaN stays NaN
+    }
+    if (lane < d) x[lane] = xn[lane];
   }
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
@@ -1327,13 +1466,32 @@ bool wave48_simsmooth_supported(const KArgs& a) {
 template <int DT, int PT>
 static hipError_t launch_w48_sims_k(const KArgs& a, int K, const double* xplus, const double* innov, hipStream_t s) {
   const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
-  if (K <= 2) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
-  else hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 4>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+  const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
+  if (K <= 2) {
+    if (kf == 1) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+    else if (kf > 1) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2, 4>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+    else hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2, 0>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+  } else {
+    if (kf >= 1) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 4, 4>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+    else hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 4, 0>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_wave48_simsmooth(const KArgs& a, int K, double* xplus, double* ystar, hipStream_t s) {
-  hipError_t e = launch_simsmooth_prologue(a, xplus, ystar, s);
+  {
+    const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;
+    const size_t lds = sizeof(double) * (48 * 49 + 32 * 33 + (kf ? 0 : w48::FIMG) + 48 + 48 + 96);
+    if (K <= 2) {
+      if (kf == 1) hipLaunchKernelGGL((w48::k_sim_prologue_w48<2, 1>), dim3(a.N), dim3(64), lds, s, a, xplus, ystar);
+      else if (kf > 1) hipLaunchKernelGGL((w48::k_sim_prologue_w48<2, 4>), dim3(a.N), dim3(64), lds, s, a, xplus, ystar);
+      else hipLaunchKernelGGL((w48::k_sim_prologue_w48<2, 0>), dim3(a.N), dim3(64), lds, s, a, xplus, ystar);
+    } else {
+      if (kf >= 1) hipLaunchKernelGGL((w48::k_sim_prologue_w48<4, 4>), dim3(a.N), dim3(64), lds, s, a, xplus, ystar);
+      else hipLaunchKernelGGL((w48::k_sim_prologue_w48<4, 0>), dim3(a.N), dim3(64), lds, s, a, xplus, ystar);
+    }
+  }
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   KArgs f = a;
   f.y = ystar; f.z = nullptr; f.theta = nullptr; f.stats = nullptr; f.fq = nullptr; f.prior = nullptr; f.loglik = nullptr;
