@@ -493,10 +493,11 @@ def test_ffbs_simulation_smoother_distribution(eng):
 # multivariate tiled-MFMA path (16 <= d <= 48, p <= 32): config C4 and friends
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["c4", "d17_p3_irregular", "d24_p5_timevarying_f", "d20_p10_structured_irregular",
-                                  "d48_p32_dense"])
+                                  "d48_p32_dense", "d20_p6_dense_f", "d36_p18_tridiag_g_two_per_column_f"])
 def test_tiled_mfma_path(eng, case):
     rng = np.random.default_rng({"c4": 40, "d17_p3_irregular": 17, "d24_p5_timevarying_f": 24,
-                                 "d20_p10_structured_irregular": 20, "d48_p32_dense": 48}[case])
+                                 "d20_p10_structured_irregular": 20, "d48_p32_dense": 48, "d20_p6_dense_f": 206,
+                                 "d36_p18_tridiag_g_two_per_column_f": 36}[case])
     if case == "d20_p10_structured_irregular":
         # |*| of ten polynomial(2) blocks on an irregular grid with a repeated time: several structured G tables
         # (the gather congruence), W dt, and the dt = 0 identity advance
@@ -514,6 +515,24 @@ def test_tiled_mfma_path(eng, case):
         mod = Dlm(lambda t: F, lambda dt: G1)
         times = np.arange(1, 13, dtype=np.float64)
         B = rng.standard_normal((p_, p_)); V = B @ B.T / p_ + 0.5 * np.eye(p_)
+    elif case == "d20_p6_dense_f":
+        # structured G (bidiagonal) with a dense time-invariant F: the per-wave kernels with MFMA products for F
+        d, p_ = 20, 6
+        G1 = 0.85 * np.eye(d) + 0.1 * np.eye(d, k=1)
+        F = rng.standard_normal((d, p_))
+        mod = Dlm(lambda t: F, lambda dt: G1)
+        times = np.arange(1, 31, dtype=np.float64)
+        B = rng.standard_normal((p_, p_)); V = B @ B.T / p_ + 0.5 * np.eye(p_)
+    elif case == "d36_p18_tridiag_g_two_per_column_f":
+        # three nonzeros per row of G and two per column of F: the wider gather tables (K = 4, KF = 4 instantiations)
+        d, p_ = 36, 18
+        G1 = 0.7 * np.eye(d) + 0.12 * np.eye(d, k=1) - 0.1 * np.eye(d, k=-1)
+        F = np.zeros((d, p_))
+        for j in range(p_):
+            F[2 * j, j] = 1.0; F[(2 * j + 5) % d, j] = 0.5
+        mod = Dlm(lambda t: F, lambda dt: G1)
+        times = np.arange(1, 31, dtype=np.float64)
+        V = np.diag(rng.uniform(0.5, 2.0, p_))
     elif case == "c4":
         mod = Dlm.polynomial(2)
         for _ in range(19):
@@ -546,7 +565,8 @@ def test_tiled_mfma_path(eng, case):
     out = eng.filter_smooth(mat, p, y)
     # a structured G runs one wavefront per series with register-resident tiles (dlm_wave48.hip), a dense G the
     # workgroup-per-series kernels (dlm_tiled.hip); the forecast output stays on the latter
-    structured = case in ("c4", "d20_p10_structured_irregular", "d24_p5_timevarying_f")
+    structured = case in ("c4", "d20_p10_structured_irregular", "d24_p5_timevarying_f", "d20_p6_dense_f",
+                          "d36_p18_tridiag_g_two_per_column_f")
     assert eng.last_variant == ("wave-mfma" if structured else "tiled-mfma") and np.all(out["status"] == 0)
     if structured:   # the two implementations agree far inside the oracle tolerance
         os.environ["DLM_NO_WAVE48"] = "1"
@@ -788,6 +808,21 @@ def test_ffbs_simulation_smoother_multivariate(eng):
         del os.environ["DLM_NO_WAVE48"]
     np.testing.assert_allclose(new2["theta"], old2["theta"], rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(new2["stats"], old2["stats"], rtol=1e-7, atol=1e-8)
+    # a dense F next to a structured G (MFMA products with F on the per-wave path)
+    Fd = rng.standard_normal((20, 6)); Gd = 0.85 * np.eye(20) + 0.1 * np.eye(20, k=1)
+    mat3 = materialise(Dlm(lambda t: Fd, lambda dt: Gd), np.arange(1, 41, dtype=np.float64))
+    p3 = DlmParameters(np.eye(6) * 0.8, A @ A.T / d + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d))
+    y3 = rng.standard_normal((N, 40, 6)).cumsum(axis=1)
+    y3[rng.random(y3.shape) < 0.1] = np.nan
+    new3 = eng.ffbs(mat3, p3, y3, seed=8, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    assert eng.last_variant == "wave-simsmooth"
+    os.environ["DLM_NO_WAVE48"] = "1"
+    try:
+        old3 = eng.ffbs(mat3, p3, y3, seed=8, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    finally:
+        del os.environ["DLM_NO_WAVE48"]
+    np.testing.assert_allclose(new3["theta"], old3["theta"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(new3["stats"], old3["stats"], rtol=1e-7, atol=1e-8)
 
 
 # ------------------------------------------------------------------------------------------
