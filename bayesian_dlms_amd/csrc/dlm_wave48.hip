@@ -495,6 +495,12 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 
   double* out = a.filt ? a.filt + (size_t)n * (T + 1) * rec : nullptr;
   const __amdgpu_buffer_rsrc_t rfo = mk_rsrc(out, out ? (size_t)(T + 1) * recb : 0);   // zero-sized: stores are dropped
+  double* pri = a.prior ? a.prior + (size_t)n * (T + 1) * rec : nullptr;               // optional (a_t, R_t) records
+  const __amdgpu_buffer_rsrc_t rpr = mk_rsrc(pri, pri ? (size_t)(T + 1) * recb : 0);
+  const int frec = p + p * p;
+  double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * frec : nullptr;                     // optional (f_t, Q_t) records
+  const __amdgpu_buffer_rsrc_t rfq = mk_rsrc(fq, fq ? (size_t)(T + 1) * frec * 8 : 0);
+  if (fq) for (int i = lane; i < frec; i += 64) fq[i] = __builtin_nan("");
   const double* y = a.y + (size_t)n * T * p;
   const __amdgpu_buffer_rsrc_t ry = mk_rsrc(y, (size_t)T * p * 8);
   double* es = innov ? innov + (size_t)n * T * p : nullptr;
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
   for (int b = 0; b < DT; ++b) moff[b] = (jd[b] && g == 0) ? (16 * b + c) * 8 : OOB;
   wave_sync();
 
-  auto store_record = [&](int t, int g, int c) {
+  auto store_record = [&](const __amdgpu_buffer_rsrc_t& rfo, const double* mv, int t, int g, int c) {
     const int so = t * recb;
 #pragma unroll
     for (int aa = 0; aa < DT; ++aa)
@@ -520,7 +526,8 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 #pragma unroll
     for (int b = 0; b < DT; ++b) bst(rfo, moff[b], so, mv[16 * b + c]);
   };
-  store_record(0, g, c);
+  store_record(rfo, mv, 0, g, c);
+  if (pri) store_record(rpr, mv, 0, g, c);
 
   double ynext[PT];
 #pragma unroll
@@ -562,6 +569,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       wave_sync();
     }
     // (C now holds R)
+    if (pri) store_record(rpr, av, t + 1, g, c);
 
     // ---- forecast
     double obs[PT];   // 1.0: component 16 b + c observed
@@ -591,12 +599,10 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
     }
     wave_sync();
 
-    if (!any) {   // updateState without an observation: m = a, C = R
-      if (lane < d) mv[lane] = av[lane];
-    } else {
-      d4 S[DT][PT], Q[PT][PT], ST[PT][DT];
+    d4 S[DT][PT], Q[PT][PT], ST[PT][DT];
+    if (any || fq) {   // S = R F and Q = F^T R F + V with the FULL F (the forecast record wants them unmasked)
       if (KF > 0) {
-        // S[i][j] = sum_s R[i][idx_s(j)] val_s(j), observed columns only; R is in the image
+        // S[i][j] = sum_s R[i][idx_s(j)] val_s(j); R is in the image
 #pragma unroll
         for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
               double s_ = 0.0;
 #pragma unroll
               for (int s = 0; s < KFA; ++s) s_ = fma(row[fix[b][s]], fvl[b][s], s_);
-              S[aa][b][r] = s_ * obs[b];
+              S[aa][b][r] = s_;
             }
         wave_sync();
 #pragma unroll
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 #pragma unroll
             for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * IL + 16 * b + c] = S[aa][b][r];
         wave_sync();
-        // Q[l][j] = sum_s S[idx_s(j)][l] val_s(j) (= (S^T Fm)[l][j], symmetric), upper tiles; S^T read from the same image
+        // Q[l][j] = sum_s S[idx_s(j)][l] val_s(j) (= (S^T F)[l][j], symmetric), upper tiles; S^T read from the same image
 #pragma unroll
         for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
@@ -628,34 +634,56 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
               double s_ = 0.0;
 #pragma unroll
               for (int s = 0; s < KFA; ++s) s_ = fma(img[fix[b][s] * IL + l], fvl[b][s], s_);
-              Q[aa][b][r] = s_ * obs[b];
+              Q[aa][b][r] = s_;
             }
 #pragma unroll
         for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
           for (int b = 0; b < PT; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ST[b][aa][r] = img[(16 * aa + c) * IL + 16 * b + 4 * r + g];
+            for (int r = 0; r < 4; ++r) ST[b][aa][r] = img[(16 * aa + c) * IL + 16 * b + 4 * r + g] * __shfl(obs[b], 4 * r + g);   // row 16 b + 4 r + g of S^T: the mask of that observation sits in lane 4 r + g
         wave_sync();
       } else {
-#pragma unroll
-        for (int aa = 0; aa < DT; ++aa)
-#pragma unroll
-          for (int b = 0; b < PT; ++b) Fm[aa][b] *= obs[b];
-        mmT<DT, DT, PT, false>(C, Fm, S, d);                     // R Fm (R symmetric)
-        mmT<DT, PT, PT, true>(Fm, S, Q, d);                      // Fm^T R Fm, upper tiles
+        mmT<DT, DT, PT, false>(C, Fm, S, d);                     // R F (R symmetric)
+        mmT<DT, PT, PT, true>(Fm, S, Q, d);                      // F^T R F, upper tiles
       }
 #pragma unroll
       for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
-        for (int b = aa; b < PT; ++b)
+        for (int b = aa; b < PT; ++b) Q[aa][b] += Vt[aa][b];
+      mirror<PT, false>(Q, img, g, c);
+      if (fq) {
+        const int so = (t + 1) * frec * 8;
+#pragma unroll
+        for (int b = 0; b < PT; ++b) bst(rfq, g == 0 ? yoff[b] : OOB, so, fcol[b]);
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * aa + 4 * r + g;
+              bst(rfq, (i < p && jp[b]) ? (p + i + (16 * b + c) * p) * 8 : OOB, so, Q[aa][b][r]);
+            }
+      }
+    }
+    if (!any) {   // updateState without an observation: m = a, C = R
+      if (lane < d) mv[lane] = av[lane];
+    } else {
+      // missing components: their columns of S and rows / columns of Q leave the update (unit diagonal in Q)
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) S[aa][b] *= obs[b];
+#pragma unroll
+      for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+        for (int b = 0; b < PT; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
-            const double oi = ob[i];
-            Q[aa][b][r] += (oi != 0.0 && obs[b] != 0.0) ? Vt[aa][b][r] : ((i == j && jp[b]) ? 1.0 : 0.0);
+            Q[aa][b][r] = (__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? Q[aa][b][r] : ((i == j && jp[b]) ? 1.0 : 0.0);
           }
-      mirror<PT, false>(Q, img, g, c);
       // a warm start from a different missingness pattern is too far off anyway: the residual test sends it to the
       // direct inverse
       if (spd_inverse_warm<PT>(Q, Qi, p, warm, img, lane, g, c)) st |= DLM_ST_NOT_PD;
@@ -676,7 +704,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       mirror<DT, false>(C, img, g, c);
     }
     wave_sync();
-    store_record(t + 1, g, c);
+    store_record(rfo, mv, t + 1, g, c);
     }
   }
   bool bad = false;
@@ -810,7 +838,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
-              Vm[aa][b][r] = (i < p && jp[b]) ? ((ob[i] != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
+              Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
             }
         if (direct_inverse<PT>(Vm, Vi, p, img, lane, g, c)) st |= DLM_ST_NOT_PD;
 #pragma unroll
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 #pragma unroll
           for (int b = 0; b < PT; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (!(ob[16 * aa + 4 * r + g] != 0.0 && obs[b] != 0.0)) Vi[aa][b][r] = 0.0;
+            for (int r = 0; r < 4; ++r) if (!(__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0)) Vi[aa][b][r] = 0.0;
 #pragma unroll
         for (int b = 0; b < PT; ++b) obsP[b] = obs[b];
       }
@@ -1179,7 +1207,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
-              Vm[aa][b][r] = (i < p && jp[b]) ? ((ob[i] != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
+              Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
             }
         if (direct_inverse<PT>(Vm, Vi, p, img, lane, g, c)) st |= DLM_ST_NOT_PD;
 #pragma unroll
@@ -1187,7 +1215,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
 #pragma unroll
           for (int b = 0; b < PT; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (!(ob[16 * aa + 4 * r + g] != 0.0 && obs[b] != 0.0)) Vi[aa][b][r] = 0.0;
+            for (int r = 0; r < 4; ++r) if (!(__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0)) Vi[aa][b][r] = 0.0;
 #pragma unroll
         for (int b = 0; b < PT; ++b) obsP[b] = obs[b];
       }
@@ -1394,7 +1422,7 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
 }  // namespace w48
 
 // The per-wave kernels take the structured-G models without per-step variance streams; the rest of the tiled feature
-// set (dense G, forecast / prior outputs, log-likelihood, V_t / W_t, simulation smoother) stays on dlm_tiled.hip.
+// set (dense G, log-likelihood, V_t / W_t) stays on dlm_tiled.hip.
 // One wave per series needs more series than the chip has SIMDs to pay off: up to one series per CU (N <= 256) the
 // workgroup-per-series kernels of dlm_tiled.hip finish a step sooner (10.8 against 13 us at d = 40, p = 20).
 // DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip, DLM_FORCE_WAVE48 lifts the batch-size rule (A/B
@@ -1404,7 +1432,7 @@ static bool wave48_wanted(const KArgs& a) {
   return a.N > 256 || getenv("DLM_FORCE_WAVE48");
 }
 bool wave48_filter_supported(const KArgs& a) {
-  return tiled_supported(a) && a.spb && !a.fq && !a.prior && !a.loglik && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
+  return tiled_supported(a) && a.spb && !a.loglik && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
 }
 
 template <int DT, int PT>

@@ -564,7 +564,7 @@ def test_tiled_mfma_path(eng, case):
     y[:, 5, :] = np.nan                                  # a fully missing record
     out = eng.filter_smooth(mat, p, y)
     # a structured G runs one wavefront per series with register-resident tiles (dlm_wave48.hip), a dense G the
-    # workgroup-per-series kernels (dlm_tiled.hip); the forecast output stays on the latter
+    # workgroup-per-series kernels (dlm_tiled.hip)
     structured = case in ("c4", "d20_p10_structured_irregular", "d24_p5_timevarying_f", "d20_p6_dense_f",
                           "d36_p18_tridiag_g_two_per_column_f")
     assert eng.last_variant == ("wave-mfma" if structured else "tiled-mfma") and np.all(out["status"] == 0)
@@ -578,7 +578,7 @@ def test_tiled_mfma_path(eng, case):
         np.testing.assert_allclose(out["filt"], ref["filt"], rtol=1e-9, atol=1e-10)
         np.testing.assert_allclose(out["smooth"], ref["smooth"], rtol=1e-8, atol=1e-9)
     fq = eng.filter(mat, p, y, want_fq=True)
-    assert eng.last_variant == "tiled-mfma"
+    assert eng.last_variant == ("wave-mfma" if structured else "tiled-mfma")
     for n in range(N):
         f, s = oracle_filter_smooth(mat, p, y[n])
         m, C = split(out["filt"][n], d); sm, S = split(out["smooth"][n], d)
@@ -903,7 +903,7 @@ def test_prior_records_on_fast_paths(eng):
     p2 = DlmParameters(np.eye(8), np.eye(16) * 0.2, np.zeros(16), np.eye(16))
     y2 = np.random.default_rng(1).standard_normal((2, 20, 8))
     out2 = eng.filter(mat2, p2, y2, want_prior=True)
-    assert eng.last_variant == "tiled-mfma"
+    assert eng.last_variant == "wave-mfma"
     f2 = oracle.kf_filter(omodel(mat2), p2.v, p2.w, p2.m0, p2.c0, y2[0])
     a2, R2 = split(out2["prior"][0], 16)
     np.testing.assert_allclose(a2, f2["a"], rtol=1e-9, atol=1e-10)
