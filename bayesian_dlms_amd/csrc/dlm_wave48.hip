@@ -421,6 +421,26 @@ __device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[
   return direct_inverse<PT>(Q, X, n, img, lane, g, c);
 }
 
+__device__ __forceinline__ bool chol_rows(double* L, int n, int ld, int lane) {   // in-place lower Cholesky, row-major
+  bool bad = false;
+  for (int k = 0; k < n; ++k) {
+    double akk = L[k * ld + k];
+    if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
+    const double lkk = sqrt(akk), inv = 1.0 / lkk;
+    wave_sync();
+    if (lane >= k && lane < n) L[lane * ld + k] = (lane == k) ? lkk : L[lane * ld + k] * inv;
+    wave_sync();
+    const int rr = n - k - 1;
+    for (int idx = lane; idx < rr * rr; idx += 64) {
+      const int i = k + 1 + idx % rr, j = k + 1 + idx / rr;
+      if (i >= j) L[i * ld + j] = fma(-L[i * ld + k], L[j * ld + k], L[i * ld + j]);
+    }
+    wave_sync();
+  }
+  return bad;
+}
+
+
 // ---------------------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------------------
@@ -533,6 +553,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 #pragma unroll
   for (int b = 0; b < PT; ++b) ynext[b] = bld(ry, T > 0 ? yoff[b] : OOB, 0);
   bool warm = false;
+  double ll = 0.0;   // prediction-error log-likelihood of the series (every lane holds it)
 
   for (int t = 0; t < T; ++t) {
     // opaque copies of the lane coordinates: the compiler would otherwise hoist the few dozen address computations of
@@ -688,6 +709,25 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       // direct inverse
       if (spd_inverse_warm<PT>(Q, Qi, p, warm, img, lane, g, c)) st |= DLM_ST_NOT_PD;
       warm = true;
+      if (a.loglik) {   // -1/2 (n_obs log 2 pi + log det Qm + e^T Qm^-1 e) (KalmanFilter.scala:138-153); det from a one-wave Cholesky of Qm
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[(16 * aa + 4 * r + g) * QL + 16 * b + c] = Q[aa][b][r];
+        wave_sync();
+        if (chol_rows(img, p, QL, lane)) st |= DLM_ST_NOT_PD;
+        double ucol[PT];
+        matTvec<PT, PT>(Qi, ev, g, ucol);                        // Qm^-1 e
+        double part = 0.0;
+#pragma unroll
+        for (int b = 0; b < PT; ++b)
+          if (g == 0 && jp[b]) part += 2.0 * log(img[(16 * b + c) * QL + 16 * b + c]) + ev[16 * b + c] * ucol[b] + 1.8378770664093453 * obs[b];
+        for (int o_ = 32; o_ > 0; o_ >>= 1) part += __shfl_xor(part, o_);
+        ll -= 0.5 * part;
+        wave_sync();
+      }
       if (KF == 0) transpose<DT, PT>(S, ST, img, g, c);
       d4 KT[PT][DT];
       mmT<PT, PT, DT, false>(Qi, ST, KT, p);                     // K^T = Qi S^T (Qi symmetric)
@@ -707,6 +747,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
     store_record(rfo, mv, t + 1, g, c);
     }
   }
+  if (a.loglik && lane == 0) a.loglik[n] = ll;
   bool bad = false;
 #pragma unroll
   for (int aa = 0; aa < DT; ++aa)
@@ -1318,25 +1359,6 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
 // tables of a structured F (KF > 0) or from the LDS copy of F.  Normals: (seed, series, record t, i), i < d state noise
 // (record 0: the initial state), d <= i < d + p observation noise, or a.z [N][T+1][d+p] when given.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool chol_rows(double* L, int n, int ld, int lane) {   // in-place lower Cholesky, row-major
-  bool bad = false;
-  for (int k = 0; k < n; ++k) {
-    double akk = L[k * ld + k];
-    if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
-    const double lkk = sqrt(akk), inv = 1.0 / lkk;
-    wave_sync();
-    if (lane >= k && lane < n) L[lane * ld + k] = (lane == k) ? lkk : L[lane * ld + k] * inv;
-    wave_sync();
-    const int rr = n - k - 1;
-    for (int idx = lane; idx < rr * rr; idx += 64) {
-      const int i = k + 1 + idx % rr, j = k + 1 + idx / rr;
-      if (i >= j) L[i * ld + j] = fma(-L[i * ld + k], L[j * ld + k], L[i * ld + j]);
-    }
-    wave_sync();
-  }
-  return bad;
-}
-
 template <int K, int KF>
 __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __restrict__ xplus, double* __restrict__ ystar) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1422,7 +1444,7 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
 }  // namespace w48
 
 // The per-wave kernels take the structured-G models without per-step variance streams; the rest of the tiled feature
-// set (dense G, log-likelihood, V_t / W_t) stays on dlm_tiled.hip.
+// set (dense G, V_t / W_t) stays on dlm_tiled.hip.
 // One wave per series needs more series than the chip has SIMDs to pay off: up to one series per CU (N <= 256) the
 // workgroup-per-series kernels of dlm_tiled.hip finish a step sooner (10.8 against 13 us at d = 40, p = 20).
 // DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip, DLM_FORCE_WAVE48 lifts the batch-size rule (A/B
@@ -1432,7 +1454,7 @@ static bool wave48_wanted(const KArgs& a) {
   return a.N > 256 || getenv("DLM_FORCE_WAVE48");
 }
 bool wave48_filter_supported(const KArgs& a) {
-  return tiled_supported(a) && a.spb && !a.loglik && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
+  return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
 }
 
 template <int DT, int PT>

@@ -953,12 +953,14 @@ def test_time_varying_f_regression_on_fast_path(eng):
         np.testing.assert_allclose(o2["stats"][n, 2:2 + d], st["ss"], rtol=1e-7)
 
 
-@pytest.mark.parametrize("case", ["sparse16_d13", "mfma16_dense_d6", "generic_d8_p4", "tiled_d17_p3", "per_series_params"])
+@pytest.mark.parametrize("case", ["sparse16_d13", "mfma16_dense_d6", "generic_d8_p4", "tiled_d17_p3", "per_series_params",
+                                  "wave_d20_p10", "wave_d24_p18_dense_f"])
 def test_log_likelihood_prediction_error_decomposition(eng, case):
     """dlm_loglik_batch = sum_t KalmanFilter.conditionalLikelihood(f_t, Q_t, y_t) (KalmanFilter.scala:138-153) on every
     forward variant, with missing observations; nothing but N numbers leaves the GPU."""
     rng = np.random.default_rng(abs(hash(case)) % 1000 if False else {"sparse16_d13": 1, "mfma16_dense_d6": 2, "generic_d8_p4": 3,
-                                                                      "tiled_d17_p3": 4, "per_series_params": 5}[case])
+                                                                      "tiled_d17_p3": 4, "per_series_params": 5, "wave_d20_p10": 6,
+                                                                      "wave_d24_p18_dense_f": 7}[case])
     N = 3
     if case in ("sparse16_d13", "per_series_params"):
         mod, mat, p = seasonal_model(T=80)
@@ -975,6 +977,22 @@ def test_log_likelihood_prediction_error_decomposition(eng, case):
         B = rng.standard_normal((4, 4))
         p = DlmParameters(B @ B.T / 4 + 0.5 * np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8))
         expect = "generic"
+    elif case == "wave_d20_p10":   # structured G and F on an irregular grid: the per-wave kernel, determinant by a one-wave Cholesky
+        mod = Dlm.polynomial(2)
+        for _ in range(9):
+            mod = mod * Dlm.polynomial(2)
+        mat = materialise(mod, np.cumsum(np.array([1, 2, 1, 0, 3] * 8, dtype=np.float64)) + 1.0)
+        B = rng.standard_normal((10, 10)); A2 = rng.standard_normal((20, 20))
+        p = DlmParameters(B @ B.T / 10 + 0.5 * np.eye(10), A2 @ A2.T / 20 + 0.1 * np.eye(20), rng.standard_normal(20), np.eye(20))
+        expect = "wave-mfma"
+    elif case == "wave_d24_p18_dense_f":   # two-tile Q (p > 16) with a dense F
+        d, q = 24, 18
+        G1 = 0.8 * np.eye(d) + 0.1 * np.eye(d, k=1)
+        F = rng.standard_normal((d, q))
+        mat = materialise(Dlm(lambda t: F, lambda dt: G1), np.arange(1, 31, dtype=np.float64))
+        B = rng.standard_normal((q, q))
+        p = DlmParameters(B @ B.T / q + 0.5 * np.eye(q), np.eye(d) * 0.3, rng.standard_normal(d), np.eye(d))
+        expect = "wave-mfma"
     else:
         d, q = 17, 3
         A = rng.standard_normal((d, d)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
