@@ -1253,3 +1253,64 @@ def test_simulate_on_device_matches_oracle_and_model(eng):
     big = eng.simulate(ll, DlmParameters([[2.0]], [[0.5]], [1.0], [[3.0]]), 20000, seed=3)
     assert abs(big["x"][:, 0, 0].mean() - 1.0) < 0.05 and abs(big["x"][:, 0, 0].var() - 3.0) < 0.1
     assert abs(big["y"][:, 0, 0].var() - 5.5) < 0.2
+
+
+@pytest.mark.parametrize("shape", ["d16_p1", "d48_p24", "d33_p17"])
+def test_per_wave_kernels_edge_shapes_and_status(eng, shape):
+    """dlm_wave48.hip at the corners of its range: one observation component, the largest structured shape, tile counts that
+    leave one row / column in the last tile; T = 1; a series without a single observation; status flags."""
+    rng = np.random.default_rng({"d16_p1": 161, "d48_p24": 4824, "d33_p17": 3317}[shape])
+    if shape == "d16_p1":
+        mod = Dlm.polynomial(2) + Dlm.seasonal(12, 7)     # one observation component, eight nonzeros in F's column (dense-F products)
+    elif shape == "d48_p24":
+        mod = Dlm.polynomial(2)
+        for _ in range(23):
+            mod = mod * Dlm.polynomial(2)
+    else:
+        mod = Dlm.polynomial(1)
+        for _ in range(16):
+            mod = mod * Dlm.polynomial(2)
+    times = np.arange(1, 13, dtype=np.float64)
+    mat = materialise(mod, times)
+    d, q = mat.d, mat.p
+    assert (d, q) == {"d16_p1": (16, 1), "d48_p24": (48, 24), "d33_p17": (33, 17)}[shape]
+    A = rng.standard_normal((d, d)); B = rng.standard_normal((q, q))
+    p = DlmParameters(B @ B.T / q + 0.5 * np.eye(q), A @ A.T / d * 0.05 + 0.02 * np.eye(d), rng.standard_normal(d) * 0.1, np.eye(d) * 0.5)
+    y = rng.standard_normal((3, mat.T, q)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.15] = np.nan
+    y[2] = np.nan                                        # nothing observed at all
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "wave-mfma" and np.all(out["status"] == 0)
+    ll = eng.loglik(mat, p, y)
+    assert eng.last_variant == "wave-mfma"
+    for n in range(3):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], d); sm, S = split(out["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(ll["loglik"][n], oracle.loglik(omodel(mat), oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n]), y[n]),
+                                   rtol=1e-9, atol=1e-8)
+    assert ll["loglik"][2] == 0.0
+    # T = 1
+    mat1 = materialise(mod, [3.0])
+    o1 = eng.filter_smooth(mat1, p, y[:2, :1])
+    assert eng.last_variant == "wave-mfma"
+    f, s = oracle_filter_smooth(mat1, p, y[0, :1])
+    m, C = split(o1["filt"][0], d); sm, S = split(o1["smooth"][0], d)
+    np.testing.assert_allclose(C, f["C"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(S, s["S"], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(sm, s["s"], rtol=1e-7, atol=1e-7)
+    # simulation-smoother draw: construction against the oracle with injected normals
+    z = rng.standard_normal((2, mat.T + 1, d + q))
+    o2 = eng.ffbs(mat, p, y[:2], z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    assert eng.last_variant == "wave-simsmooth" and np.all(o2["status"] == 0)
+    for n in range(2):
+        np.testing.assert_allclose(o2["theta"][n], dk_reference_draw_mv(mat, p, y[n], z[n]), rtol=1e-6, atol=1e-6)
+    # status: a non-finite observation poisons only its own series; an indefinite V is reported
+    yb = y.copy(); yb[1, 4, 0] = np.inf
+    st = eng.filter_smooth(mat, p, yb)["status"]
+    assert st[0] == 0 and st[2] == 0 and (st[1] & _lib.ST_NONFINITE)
+    bad = DlmParameters(-np.eye(q), p.w, p.m0, p.c0)
+    assert eng.filter_smooth(mat, bad, y[:1])["status"][0] & (_lib.ST_NOT_PD | _lib.ST_NONFINITE)
