@@ -1,6 +1,7 @@
 // C-ABI implementation (include/dlm_engine.h): argument checking, host<->device staging,
 // kernel-variant dispatch, RCCL wrapper.  No torch types, no exceptions across the boundary.
 #include "../../include/dlm_engine.h"
+#include <cstdlib>
 #include "dlm_internal.h"
 
 #include <rccl/rccl.h>
@@ -149,6 +150,8 @@ void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params
 bool fast_shape_ok(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::fast_shape(k); }
 // d <= 15, p = 1 fast path: the structured kernels take any time grid, the dense-G MFMA kernels a regular one
 bool use_fast(const dlm_engine* e, const KArgs& k) { return fast_shape_ok(k) && (e->sparse_k > 0 || dlm::mfma16_supported(k)); }
+// d <= 3, p = 1 and thousands of series: one lane per series (DLM_NO_LANE in the environment: A/B measurements)
+bool use_lane(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::lane_supported(k) && !getenv("DLM_NO_LANE"); }
 bool use_tiled(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::tiled_supported(k); }
 
 // Inspect every G of the table (fast-path shapes only) and upload the sparse tables when all of them are
@@ -264,7 +267,10 @@ int ensure_ystar(dlm_engine* e, const KArgs& k) {
 
 // want_side: the caller will run the fast backward pass on this filter's output
 int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
-  if (use_fast(e, k) && (!k.prior || e->sparse_k)) {   // the dense-G MFMA kernel does not write (a, R) records
+  if (use_lane(k)) {
+    e->variant = "lane";
+    HIP_TRY(e, dlm::launch_lane_filter(k, e->stream));
+  } else if (use_fast(e, k) && (!k.prior || e->sparse_k)) {   // the dense-G MFMA kernel does not write (a, R) records
     if (want_side) { int rc = ensure_side(e, k); if (rc) return rc; }
     double* side = want_side ? e->side : nullptr;
     if (e->sparse_k) {
@@ -289,7 +295,10 @@ bool fast_smoother_ok(const dlm_engine* e, const KArgs& k) { return use_fast(e, 
 
 // have_side: the preceding run_filter(.., want_side = true) of THIS call filled e->side
 int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
-  if (have_side && fast_smoother_ok(e, k)) {
+  if (use_lane(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1) && !k.packed) {
+    e->variant = "lane";   // needs nothing from the forward pass: also serves dlm_smooth_batch
+    HIP_TRY(e, dlm::launch_lane_smoother(k, e->stream));
+  } else if (have_side && fast_smoother_ok(e, k)) {
     if (e->sparse_k) {
       e->variant = "sparse16";
       HIP_TRY(e, dlm::launch_sparse16_smoother(k, e->sparse_k, e->sp_dev, e->side, e->stream));
@@ -542,7 +551,7 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
   const bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
   if (!filt) {   // smoothed moments only: the filtered records stay in an engine workspace, packed on the structured path
-    k.packed = (fast_smoother_ok(e, k) && e->sparse_k > 0) ? 1 : 0;
+    k.packed = (fast_smoother_ok(e, k) && e->sparse_k > 0 && !use_lane(k)) ? 1 : 0;
     if ((rc = ensure_fws(e, k.packed ? N * (T + 1) * (size_t)dlm::packed_rec_bytes((int)d) : N * (T + 1) * rec * sizeof(double)))) return rc;
     k.filt = e->fws;
   }

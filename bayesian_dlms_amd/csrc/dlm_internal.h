@@ -101,6 +101,11 @@ size_t svd_filter_lds_bytes(int d, int p);
 hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s);
 hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s);
 
+// ---- one lane per series for d <= 3, p = 1 (dlm_lane.hip): filter (+ prior / forecast records, log-likelihood), RTS smoother
+bool lane_supported(const KArgs& a);
+hipError_t launch_lane_filter(const KArgs& a, hipStream_t s);
+hipError_t launch_lane_smoother(const KArgs& a, hipStream_t s);   // a.filt_in -> a.smooth; no side buffer
+
 // ---- scalar AR(1) FFBS, one lane per series (FilterAr.scala:15-82), dlm_ar1.hip -----------------
 // times != nullptr: the Ornstein-Uhlenbeck variant on that (shared, irregular) time grid (FilterOu.scala:7-79)
 hipError_t launch_ar1_ffbs(int N, int T, const double* times, const double* y, const double* v, long long v_stride,

@@ -1,0 +1,400 @@
+// One LANE per series for the smallest models: d <= 3, p = 1 (local level, linear growth, quadratic trend, a single
+// harmonic, ...; Dlm.scala:139-243) -- the shapes of the reference's first examples (FirstOrderDlm.scala) run over
+// very many series.
+//
+// With d <= 3 a wavefront per series (dlm_sparse16.hip) computes on a 16 x 16 tile that is 1-4 % full and moves
+// 16-96 bytes per step; the recursion of such a model is a few dozen scalar operations.  Here a lane owns a series:
+// the state (m, C) lives in a handful of registers, the model matrices are wave-uniform (scalar loads), and the only
+// traffic is the record stream -- the pass is bound by how well a lane's private, contiguous stream uses HBM, like
+// the AR(1) kernel (dlm_ar1.hip): observations / records are requested a TILE of steps ahead as 16-byte loads and
+// every step's record leaves as whole 16-byte stores (a record of d + d^2 doubles is 2, 6 or 12 doubles).
+//
+// Filter: KalmanFilter.scala:64-118, 262-294 (advance, forecast, masked update; dt == 0: identity advance);
+// log-likelihood :138-153.  Smoother: Smoothing.scala:31-64 in its textbook form
+//   J = C G^T R^-1,  s = m + J (s+ - a+),  S = C - J (R+ - S+) J^T
+// with (a+, R+) recomputed from (m, C) exactly as the filter formed them -- no side buffer, so the same kernel serves
+// the fused call and dlm_smooth_batch.
+#include "dlm_internal.h"
+#include "../../include/dlm_engine.h"
+
+namespace dlm {
+namespace lane {
+
+typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
+constexpr int YT = 16;   // observations requested per tile in the forward pass (one 128-byte line per lane)
+
+template <int D>
+struct Adv { double a[D], R[D][D]; };
+
+// a = G m, R = G C G^T + W dt (lower triangle computed, mirrored); dt == 0: identity advance
+template <int D>
+__device__ __forceinline__ void advance(const double* __restrict__ Gt, double dt, const double (&W)[D][D],
+                                        const double (&m)[D], const double (&C)[D][D], double (&a)[D], double (&R)[D][D]) {
+  if (dt == 0.0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      a[i] = m[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j) R[i][j] = C[i][j];
+    }
+    return;
+  }
+  double G[D][D], T[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int k = 0; k < D; ++k) G[i][k] = Gt[i + k * D];   // column-major table, wave-uniform
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s = fma(G[i][k], m[k], s);
+    a[i] = s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double t_ = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t_ = fma(G[i][k], C[k][j], t_);
+      T[i][j] = t_;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = W[i][j] * dt;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s = fma(T[i][k], G[j][k], s);
+      R[i][j] = s; R[j][i] = s;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void load_w(const double* __restrict__ Wp, double (&W)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) W[i][j] = Wp[i + j * D];
+}
+
+// ---------------------------------------------------------------------------------------
+// forward pass
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
+  constexpr int REC = D + D * D;
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= a.N) return;
+  const int T = a.T;
+  const double* V0 = a.V + (size_t)n * a.v_stride;
+  const double* W0 = a.W + (size_t)n * a.w_stride;
+  double V = V0[0], W[D][D], m[D], C[D][D];
+  load_w<D>(W0, W);
+  {
+    const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+    const double* C0 = a.C0 + (size_t)n * a.c0_stride;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      m[i] = m0[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j) C[i][j] = C0[i + j * D];
+    }
+  }
+  const double* y = a.y + (size_t)n * T;
+  double* out = a.filt ? a.filt + (size_t)n * (T + 1) * REC : nullptr;
+  double* pri = a.prior ? a.prior + (size_t)n * (T + 1) * REC : nullptr;
+  double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
+  int st = 0;
+  double ll = 0.0;
+  auto store = [&](double* base, int t, const double (&mm)[D], const double (&CC)[D][D]) {
+    double r[REC];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = mm[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int i = 0; i < D; ++i) r[D + i + j * D] = CC[i][j];
+    dbl2* o = (dbl2*)(base + (size_t)t * REC);
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) o[q] = dbl2{r[2 * q], r[2 * q + 1]};
+  };
+  if (out) store(out, 0, m, C);
+  if (pri) store(pri, 0, m, C);
+  if (fq) { fq[0] = __builtin_nan(""); fq[1] = __builtin_nan(""); }
+
+  const int Tl = T - 1;
+  double yb[YT];
+  auto request = [&](int t0) {
+    if (t0 + YT <= T && (T & 1) == 0) {   // whole tile, 16-byte aligned stream
+#pragma unroll
+      for (int j = 0; j < YT / 2; ++j) { const dbl2 v = *(const dbl2*)(y + t0 + 2 * j); yb[2 * j] = v.x; yb[2 * j + 1] = v.y; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < YT; ++j) { const int t = t0 + j < Tl ? t0 + j : Tl; yb[j] = y[t]; }
+    }
+  };
+  if (T > 0) request(0);
+  for (int t0 = 0; t0 < T; t0 += YT) {
+    double yc[YT];
+#pragma unroll
+    for (int j = 0; j < YT; ++j) yc[j] = yb[j];
+    if (t0 + YT < T) request(t0 + YT);
+#pragma unroll
+    for (int j = 0; j < YT; ++j) {
+      const int t = t0 + j;
+      if (t < T) {
+        const double dt = a.dt ? a.dt[t] : 1.0;
+        const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
+        const double* Ft = a.F + (size_t)t * a.f_stride;
+        if (a.v_tstride) V = V0[(size_t)t * a.v_tstride];
+        if (a.w_tstride) load_w<D>(W0 + (size_t)t * a.w_tstride, W);
+        double av[D], R[D][D];
+        advance<D>(Gt, dt, W, m, C, av, R);
+        if (pri) store(pri, t + 1, av, R);
+        double F[D], RF[D], f = 0.0, Q = V;
+#pragma unroll
+        for (int i = 0; i < D; ++i) { F[i] = Ft[i]; f = fma(F[i], av[i], f); }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) s = fma(R[i][k], F[k], s);
+          RF[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) Q = fma(F[i], RF[i], Q);
+        if (fq) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
+        const double yt = yc[j];
+        if (yt == yt) {
+          if (!(Q > 0.0)) st |= DLM_ST_NOT_PD;
+          const double e = yt - f, iq = 1.0 / Q;
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            m[i] = fma(RF[i], e * iq, av[i]);
+#pragma unroll
+            for (int k = 0; k <= i; ++k) { const double c_ = fma(-RF[i] * iq, RF[k], R[i][k]); C[i][k] = c_; C[k][i] = c_; }
+          }
+          if (a.loglik) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * e * iq);
+        } else {
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            m[i] = av[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) C[i][k] = R[i][k];
+          }
+        }
+        if (out) store(out, t + 1, m, C);
+      }
+    }
+  }
+  if (a.loglik) a.loglik[n] = ll;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    bad |= !isfinite(m[i]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) bad |= !isfinite(C[i][k]);
+  }
+  if (bad) st |= DLM_ST_NONFINITE;
+  if (a.status && st) atomicOr(&a.status[n], st);
+}
+
+// ---------------------------------------------------------------------------------------
+// backward pass
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
+  constexpr int REC = D + D * D;
+  constexpr int RT = D == 3 ? 4 : 8;     // records requested per tile (128 / 384 / 384 bytes per lane)
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= a.N) return;
+  const int T = a.T;
+  const double* W0 = a.W + (size_t)n * a.w_stride;
+  double W[D][D];
+  load_w<D>(W0, W);
+  const dbl2* in = (const dbl2*)(a.filt_in + (size_t)n * (T + 1) * REC);
+  double* outp = a.smooth + (size_t)n * (T + 1) * REC;
+  int st = 0;
+  double s[D], S[D][D];
+  auto unpack = [&](const dbl2* r, double (&mm)[D], double (&CC)[D][D]) {
+    double v[REC];
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) { v[2 * q] = r[q].x; v[2 * q + 1] = r[q].y; }
+#pragma unroll
+    for (int i = 0; i < D; ++i) mm[i] = v[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int i = 0; i < D; ++i) CC[i][j] = v[D + i + j * D];
+  };
+  auto store = [&](int t, const double (&mm)[D], const double (&CC)[D][D]) {
+    double r[REC];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = mm[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int i = 0; i < D; ++i) r[D + i + j * D] = CC[i][j];
+    dbl2* o = (dbl2*)(outp + (size_t)t * REC);
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) o[q] = dbl2{r[2 * q], r[2 * q + 1]};
+  };
+  {   // record T: the smoothed moments are the filtered ones
+    dbl2 r[REC / 2];
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) r[q] = in[(size_t)T * (REC / 2) + q];
+    unpack(r, s, S);
+    store(T, s, S);
+  }
+  // tiles of records t0 .. t0 + RT - 1 walked downwards from T - 1; the top tile may be ragged
+  dbl2 buf[RT][REC / 2];
+  int t0 = T > 0 ? ((T - 1) / RT) * RT : -1;
+  auto request = [&](int t0) {
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const int t = t0 + j < T ? t0 + j : T - 1;
+#pragma unroll
+      for (int q = 0; q < REC / 2; ++q) buf[j][q] = in[(size_t)t * (REC / 2) + q];
+    }
+  };
+  if (T > 0) request(t0);
+  for (; t0 >= 0; t0 -= RT) {
+    dbl2 cur[RT][REC / 2];
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+      for (int q = 0; q < REC / 2; ++q) cur[j][q] = buf[j][q];
+    if (t0 > 0) request(t0 - RT);
+#pragma unroll
+    for (int j = RT - 1; j >= 0; --j) {
+      const int t = t0 + j;
+      if (t < T) {
+        double m[D], C[D][D];
+        unpack(cur[j], m, C);
+        const double dt = a.dt ? a.dt[t] : 1.0;
+        const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
+        if (a.w_tstride) load_w<D>(W0 + (size_t)t * a.w_tstride, W);
+        double a1[D], R1[D][D];
+        advance<D>(Gt, dt, W, m, C, a1, R1);
+        // Cholesky of R+ (lower), B = C G^T, J = B R+^-1 row by row
+        double L[D][D];
+        bool bad = false;
+#pragma unroll
+        for (int jj = 0; jj < D; ++jj) {
+          double sd = R1[jj][jj];
+#pragma unroll
+          for (int k = 0; k < jj; ++k) sd = fma(-L[jj][k], L[jj][k], sd);
+          if (!(sd > 0.0)) { bad = true; sd = 1e-300; }
+          const double ljj = sqrt(sd), inv = 1.0 / ljj;
+          L[jj][jj] = inv;   // the RECIPROCAL of the diagonal
+#pragma unroll
+          for (int i = jj + 1; i < D; ++i) {
+            double v = R1[i][jj];
+#pragma unroll
+            for (int k = 0; k < jj; ++k) v = fma(-L[i][k], L[jj][k], v);
+            L[i][jj] = v * inv;
+          }
+        }
+        if (bad) st |= DLM_ST_NOT_PD;
+        double J[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          double x[D];
+#pragma unroll
+          for (int jj = 0; jj < D; ++jj) {   // B[i][jj] = sum_k C[i][k] G[jj][k]  (the table entry g(dt), also for dt == 0: Smoothing.scala:41)
+            double b = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) b = fma(C[i][k], Gt[jj + k * D], b);
+            x[jj] = b;
+          }
+#pragma unroll
+          for (int r = 0; r < D; ++r) {      // L z = b
+            double v = x[r];
+#pragma unroll
+            for (int k = 0; k < r; ++k) v = fma(-L[r][k], x[k], v);
+            x[r] = v * L[r][r];
+          }
+#pragma unroll
+          for (int r = D - 1; r >= 0; --r) { // L^T x = z
+            double v = x[r];
+#pragma unroll
+            for (int k = r + 1; k < D; ++k) v = fma(-L[k][r], x[k], v);
+            x[r] = v * L[r][r];
+          }
+#pragma unroll
+          for (int jj = 0; jj < D; ++jj) J[i][jj] = x[jj];
+        }
+        double sn[D], Sn[D][D], X[D][D], JX[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int k = 0; k < D; ++k) X[i][k] = R1[i][k] - S[i][k];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          double v = m[i];
+#pragma unroll
+          for (int k = 0; k < D; ++k) v = fma(J[i][k], s[k] - a1[k], v);
+          sn[i] = v;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            double w = 0.0;
+#pragma unroll
+            for (int q = 0; q < D; ++q) w = fma(J[i][q], X[q][k], w);
+            JX[i][k] = w;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int k = 0; k <= i; ++k) {
+            double w = C[i][k];
+#pragma unroll
+            for (int q = 0; q < D; ++q) w = fma(-JX[i][q], J[k][q], w);
+            Sn[i][k] = w; Sn[k][i] = w;
+          }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          s[i] = sn[i];
+#pragma unroll
+          for (int k = 0; k < D; ++k) S[i][k] = Sn[i][k];
+        }
+        store(t, s, S);
+      }
+    }
+  }
+  bool nf = false;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    nf |= !isfinite(s[i]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) nf |= !isfinite(S[i][k]);
+  }
+  if (nf) st |= DLM_ST_NONFINITE;
+  if (a.status && st) atomicOr(&a.status[n], st);
+}
+
+}  // namespace lane
+
+// d <= 3, p = 1, enough series to fill the chip with lanes (below that a wavefront per series finishes sooner);
+// per-step V_t / W_t streams are read per lane, any time grid, time-varying F.
+bool lane_supported(const KArgs& a) {
+  return a.d >= 1 && a.d <= 3 && a.p == 1 && a.N >= 8192 && (((size_t)a.T + 1) * (a.d + a.d * a.d)) % 2 == 0;
+}
+
+hipError_t launch_lane_filter(const KArgs& a, hipStream_t s) {
+  const dim3 grid((a.N + 63) / 64), block(64);
+  if (a.d == 1) hipLaunchKernelGGL(lane::k_filter_lane<1>, grid, block, 0, s, a);
+  else if (a.d == 2) hipLaunchKernelGGL(lane::k_filter_lane<2>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(lane::k_filter_lane<3>, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_lane_smoother(const KArgs& a, hipStream_t s) {
+  const dim3 grid((a.N + 63) / 64), block(64);
+  if (a.d == 1) hipLaunchKernelGGL(lane::k_smoother_lane<1>, grid, block, 0, s, a);
+  else if (a.d == 2) hipLaunchKernelGGL(lane::k_smoother_lane<2>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(lane::k_smoother_lane<3>, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace dlm

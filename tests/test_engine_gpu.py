@@ -1314,3 +1314,58 @@ def test_per_wave_kernels_edge_shapes_and_status(eng, shape):
     assert st[0] == 0 and st[2] == 0 and (st[1] & _lib.ST_NONFINITE)
     bad = DlmParameters(-np.eye(q), p.w, p.m0, p.c0)
     assert eng.filter_smooth(mat, bad, y[:1])["status"][0] & (_lib.ST_NOT_PD | _lib.ST_NONFINITE)
+
+
+@pytest.mark.parametrize("kind", ["local_level", "linear_growth_irregular", "harmonic_plus_level_d3", "regression_d2_timevarying_f"])
+def test_lane_per_series_small_models(eng, kind):
+    """d <= 3, p = 1 over thousands of series: one lane per series (dlm_lane.hip) -- filter with prior / forecast records,
+    log-likelihood, the textbook RTS smoother (fused and standalone) against the oracle and against the wavefront-per-series path."""
+    rng = np.random.default_rng({"local_level": 11, "linear_growth_irregular": 12, "harmonic_plus_level_d3": 13,
+                                 "regression_d2_timevarying_f": 14}[kind])
+    N = 8192
+    if kind == "local_level":
+        mod = Dlm.polynomial(1); times = np.arange(1, 38, dtype=np.float64)
+    elif kind == "linear_growth_irregular":
+        mod = Dlm.polynomial(2); times = np.cumsum(np.array([1, 2, 1, 0, 3, 1, 1] * 5, dtype=np.float64)) + 1.0
+    elif kind == "harmonic_plus_level_d3":
+        mod = Dlm.polynomial(1) + Dlm.seasonal(12, 1); times = np.arange(1, 30, dtype=np.float64)
+    else:
+        xs = rng.standard_normal(33)
+        mod = Dlm(lambda t: np.array([[1.0], [xs[int(t) - 1]]]), lambda dt: np.eye(2)); times = np.arange(1, 34, dtype=np.float64)
+    mat = materialise(mod, times)
+    d, T = mat.d, mat.T
+    A = rng.standard_normal((d, d))
+    p = DlmParameters([[0.7]], A @ A.T / d * 0.3 + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d) * 2.0)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    y[5] = np.nan
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "lane" and np.all(out["status"] == 0)
+    pf = eng.filter(mat, p, y, want_prior=True, want_fq=True)
+    assert eng.last_variant == "lane"
+    ll = eng.loglik(mat, p, y)
+    assert eng.last_variant == "lane"
+    sm2 = eng.smooth(mat, p, out["filt"])                 # standalone smoother on the same kernel
+    assert eng.last_variant == "lane"
+    np.testing.assert_array_equal(sm2["smooth"], out["smooth"])
+    for n in (0, 5, 63, 64, 4097, N - 1):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], d); sm, S = split(out["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-9, atol=1e-9)
+        a_, R_ = split(pf["prior"][n], d)
+        np.testing.assert_allclose(a_[1:], f["a"][1:], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(R_[1:], f["R"][1:], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(pf["fq"][n][1:, 0], np.asarray(f["f"])[1:].reshape(T), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(pf["fq"][n][1:, 1], np.asarray(f["Q"])[1:].reshape(T), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(ll["loglik"][n], oracle.loglik(omodel(mat), f, y[n]), rtol=1e-10, atol=1e-9)
+    os.environ["DLM_NO_LANE"] = "1"
+    try:
+        ref = eng.filter_smooth(mat, p, y)
+        assert eng.last_variant != "lane"
+    finally:
+        del os.environ["DLM_NO_LANE"]
+    np.testing.assert_allclose(out["filt"], ref["filt"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(out["smooth"], ref["smooth"], rtol=1e-8, atol=1e-8)
