@@ -66,6 +66,22 @@ def main():
         dt = timeit(lambda: eng.ffbs(mat, p, y, seed=1, want_theta=False, flags=_lib.OPT_STATS_OUTER | _lib.OPT_FFBS_SIMSMOOTH), reps=2)
         print(json.dumps({"config": "C4 FFBS + outer-product stats (simulation smoother), d=40, p=20, N=2000, T=1000", "variant": eng.last_variant,
                           "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "lane" in which:   # the smallest models over very many series: one lane per series (dlm_lane.hip)
+        for name, mod, d, N in (("local level (polynomial(1)), d=1", Dlm.polynomial(1), 1, 500000),
+                                ("linear growth (polynomial(2)), d=2", Dlm.polynomial(2), 2, 200000)):
+            T = 1000
+            mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+            p = DlmParameters([[2.0]], np.eye(d) * 0.5, np.zeros(d), np.eye(d) * 10.0)
+            y = torch.randn((N, T, 1), device=dev, dtype=torch.float64).cumsum(dim=1)
+            out = {"filt": torch.empty((N, T + 1, d + d * d), device=dev, dtype=torch.float64),
+                   "smooth": torch.empty((N, T + 1, d + d * d), device=dev, dtype=torch.float64),
+                   "status": torch.zeros((N,), device=dev, dtype=torch.int32)}
+            dt = timeit(lambda: eng.filter_smooth(mat, p, y, out=out))
+            fwd, bwd = eng.last_timing()
+            rec = (d + d * d) * 8
+            print(json.dumps({"config": f"filter+smooth, {name}, N={N}, T={T}", "variant": eng.last_variant, "ms": dt * 1e3,
+                              "forward_ms": fwd, "backward_ms": bwd, "series_steps_per_s": N * T / dt,
+                              "GBps_algorithmic": N * T * (8 + 3 * rec) / dt / 1e9}))
     if "c2s" in which:
         mod, p = seasonal_c2(); N, T = 10000, 1000
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
