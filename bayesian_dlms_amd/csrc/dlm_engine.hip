@@ -580,8 +580,10 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
   const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
-  if (simflag && (params->v_tstride || params->w_tstride))
-    return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes time-invariant V and W (drop DLM_OPT_FFBS_SIMSMOOTH for V_t / W_t streams)");
+  // a V_t stream is a scalar per step on the structured d <= 15, p = 1 path (the Student-t DLM, StudentTGibbs.scala:100-136)
+  // and goes through; W_t streams and V_t elsewhere would need a factorisation per step
+  if (simflag && (params->w_tstride || (params->v_tstride && !(model->p == 1 && model->d <= 15))))
+    return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes a time-invariant W, and a V_t stream only on the structured d <= 15, p = 1 path (drop DLM_OPT_FFBS_SIMSMOOTH otherwise)");
   st.in(&k.y, y, y ? N * T * p : 0);
   st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + p : d) : 0);
   if (forward) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
@@ -602,6 +604,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       HIP_TRY(e, dlm::launch_sparse16_simsmooth(k, e->sparse_k, e->sp_dev, e->side, e->xplus, e->stream));
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
+    if (simflag && k.v_tstride)
+      return fail(e, DLM_ERR_UNSUPPORTED, "a V_t stream with DLM_OPT_FFBS_SIMSMOOTH needs the structured d <= 15, p = 1 path (this G is dense)");
     if (simflag && use_tiled(k)) {
       if ((rc = ensure_xplus(e, k)) || (rc = ensure_ystar(e, k))) return rc;
       e->variant = dlm::wave48_simsmooth_supported(k) ? "wave-simsmooth" : "tiled-simsmooth";

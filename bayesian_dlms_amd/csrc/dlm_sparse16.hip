@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
         else { wl = 0.0; for (int k = 0; k <= c && k < d; ++k) wl = fma(imgW[c * LD + k], zr[k], wl); }
         xcol = vc ? fma(wl, sqrt(dt), xg) : 0.0;
       }
-      const double yplus = fma(sqV, zr[d], row_sum(Fc * xcol));
+      const double yplus = fma((IRR && a.v_tstride) ? sqrt(V) : sqV, zr[d], row_sum(Fc * xcol));   // V_t of this step when time-varying
       yt = yt - yplus;                                       // NaN (missing) stays NaN
       if (g == 0 && vc) xp[(size_t)(t + 1) * d + c] = xcol;
     }
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
 
   const double V = a.V[(size_t)n * a.v_stride];
-  const double rV = 1.0 / V;
+  double rV = 1.0 / V;   // 1 / V_t of the record's observation when time-varying (IRR instantiation)
   const char* bin = (const char*)a.filt_in + (size_t)n * (T + 1) * recb;
   const __amdgpu_buffer_rsrc_t rin = make_rsrc(bin, (size_t)(T + 1) * recb);
   const double* sd = side + (size_t)n * (T + 1) * 2;
@@ -867,6 +867,11 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
     if (t == 0) break;
 
     double rcol = qcol;
+    if (IRR && a.v_tstride) {                                // V of the observation at record t (StudentTGibbs.scala:100-136)
+      const double Vt = a.V[(size_t)n * a.v_stride + (size_t)(t - 1) * a.v_tstride];
+      if (!(Vt > 0.0)) st |= DLM_ST_NOT_PD;
+      rV = 1.0 / Vt;
+    }
     if (observed) {
       double kc = 0.0;
 #pragma unroll
@@ -949,7 +954,7 @@ static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, doub
 }
 template <int K>
 static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* side, const double* xplus, hipStream_t s) {
-  if (a.g_index || a.dt || a.f_stride) hipLaunchKernelGGL((k_simsmooth_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  if (a.g_index || a.dt || a.f_stride || a.v_tstride) hipLaunchKernelGGL((k_simsmooth_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
   else hipLaunchKernelGGL((k_simsmooth_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
   return hipGetLastError();
 }

@@ -1369,3 +1369,36 @@ def test_lane_per_series_small_models(eng, kind):
         del os.environ["DLM_NO_LANE"]
     np.testing.assert_allclose(out["filt"], ref["filt"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(out["smooth"], ref["smooth"], rtol=1e-8, atol=1e-8)
+
+
+def test_simulation_smoother_with_scalar_variance_stream(eng):
+    """The Student-t DLM's FFBS (StudentTGibbs.scala:100-136: V_t = V / lambda_t, p = 1) on the structured fast path with
+    DLM_OPT_FFBS_SIMSMOOTH: the draw is the Durbin-Koopman construction with the per-step variances, statistics included;
+    W_t streams and V_t on other paths are refused."""
+    mod, mat, p = seasonal_model(T=60)
+    d, T, N = 13, mat.T, 3
+    rng = np.random.default_rng(808)
+    Vt = rng.uniform(0.3, 3.0, (T, 1, 1))
+    pt = DlmParameters(Vt, p.w, p.m0, p.c0)
+    y = simulate(mat, p, N, seed=5, missing=0.1)
+    z = rng.standard_normal((N, T + 1, d + 1))
+    out = eng.ffbs(mat, pt, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    assert eng.last_variant == "sparse16-simsmooth" and np.all(out["status"] == 0)
+    om = omodel(mat)
+    G = oracle.from_cm(mat.G[:d * d], d, d); F = np.asarray(mat.F[:d])
+    Lc, Lw = np.linalg.cholesky(p.c0), np.linalg.cholesky(p.w)
+    for n in range(N):
+        x = p.m0 + Lc @ z[n, 0, :d]
+        xs, yp = [x], np.empty((T, 1))
+        for t in range(1, T + 1):
+            x = G @ x + Lw @ z[n, t, :d]
+            xs.append(x); yp[t - 1, 0] = F @ x + np.sqrt(Vt[t - 1, 0, 0]) * z[n, t, d]
+        f = oracle.kf_filter(om, Vt, p.w, np.zeros(d), p.c0, y[n] - yp)
+        ref = oracle.smoother(om, f)["s"] + np.array(xs)
+        np.testing.assert_allclose(out["theta"][n], ref, rtol=1e-7, atol=1e-8)
+        st = oracle.gibbs_stats(om, y[n], ref)
+        np.testing.assert_allclose(out["stats"][n, 0], st["ssy"][0], rtol=1e-7)
+        np.testing.assert_allclose(out["stats"][n, 2:2 + d], st["ss"], rtol=1e-7)
+    Wt = np.tile(p.w, (T, 1, 1))
+    with pytest.raises(EngineError):
+        eng.ffbs(mat, DlmParameters(p.v, Wt, p.m0, p.c0), y, flags=_lib.OPT_FFBS_SIMSMOOTH)
