@@ -152,7 +152,9 @@ bool fast_shape_ok(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) &
 bool use_fast(const dlm_engine* e, const KArgs& k) { return fast_shape_ok(k) && (e->sparse_k > 0 || dlm::mfma16_supported(k)); }
 // d <= 3, p = 1 and thousands of series: one lane per series (DLM_NO_LANE in the environment: A/B measurements)
 bool use_lane(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::lane_supported(k) && !getenv("DLM_NO_LANE"); }
-bool use_tiled(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::tiled_supported(k); }
+// the d >= 16 kernels, or -- d <= 15 with several observation components and a structured G -- the per-wave kernels
+bool use_tiled(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && (dlm::tiled_supported(k) || dlm::wave48_small_ok(k)); }
+bool tiled_analysis_wanted(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && (dlm::tiled_supported(k) || dlm::wave48_small_shape(k)); }
 
 // Inspect every G of the table (fast-path shapes only) and upload the sparse tables when all of them are
 // structured.  `G_user` is the caller's pointer (host or device according to host_mode).
@@ -199,7 +201,7 @@ int analyse_g_tiled(dlm_engine* e, KArgs& k, const double* G_user, bool host_mod
 int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   e->sparse_k = 0;
   k.spb = nullptr;
-  if (use_tiled(k)) return analyse_g_tiled(e, k, G_user, host_mode);
+  if (tiled_analysis_wanted(k)) return analyse_g_tiled(e, k, G_user, host_mode);
   if (!fast_shape_ok(k)) return DLM_OK;
   const size_t dd = (size_t)k.d * k.d, ng = (size_t)k.n_g;
   std::vector<double> g(dd * ng);

@@ -1449,12 +1449,19 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
 // workgroup-per-series kernels of dlm_tiled.hip finish a step sooner (10.8 against 13 us at d = 40, p = 20).
 // DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip, DLM_FORCE_WAVE48 lifts the batch-size rule (A/B
 // measurements and the parity tests of the two paths).
+// Multivariate models below the tiled range (d <= 15, 2 <= p <= 32) run on the same kernels with one tile per dimension:
+// their only alternative is the generic LDS kernel, so the batch-size rule does not apply to them.
+bool wave48_small_shape(const KArgs& a) {
+  return a.d >= 1 && a.d <= 15 && a.p >= 2 && a.p <= 32 && ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);
+}
 static bool wave48_wanted(const KArgs& a) {
   if (getenv("DLM_NO_WAVE48")) return false;
-  return a.N > 256 || getenv("DLM_FORCE_WAVE48");
+  return wave48_small_shape(a) || a.N > 256 || getenv("DLM_FORCE_WAVE48");
 }
+static bool shape_ok(const KArgs& a) { return tiled_supported(a) || wave48_small_shape(a); }
+bool wave48_small_ok(const KArgs& a) { return wave48_small_shape(a) && a.spb && !a.v_tstride && !a.w_tstride && !getenv("DLM_NO_WAVE48"); }
 bool wave48_filter_supported(const KArgs& a) {
-  return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
+  return shape_ok(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
 }
 
 template <int DT, int PT>
@@ -1472,7 +1479,7 @@ static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, int 
   return hipGetLastError();
 }
 
-bool wave48_smoother_supported(const KArgs& a) { return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a); }
+bool wave48_smoother_supported(const KArgs& a) { return shape_ok(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a); }
 
 template <int DT, int PT>
 static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {
@@ -1491,6 +1498,8 @@ static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* inn
 
 hipError_t launch_wave48_smoother(const KArgs& a, int K, const double* innov, hipStream_t s) {
   const bool d2 = a.d <= 32, p1 = a.p <= 16;
+  if (a.d <= 16 && p1) return launch_w48_smoother_k<1, 1>(a, K, innov, s);
+  if (a.d <= 16) return launch_w48_smoother_k<1, 2>(a, K, innov, s);
   if (d2 && p1) return launch_w48_smoother_k<2, 1>(a, K, innov, s);
   if (d2) return launch_w48_smoother_k<2, 2>(a, K, innov, s);
   if (p1) return launch_w48_smoother_k<3, 1>(a, K, innov, s);
@@ -1499,6 +1508,8 @@ hipError_t launch_wave48_smoother(const KArgs& a, int K, const double* innov, hi
 
 static hipError_t launch_wave48_filter_z(const KArgs& a, int K, double* innov, int zero_m0, hipStream_t s) {
   const bool d2 = a.d <= 32, p1 = a.p <= 16;
+  if (a.d <= 16 && p1) return launch_w48_filter_k<1, 1>(a, K, innov, zero_m0, s);
+  if (a.d <= 16) return launch_w48_filter_k<1, 2>(a, K, innov, zero_m0, s);
   if (d2 && p1) return launch_w48_filter_k<2, 1>(a, K, innov, zero_m0, s);
   if (d2) return launch_w48_filter_k<2, 2>(a, K, innov, zero_m0, s);
   if (p1) return launch_w48_filter_k<3, 1>(a, K, innov, zero_m0, s);
@@ -1510,7 +1521,7 @@ hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_
 // y* = y - y+ in `ystar`; the forward pass filters y* from a zero prior mean and overwrites y*_t by its innovation (it has
 // read y*_{t+1} by then); the mean-only backward pass adds x+.
 bool wave48_simsmooth_supported(const KArgs& a) {
-  return tiled_supported(a) && a.spb && !a.v_tstride && !a.w_tstride && !a.cond && wave48_wanted(a);
+  return shape_ok(a) && a.spb && !a.v_tstride && !a.w_tstride && !a.cond && wave48_wanted(a);
 }
 
 template <int DT, int PT>
@@ -1550,6 +1561,8 @@ hipError_t launch_wave48_simsmooth(const KArgs& a, int K, double* xplus, double*
   KArgs b = a;
   b.filt_in = a.filt;
   const bool d2 = a.d <= 32, p1 = a.p <= 16;
+  if (a.d <= 16 && p1) return launch_w48_sims_k<1, 1>(b, K, xplus, ystar, s);
+  if (a.d <= 16) return launch_w48_sims_k<1, 2>(b, K, xplus, ystar, s);
   if (d2 && p1) return launch_w48_sims_k<2, 1>(b, K, xplus, ystar, s);
   if (d2) return launch_w48_sims_k<2, 2>(b, K, xplus, ystar, s);
   if (p1) return launch_w48_sims_k<3, 1>(b, K, xplus, ystar, s);

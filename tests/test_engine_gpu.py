@@ -976,7 +976,7 @@ def test_log_likelihood_prediction_error_decomposition(eng, case):
         mat = materialise(mod, np.cumsum(np.array([1, 2, 1, 1, 3] * 8, dtype=np.float64)))
         B = rng.standard_normal((4, 4))
         p = DlmParameters(B @ B.T / 4 + 0.5 * np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8))
-        expect = "generic"
+        expect = "wave-mfma"   # d <= 15 with p > 1 and a structured G: the per-wave kernels, one tile per dimension
     elif case == "wave_d20_p10":   # structured G and F on an irregular grid: the per-wave kernel, determinant by a one-wave Cholesky
         mod = Dlm.polynomial(2)
         for _ in range(9):
@@ -1223,7 +1223,7 @@ def test_fused_call_without_filtered_output(eng, case):
     else:
         mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
         mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
-        p = DlmParameters(np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8)); expect = "generic"
+        p = DlmParameters(np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8)); expect = "wave-mfma"   # d <= 15 with p > 1: the per-wave kernels, one tile per dimension
     y = rng.standard_normal((5, mat.T, mat.p)).cumsum(axis=1)
     y[rng.random(y.shape) < 0.1] = np.nan
     full = eng.filter_smooth(mat, p, y)
@@ -1402,3 +1402,52 @@ def test_simulation_smoother_with_scalar_variance_stream(eng):
     Wt = np.tile(p.w, (T, 1, 1))
     with pytest.raises(EngineError):
         eng.ffbs(mat, DlmParameters(p.v, Wt, p.m0, p.c0), y, flags=_lib.OPT_FFBS_SIMSMOOTH)
+
+
+@pytest.mark.parametrize("shape", ["bivariate_local_level", "d6_p3_irregular", "d12_p4_harmonics"])
+def test_small_multivariate_models_on_per_wave_kernels(eng, shape):
+    """d <= 15 with several observation components (|*| of small models, Dlm.scala:197-208): the per-wave kernels with one tile per
+    dimension -- filter + smoother, log-likelihood and the simulation-smoother draw against the oracle, and against the generic path."""
+    rng = np.random.default_rng({"bivariate_local_level": 22, "d6_p3_irregular": 63, "d12_p4_harmonics": 124}[shape])
+    if shape == "bivariate_local_level":
+        mod = Dlm.polynomial(1) * Dlm.polynomial(1); times = np.arange(1, 41, dtype=np.float64)
+    elif shape == "d6_p3_irregular":
+        mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
+        times = np.cumsum(np.array([1, 2, 1, 0, 3, 1] * 6, dtype=np.float64)) + 1.0
+    else:
+        one = Dlm.polynomial(1) + Dlm.seasonal(12, 1)
+        mod = one * one * one * one; times = np.arange(1, 31, dtype=np.float64)
+    mat = materialise(mod, times)
+    d, q, T = mat.d, mat.p, mat.T
+    A = rng.standard_normal((d, d)); B = rng.standard_normal((q, q))
+    p = DlmParameters(B @ B.T / q + 0.5 * np.eye(q), A @ A.T / d * 0.2 + 0.05 * np.eye(d), rng.standard_normal(d), np.eye(d) * 1.5)
+    N = 5
+    y = rng.standard_normal((N, T, q)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.15] = np.nan
+    y[:, 3, :] = np.nan
+    out = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "wave-mfma" and np.all(out["status"] == 0)
+    ll = eng.loglik(mat, p, y)
+    assert eng.last_variant == "wave-mfma"
+    gen = eng.filter_smooth(mat, p, y, flags=_lib.OPT_FORCE_GENERIC)
+    assert eng.last_variant == "generic"
+    np.testing.assert_allclose(out["filt"], gen["filt"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out["smooth"], gen["smooth"], rtol=1e-8, atol=1e-9)
+    z = rng.standard_normal((N, T + 1, d + q))
+    dr = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_STATS_OUTER)
+    assert eng.last_variant == "wave-simsmooth" and np.all(dr["status"] == 0)
+    om = omodel(mat)
+    for n in range(N):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, C = split(out["filt"][n], d); sm, S = split(out["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(C, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(ll["loglik"][n], oracle.loglik(om, f, y[n]), rtol=1e-10, atol=1e-9)
+        if mat.dt is None:   # (the reference construction below is written for a regular grid)
+            ref = dk_reference_draw_mv(mat, p, y[n], z[n])
+            np.testing.assert_allclose(dr["theta"][n], ref, rtol=1e-7, atol=1e-8)
+            st = oracle.gibbs_stats(om, y[n], ref, want_outer=True)
+            np.testing.assert_allclose(dr["stats"][n, :q], st["ssy"], rtol=1e-7)
+            np.testing.assert_allclose(dr["stats"][n, 2 * q:2 * q + d * d], st["outer"], rtol=1e-6, atol=1e-7)

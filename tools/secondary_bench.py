@@ -82,6 +82,17 @@ def main():
             print(json.dumps({"config": f"filter+smooth, {name}, N={N}, T={T}", "variant": eng.last_variant, "ms": dt * 1e3,
                               "forward_ms": fwd, "backward_ms": bwd, "series_steps_per_s": N * T / dt,
                               "GBps_algorithmic": N * T * (8 + 3 * rec) / dt / 1e9}))
+    if "mv8" in which:   # a small multivariate model (d = 8, p = 4): per-wave kernels with one tile per dimension vs the generic path
+        from bayesian_dlms_amd import _lib
+        mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
+        N, T = 10000, 1000
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        p = DlmParameters(np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8))
+        y = torch.randn((N, T, 4), device=dev, dtype=torch.float64).cumsum(dim=1)
+        for name, fl in (("per-wave", 0), ("generic", _lib.OPT_FORCE_GENERIC)):
+            dt = timeit(lambda: eng.filter_smooth(mat, p, y, flags=fl), reps=2)
+            print(json.dumps({"config": f"filter+smooth, d=8, p=4 (4 x linear growth), N={N}, T={T} ({name})", "variant": eng.last_variant,
+                              "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
     if "c2s" in which:
         mod, p = seasonal_c2(); N, T = 10000, 1000
         mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
