@@ -28,13 +28,24 @@ namespace w48 {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
-constexpr int IL = 49;          // leading dimension of the LDS image (odd: row-wise and transposed reads both spread over the banks)
-constexpr int IMG = 48 * IL;
-constexpr int QL = 33;          // leading dimension of the p x p scratch of the direct inverse
 constexpr int OOB = 0x7ffffff0;
-constexpr int FLD = 33;         // leading dimension of the LDS copy of F (d x p, row-major)
-constexpr int FIMG = 48 * FLD;
-constexpr int LDS_DOUBLES = IMG + FIMG + 10 * 48;
+// LDS of one wave, sized by the tile counts of the instantiation (DT tiles for d, PT for p, MX the larger): the image
+// (16 MX rows, odd leading dimension: row-wise and transposed reads both spread over the banks), the copy of F or the
+// tables of a structured F, the scratch of the direct inverse, ten vectors.  8 KB at one tile per dimension, 35 KB at
+// d = 48 / p = 32: the small shapes keep several waves per SIMD resident.
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int il_of(int DT, int PT) { return 16 * cmax(DT, PT) + 1; }
+constexpr int img_of(int DT, int PT) { return 16 * cmax(DT, PT) * il_of(DT, PT); }
+constexpr int fld_of(int PT) { return 16 * PT + 1; }
+constexpr int fimg_of(int DT, int PT) { return cmax(16 * DT * fld_of(PT), 192); }
+constexpr int inv_of(int PT) { return 16 * PT * (16 * PT + 1); }
+constexpr int vl_of(int DT, int PT) { return 16 * cmax(DT, PT); }
+// the scratch of the direct inverse (its second half: the first is the image) sits in the image too when that is large enough
+constexpr bool inv_in_img(int DT, int PT) { return img_of(DT, PT) >= 2 * inv_of(PT); }
+constexpr int inv_extra(int DT, int PT) { return inv_in_img(DT, PT) ? 0 : inv_of(PT); }
+constexpr int lds_doubles(int DT, int PT) { return img_of(DT, PT) + fimg_of(DT, PT) + inv_extra(DT, PT) + 10 * vl_of(DT, PT); }
+constexpr int FIMG = 48 * 33;   // (the prologue kernel's own fixed layout)
+constexpr int FLD = 33;
 
 __device__ __forceinline__ void wave_sync() {   // LDS hand-off between lanes of one wave (in-order LDS queue)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -87,7 +98,7 @@ __device__ __forceinline__ void mmT(const d4 (&X)[KT][MT], const d4 (&Y)[KT][NT]
 // Complete a symmetric matrix from its upper tiles: lower tiles by transposition through the image, diagonal tiles
 // averaged with their own transposes (exactly symmetric result).  FULL: all tiles are given; every tile is averaged
 // with the transpose of its mirror tile instead.
-template <int MT, bool FULL, bool KEEP = false>   // KEEP: leave the completed matrix in the image
+template <int IL, int MT, bool FULL, bool KEEP = false>   // KEEP: leave the completed matrix in the image
 __device__ __forceinline__ void mirror(d4 (&Z)[MT][MT], double* img, int g, int c) {
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -124,7 +135,7 @@ __device__ __forceinline__ void mirror(d4 (&Z)[MT][MT], double* img, int g, int 
 }
 
 // ST = S^T for an (MT x NT)-tile matrix
-template <int MT, int NT>
+template <int IL, int MT, int NT>
 __device__ __forceinline__ void transpose(const d4 (&S)[MT][NT], d4 (&ST)[NT][MT], double* img, int g, int c) {
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -171,7 +182,7 @@ __device__ __forceinline__ void f_tiles(const double* Fl, d4 (&Ft)[DT][PT], int 
 #pragma unroll
     for (int b = 0; b < PT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ft[a][b][r] = Fl[(16 * a + 4 * r + g) * FLD + 16 * b + c];
+      for (int r = 0; r < 4; ++r) Ft[a][b][r] = Fl[(16 * a + 4 * r + g) * fld_of(PT) + 16 * b + c];
 }
 template <int DT, int PT>
 __device__ __forceinline__ void ft_tiles(const double* Fl, d4 (&FT)[PT][DT], int g, int c) {     // F^T as [p-tiles][d-tiles]
@@ -180,20 +191,20 @@ __device__ __forceinline__ void ft_tiles(const double* Fl, d4 (&FT)[PT][DT], int
 #pragma unroll
     for (int b = 0; b < DT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) FT[a][b][r] = Fl[(16 * b + c) * FLD + 16 * a + 4 * r + g];
+      for (int r = 0; r < 4; ++r) FT[a][b][r] = Fl[(16 * b + c) * fld_of(PT) + 16 * a + 4 * r + g];
 }
 template <int DT, int PT>
 __device__ __forceinline__ void load_f_lds(double* Fl, const double* F, int d, int p, int lane) {   // F column-major d x p in global memory
-  for (int idx = lane; idx < 48 * 32; idx += 64) {
-    const int i = idx % 48, j = idx / 48;
-    Fl[i * FLD + j] = (i < d && j < p) ? F[i + j * d] : 0.0;
+  for (int idx = lane; idx < 16 * DT * 16 * PT; idx += 64) {
+    const int i = idx % (16 * DT), j = idx / (16 * DT);
+    Fl[i * fld_of(PT) + j] = (i < d && j < p) ? F[i + j * d] : 0.0;
   }
 }
 
 // Z = T X T^T (+ Wt dt on the upper tiles) for symmetric X, T given by the row tables (tix, tvl) of the lanes' columns:
 //   pass 1   Y[i][j] = sum_s X[i][idx_s(j)] val_s(j)          (= X T^T)
 //   pass 2   Z[i][j] = sum_s Y[idx_s(j)][i] val_s(j)          (= (T Y)^T = T X T^T), upper tiles, then mirrored
-template <int DT, int K, bool ADDW, bool KEEP = false>
+template <int IL, int DT, int K, bool ADDW, bool KEEP = false>
 __device__ __forceinline__ void congruence(d4 (&C)[DT][DT], const d4 (&Wt)[DT][DT], double dt, const int (&tix)[DT][K],
                                            const double (&tvl)[DT][K], double* img, int g, int c) {
 #pragma unroll
@@ -236,7 +247,7 @@ __device__ __forceinline__ void congruence(d4 (&C)[DT][DT], const d4 (&Wt)[DT][D
         C[aa][b][r] = s_;
       }
   wave_sync();
-  mirror<DT, false, KEEP>(C, img, g, c);
+  mirror<IL, DT, false, KEEP>(C, img, g, c);
 }
 // y[j] = sum_s x[idx_s(j)] val_s(j) for the lanes' columns (x: LDS vector)
 template <int DT, int K>
@@ -267,7 +278,7 @@ __device__ __forceinline__ void mmT_acc_up(const d4 (&X)[KT][MT], const d4 (&Y)[
 // Products with a structured F as gathers through the image (tables: SparseF).
 // Z[j][i] = sum_s val_s(j) X[idx_s(j)][i] (= F^T X) for the rows j = 16 a + 4 r + g of a p-row result; the column
 // tables of F are read from LDS (ci: [32][4] ints, cv: [32][4] doubles), X is in the image.
-template <int PT, int NT, int KF>
+template <int IL, int PT, int NT, int KF>
 __device__ __forceinline__ void ft_times_image(d4 (&Z)[PT][NT], const double* img, const int* ci, const double* cv, int g, int c) {
 #pragma unroll
   for (int a = 0; a < PT; ++a)
@@ -290,7 +301,7 @@ __device__ __forceinline__ void ft_times_image(d4 (&Z)[PT][NT], const double* im
 }
 // Z[i][i'] = sum_s X[i][idx_s(i')] val_s(i') (= X F^T) for an (MT x .)-tile X in the image; (ri, rv): the row tables of F
 // of the lanes' columns i' = 16 b + c.
-template <int MT, int DT, int KF>
+template <int IL, int MT, int DT, int KF>
 __device__ __forceinline__ void image_times_ft(d4 (&Z)[MT][DT], const double* img, const int (&ri)[DT][KF], const double (&rv)[DT][KF], int g) {
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -305,7 +316,7 @@ __device__ __forceinline__ void image_times_ft(d4 (&Z)[MT][DT], const double* im
         Z[a][b][r] = s_;
       }
 }
-template <int MT, int NT>
+template <int IL, int MT, int NT>
 __device__ __forceinline__ void to_image(const d4 (&X)[MT][NT], double* img, int g, int c) {
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -328,9 +339,9 @@ __device__ __forceinline__ void load_f_tables(const SparseF* spf, int* ci, doubl
 // the LDS image (fallback of the Newton-Schulz refinement: first step, changed missingness pattern).  Returns whether
 // a non-positive pivot was met.
 template <int PT>
-__device__ __forceinline__ bool direct_inverse(const d4 (&Q)[PT][PT], d4 (&X)[PT][PT], int n, double* img, int lane, int g, int c) {
-  double* L = img;              // n x n, row-major, leading dimension QL
-  double* B = img + 32 * QL;    // the inverse, column j by lane j
+__device__ __forceinline__ bool direct_inverse(const d4 (&Q)[PT][PT], d4 (&X)[PT][PT], int n, double* img, double* B, int lane, int g, int c) {
+  constexpr int QL = 16 * PT + 1;
+  double* L = img;              // n x n, row-major, leading dimension QL; B: the inverse, column j by lane j
 #pragma unroll
   for (int a = 0; a < PT; ++a)
 #pragma unroll
@@ -384,8 +395,8 @@ __device__ __forceinline__ bool direct_inverse(const d4 (&Q)[PT][PT], d4 (&X)[PT
 // X <- (SPD Q)^-1 by Newton-Schulz refinement of the warm start X (E = I - Q X, X <- X + X E, kept exactly symmetric:
 // the antisymmetric part of the iterate is a neutral mode, see dlm_tiled.hip), direct inverse when the start is too far
 // off or 6 iterations do not reach max|E| <= 2e-10.  Returns whether the direct path met a non-positive pivot.
-template <int PT>
-__device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[PT][PT], int n, bool warm, double* img,
+template <int IL, int PT>
+__device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[PT][PT], int n, bool warm, double* img, double* inv,
                                                  int lane, int g, int c) {
   const double tol = 2e-10;
   bool done = false;
@@ -414,11 +425,11 @@ __device__ __forceinline__ bool spd_inverse_warm(const d4 (&Q)[PT][PT], d4 (&X)[
       for (int a = 0; a < PT; ++a)
 #pragma unroll
         for (int b = 0; b < PT; ++b) X[a][b] += D[a][b];
-      mirror<PT, true>(X, img, g, c);
+      mirror<IL, PT, true>(X, img, g, c);
     }
   }
   if (done) return false;
-  return direct_inverse<PT>(Q, X, n, img, lane, g, c);
+  return direct_inverse<PT>(Q, X, n, img, inv, lane, g, c);
 }
 
 __device__ __forceinline__ bool chol_rows(double* L, int n, int ld, int lane) {   // in-place lower Cholesky, row-major
@@ -449,12 +460,13 @@ __device__ __forceinline__ bool chol_rows(double* L, int n, int ld, int lane) { 
 template <int DT, int PT, int K, int KF>
 __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int zero_m0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* img = sm;        double* Fl = sm + IMG;
-  double* mv = Fl + FIMG;  double* av = mv + 48;   double* ev = av + 48;   double* ob = ev + 48;
+  constexpr int IL = il_of(DT, PT), IMG = img_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT), QL = 16 * PT + 1;
+  double* img = sm;        double* Fl = sm + IMG;  double* vec0 = Fl + FIMG + inv_extra(DT, PT);   double* inv = inv_in_img(DT, PT) ? img + inv_of(PT) : Fl + FIMG;
+  double* mv = vec0;  double* av = mv + VL;   double* ev = av + VL;   double* ob = ev + VL;
   const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
   int st = 0;
-  for (int i = lane; i < 10 * 48; i += 64) mv[i] = 0.0;
+  for (int i = lane; i < 10 * VL; i += 64) mv[i] = 0.0;
 
   bool jd[DT], jp[PT];      // this lane's column 16 b + c lies inside d / p
   int cpart[DT];            // byte offset of C[0][16 b + c] inside a record
@@ -576,7 +588,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       gather_vec<DT, K>(mv, tix, tvl, an);                         // a = G m
 #pragma unroll
       for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) av[16 * b + c] = an[b];
-      congruence<DT, K, true, (KF > 0)>(C, Wt, dt, tix, tvl, img, g, c);    // R = G C G^T + W dt (KF: R stays in the image)
+      congruence<IL, DT, K, true, (KF > 0)>(C, Wt, dt, tix, tvl, img, g, c);    // R = G C G^T + W dt (KF: R stays in the image)
     } else {
       if (lane < d) av[lane] = mv[lane];
       if (KF > 0) {
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
         for (int b = aa; b < PT; ++b) Q[aa][b] += Vt[aa][b];
-      mirror<PT, false>(Q, img, g, c);
+      mirror<IL, PT, false>(Q, img, g, c);
       if (fq) {
         const int so = (t + 1) * frec * 8;
 #pragma unroll
@@ -707,7 +719,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
           }
       // a warm start from a different missingness pattern is too far off anyway: the residual test sends it to the
       // direct inverse
-      if (spd_inverse_warm<PT>(Q, Qi, p, warm, img, lane, g, c)) st |= DLM_ST_NOT_PD;
+      if (spd_inverse_warm<IL, PT>(Q, Qi, p, warm, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
       warm = true;
       if (a.loglik) {   // -1/2 (n_obs log 2 pi + log det Qm + e^T Qm^-1 e) (KalmanFilter.scala:138-153); det from a one-wave Cholesky of Qm
 #pragma unroll
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
         ll -= 0.5 * part;
         wave_sync();
       }
-      if (KF == 0) transpose<DT, PT>(S, ST, img, g, c);
+      if (KF == 0) transpose<IL, DT, PT>(S, ST, img, g, c);
       d4 KT[PT][DT];
       mmT<PT, PT, DT, false>(Qi, ST, KT, p);                     // K^T = Qi S^T (Qi symmetric)
       double kcol[DT];
@@ -741,7 +753,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
       for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
         for (int b = aa; b < DT; ++b) C[aa][b] -= U[aa][b];
-      mirror<DT, false>(C, img, g, c);
+      mirror<IL, DT, false>(C, img, g, c);
     }
     wave_sync();
     store_record(rfo, mv, t + 1, g, c);
@@ -774,13 +786,14 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 template <int DT, int PT, int K, int KF>
 __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* img = sm;        double* Fl = sm + IMG;
-  double* mv = Fl + FIMG;  double* qv = mv + 48;   double* rv = qv + 48;   double* ev = rv + 48;   double* ob = ev + 48;
-  double* tv = ob + 48;
+  constexpr int IL = il_of(DT, PT), IMG = img_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT);
+  double* img = sm;        double* Fl = sm + IMG;  double* vec0 = Fl + FIMG + inv_extra(DT, PT);   double* inv = inv_in_img(DT, PT) ? img + inv_of(PT) : Fl + FIMG;
+  double* mv = vec0;  double* qv = mv + VL;   double* rv = qv + VL;   double* ev = rv + VL;   double* ob = ev + VL;
+  double* tv = ob + VL;
   const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
   int st = 0;
-  for (int i = lane; i < 10 * 48; i += 64) mv[i] = 0.0;
+  for (int i = lane; i < 10 * VL; i += 64) mv[i] = 0.0;
 
   bool jd[DT], jp[PT];
   int cpart[DT];
@@ -881,7 +894,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
               const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
               Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
             }
-        if (direct_inverse<PT>(Vm, Vi, p, img, lane, g, c)) st |= DLM_ST_NOT_PD;
+        if (direct_inverse<PT>(Vm, Vi, p, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
 #pragma unroll
         for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
@@ -893,9 +906,9 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
       }
       d4 CFT[PT][DT];
       if (KF > 0) {
-        to_image<DT, DT>(C, img, g, c);
+        to_image<IL, DT, DT>(C, img, g, c);
         wave_sync();
-        ft_times_image<PT, DT, KFA>(CFT, img, fci, fcv, g, c);  // F^T C
+        ft_times_image<IL, PT, DT, KFA>(CFT, img, fci, fcv, g, c);  // F^T C
         wave_sync();
       } else {
         d4 Ft[DT][PT];
@@ -940,9 +953,9 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
         {
           d4 X0[PT][PT];
           if (KF > 0) {
-            to_image<DT, PT>(Kg, img, g, c);
+            to_image<IL, DT, PT>(Kg, img, g, c);
             wave_sync();
-            ft_times_image<PT, PT, KFA>(X0, img, fci, fcv, g, c);   // F^T K
+            ft_times_image<IL, PT, PT, KFA>(X0, img, fci, fcv, g, c);   // F^T K
             wave_sync();
           } else {
             d4 Ft[DT][PT];
@@ -955,7 +968,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
         for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
           for (int b = aa; b < PT; ++b) Qi[aa][b] = Vi[aa][b] - Qi[aa][b];
-        mirror<PT, false>(Qi, img, g, c);                       // Qm^-1
+        mirror<IL, PT, false>(Qi, img, g, c);                       // Qm^-1
         double ucol[PT], ktq[PT];
         matTvec<PT, PT>(Qi, ev, g, ucol);                       // u = Qm^-1 e
         matTvec<DT, PT>(Kg, qv, g, ktq);                        // K^T q
@@ -968,15 +981,15 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
         for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
           for (int b = aa; b < PT; ++b) X[aa][b] += Qi[aa][b];
-        mirror<PT, false>(X, img, g, c);
+        mirror<IL, PT, false>(X, img, g, c);
         if (KF > 0) {
           // T2 = (P K) F^T (all tiles), then P -= T2 + T2^T on the upper tiles
-          to_image<DT, PT>(PK, img, g, c);
+          to_image<IL, DT, PT>(PK, img, g, c);
           wave_sync();                                          // (also publishes tv)
           d4 T2[DT][DT];
-          image_times_ft<DT, DT, KFA>(T2, img, frix, frvl, g);
+          image_times_ft<IL, DT, DT, KFA>(T2, img, frix, frvl, g);
           wave_sync();
-          to_image<DT, DT>(T2, img, g, c);
+          to_image<IL, DT, DT>(T2, img, g, c);
           wave_sync();
 #pragma unroll
           for (int aa = 0; aa < DT; ++aa)
@@ -986,7 +999,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
               for (int r = 0; r < 4; ++r) P[aa][b][r] -= T2[aa][b][r] + img[(16 * b + c) * IL + 16 * aa + 4 * r + g];
           wave_sync();
         } else {
-          transpose<DT, PT>(PK, NPKT, img, g, c);               // (also publishes tv)
+          transpose<IL, DT, PT>(PK, NPKT, img, g, c);               // (also publishes tv)
         }
       }
       double ftv[DT];
@@ -995,12 +1008,12 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 #pragma unroll
         for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) rv[16 * b + c] = qv[16 * b + c] + ftv[b];
         // T1 = F X F^T: (X F^T) by columns, then F (X F^T) read as its own transpose (symmetric), upper tiles
-        to_image<PT, PT>(X, img, g, c);
+        to_image<IL, PT, PT>(X, img, g, c);
         wave_sync();
         d4 FXT[PT][DT];
-        image_times_ft<PT, DT, KFA>(FXT, img, frix, frvl, g);  // X F^T
+        image_times_ft<IL, PT, DT, KFA>(FXT, img, frix, frvl, g);  // X F^T
         wave_sync();
-        to_image<PT, DT>(FXT, img, g, c);
+        to_image<IL, PT, DT>(FXT, img, g, c);
         wave_sync();
 #pragma unroll
         for (int aa = 0; aa < DT; ++aa)
@@ -1032,7 +1045,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
         mmT_acc_up<PT, DT>(NPKT, FT, P, p);                     // - (P K) F^T
       }
       // P's lower tiles are stale now: the congruence below reads the image written from the mirrored matrix
-      mirror<DT, false>(P, img, g, c);
+      mirror<IL, DT, false>(P, img, g, c);
     } else {
       if (lane < d) rv[lane] = qv[lane];
     }
@@ -1042,7 +1055,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
     wave_sync();
 #pragma unroll
     for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) qv[16 * b + c] = qn[b];
-    congruence<DT, K, false>(P, P, 0.0, tix, tvl, img, g, c);   // P = G^T M G
+    congruence<IL, DT, K, false>(P, P, 0.0, tix, tvl, img, g, c);   // P = G^T M G
     }
   }
   bool bad = false;
@@ -1068,14 +1081,15 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 template <int DT, int PT, int K, int KF>
 __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __restrict__ xplus, const double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* img = sm;        double* Fl = sm + IMG;
-  double* qv = Fl + FIMG;  double* rv = qv + 48;   double* ev = rv + 48;   double* ob = ev + 48;
-  double* tv = ob + 48;    double* thc = tv + 48;  double* thn = thc + 48; double* dfv = thn + 48;
+  constexpr int IL = il_of(DT, PT), IMG = img_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT);
+  double* img = sm;        double* Fl = sm + IMG;  double* vec0 = Fl + FIMG + inv_extra(DT, PT);   double* inv = inv_in_img(DT, PT) ? img + inv_of(PT) : Fl + FIMG;
+  double* qv = vec0;  double* rv = qv + VL;   double* ev = rv + VL;   double* ob = ev + VL;
+  double* tv = ob + VL;    double* thc = tv + VL;  double* thn = thc + VL; double* dfv = thn + VL;
   const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0, stats = a.stats != nullptr;
   int st = 0;
-  for (int i = lane; i < 10 * 48; i += 64) qv[i] = 0.0;
+  for (int i = lane; i < 10 * VL; i += 64) qv[i] = 0.0;
 
   bool jd[DT], jp[PT];
   int cpart[DT];
@@ -1250,7 +1264,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
               const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
               Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
             }
-        if (direct_inverse<PT>(Vm, Vi, p, img, lane, g, c)) st |= DLM_ST_NOT_PD;
+        if (direct_inverse<PT>(Vm, Vi, p, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
 #pragma unroll
         for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
@@ -1264,10 +1278,10 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
       {
         d4 CFT[PT][DT];
         if (KF > 0) {
-          to_image<DT, DT>(C, img, g, c);
+          to_image<IL, DT, DT>(C, img, g, c);
           wave_sync();
           request(t - 1, g, c);                                 // C is free
-          ft_times_image<PT, DT, KFA>(CFT, img, fci, fcv, g, c);   // F^T C
+          ft_times_image<IL, PT, DT, KFA>(CFT, img, fci, fcv, g, c);   // F^T C
           wave_sync();
         } else {
           mmT<DT, PT, DT, false>(Ft, C, CFT, d);                // F^T C
@@ -1279,9 +1293,9 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
       {
         d4 X0[PT][PT];
         if (KF > 0) {
-          to_image<DT, PT>(Kg, img, g, c);
+          to_image<IL, DT, PT>(Kg, img, g, c);
           wave_sync();
-          ft_times_image<PT, PT, KFA>(X0, img, fci, fcv, g, c);    // F^T K
+          ft_times_image<IL, PT, PT, KFA>(X0, img, fci, fcv, g, c);    // F^T K
           wave_sync();
         } else {
           mmT<DT, PT, PT, false>(Ft, Kg, X0, d);                // F^T K
@@ -1292,7 +1306,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __r
       for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
         for (int b = aa; b < PT; ++b) Qi[aa][b] = Vi[aa][b] - Qi[aa][b];
-      mirror<PT, false>(Qi, img, g, c);                         // Qm^-1
+      mirror<IL, PT, false>(Qi, img, g, c);                         // Qm^-1
       double ucol[PT], ktq[PT];
       matTvec<PT, PT>(Qi, ev, g, ucol);                         // Qm^-1 e
       matTvec<DT, PT>(Kg, qv, g, ktq);                          // K^T q
@@ -1466,7 +1480,7 @@ bool wave48_filter_supported(const KArgs& a) {
 
 template <int DT, int PT>
 static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, int zero_m0, hipStream_t s) {
-  const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
+  const size_t lds = sizeof(double) * w48::lds_doubles(DT, PT);
   const int kf = (a.spf && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
   if (K <= 2) {
     if (kf == 1) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
@@ -1483,7 +1497,7 @@ bool wave48_smoother_supported(const KArgs& a) { return shape_ok(a) && a.spb && 
 
 template <int DT, int PT>
 static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {
-  const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
+  const size_t lds = sizeof(double) * w48::lds_doubles(DT, PT);
   const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
   if (K <= 2) {
     if (kf == 1) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, innov);
@@ -1526,7 +1540,7 @@ bool wave48_simsmooth_supported(const KArgs& a) {
 
 template <int DT, int PT>
 static hipError_t launch_w48_sims_k(const KArgs& a, int K, const double* xplus, const double* innov, hipStream_t s) {
-  const size_t lds = sizeof(double) * w48::LDS_DOUBLES;
+  const size_t lds = sizeof(double) * w48::lds_doubles(DT, PT);
   const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
   if (K <= 2) {
     if (kf == 1) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
