@@ -88,7 +88,7 @@ hipError_t launch_tiled_filter(const KArgs& a, double* innov, hipStream_t s);
 hipError_t launch_tiled_smoother(const KArgs& a, const double* innov, hipStream_t s);
 // ---- one wavefront per series, register-resident tiles (structured G, 16 <= d <= 48), dlm_wave48.hip ----
 bool wave48_small_shape(const KArgs& a);   // d <= 15 with 2 <= p <= 32: the per-wave kernels with one tile per dimension
-bool wave48_small_ok(const KArgs& a);      // ... and a structured G, no V_t / W_t streams
+bool wave48_small_ok(const KArgs& a);      // ... and a structured G
 bool wave48_filter_supported(const KArgs& a);
 hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_t s);
 bool wave48_smoother_supported(const KArgs& a);

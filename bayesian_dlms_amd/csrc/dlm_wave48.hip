@@ -486,20 +486,38 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
-        const bool in = i < d && jd[b];
-        C[aa][b][r] = in ? C0[i + j * d] : 0.0;
-        Wt[aa][b][r] = (in && aa <= b) ? W[i + j * d] : 0.0;
+        C[aa][b][r] = (i < d && jd[b]) ? C0[i + j * d] : 0.0;
       }
+  auto load_W = [&](const double* Wp, int g, int c) {   // upper tiles of W (the rest is never read)
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+          Wt[aa][b][r] = (i < d && jd[b] && aa <= b) ? Wp[i + j * d] : 0.0;
+        }
+  };
+  auto load_V = [&](const double* Vp, int g, int c) {
+#pragma unroll
+    for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+      for (int b = 0; b < PT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+          Vt[aa][b][r] = (i < p && jp[b] && aa <= b) ? Vp[i + j * p] : 0.0;
+        }
+  };
+  load_W(W, g, c);
+  load_V(V, g, c);
 #pragma unroll
   for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
     for (int b = 0; b < PT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
-        Vt[aa][b][r] = (i < p && jp[b] && aa <= b) ? V[i + j * p] : 0.0;
-        Qi[aa][b][r] = 0.0;
-      }
+      for (int r = 0; r < 4; ++r) Qi[aa][b][r] = 0.0;
   load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
   int tix[DT][K];
   double tvl[DT][K];
@@ -578,6 +596,8 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
     if (a.f_stride) { wave_sync(); load_f_lds<DT, PT>(Fl, a.F + (size_t)t * a.f_stride, d, p, lane); wave_sync(); }
+    if (a.v_tstride) load_V(V + (size_t)t * a.v_tstride, g, c);   // time-varying variances (StudentTGibbs.scala:100-136, DlmFsvSystem.scala:137-208)
+    if (a.w_tstride) load_W(W + (size_t)t * a.w_tstride, g, c);
     double ycur[PT];
 #pragma unroll
     for (int b = 0; b < PT; ++b) { ycur[b] = ynext[b]; ynext[b] = bld(ry, t + 1 < T ? yoff[b] : OOB, (t + 1 < T ? t + 1 : 0) * p * 8); }
@@ -883,7 +903,8 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 
     d4 Kg[DT][PT];
     if (any) {
-      if (__ballot(changed) != 0ull) {   // Vm^-1 for this missingness pattern
+      if (__ballot(changed) != 0ull || a.v_tstride) {   // Vm^-1 for this missingness pattern (and this step's V_t)
+        const double* Vr = V + (size_t)(t - 1) * a.v_tstride;   // V of the observation at record t
         d4 Vm[PT][PT];
 #pragma unroll
         for (int aa = 0; aa < PT; ++aa)
@@ -892,7 +913,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
-              Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
+              Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? Vr[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
             }
         if (direct_inverse<PT>(Vm, Vi, p, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
 #pragma unroll
@@ -1457,8 +1478,7 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
 
 }  // namespace w48
 
-// The per-wave kernels take the structured-G models without per-step variance streams; the rest of the tiled feature
-// set (dense G, V_t / W_t) stays on dlm_tiled.hip.
+// The per-wave kernels take the structured-G models; a dense G stays on dlm_tiled.hip.
 // One wave per series needs more series than the chip has SIMDs to pay off: up to one series per CU (N <= 256) the
 // workgroup-per-series kernels of dlm_tiled.hip finish a step sooner (10.8 against 13 us at d = 40, p = 20).
 // DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip, DLM_FORCE_WAVE48 lifts the batch-size rule (A/B
@@ -1473,9 +1493,9 @@ static bool wave48_wanted(const KArgs& a) {
   return wave48_small_shape(a) || a.N > 256 || getenv("DLM_FORCE_WAVE48");
 }
 static bool shape_ok(const KArgs& a) { return tiled_supported(a) || wave48_small_shape(a); }
-bool wave48_small_ok(const KArgs& a) { return wave48_small_shape(a) && a.spb && !a.v_tstride && !a.w_tstride && !getenv("DLM_NO_WAVE48"); }
+bool wave48_small_ok(const KArgs& a) { return wave48_small_shape(a) && a.spb && !getenv("DLM_NO_WAVE48"); }
 bool wave48_filter_supported(const KArgs& a) {
-  return shape_ok(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a);
+  return shape_ok(a) && a.spb && wave48_wanted(a);
 }
 
 template <int DT, int PT>
@@ -1493,7 +1513,7 @@ static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, int 
   return hipGetLastError();
 }
 
-bool wave48_smoother_supported(const KArgs& a) { return shape_ok(a) && a.spb && !a.v_tstride && !a.w_tstride && wave48_wanted(a); }
+bool wave48_smoother_supported(const KArgs& a) { return shape_ok(a) && a.spb && wave48_wanted(a); }
 
 template <int DT, int PT>
 static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {

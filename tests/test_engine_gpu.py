@@ -1034,7 +1034,7 @@ def test_time_varying_variance_streams(eng, case):
         mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
         mat = materialise(mod, np.cumsum(np.array([1, 2, 1, 1, 3] * 6, dtype=np.float64)))
         p0 = DlmParameters(np.eye(4), np.eye(8) * 0.2, np.zeros(8), np.eye(8))
-        expect = "generic"
+        expect = "wave-mfma"        # structured G, p > 1: the per-wave kernels reload V_t / W_t every step
     elif case == "tiled_d17_p3_dense":
         d, q = 17, 3
         A = rng.standard_normal((d, d)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
@@ -1048,7 +1048,7 @@ def test_time_varying_variance_streams(eng, case):
             mod = mod * Dlm.polynomial(2)
         mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
         p0 = DlmParameters(np.eye(10), np.eye(20) * 0.2, np.zeros(20), np.eye(20))
-        expect = "tiled-mfma"
+        expect = "wave-mfma"
     d, q, T = mat.d, mat.p, mat.T
     # SPD streams: V_t = s_t (B B^T / q + I/2), W_t = diag scale + a dense SPD part
     B = rng.standard_normal((q, q)); Vb = B @ B.T / q + 0.5 * np.eye(q)
