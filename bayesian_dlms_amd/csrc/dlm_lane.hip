@@ -1,13 +1,13 @@
-// One LANE per series for the smallest models: d <= 3, p = 1 (local level, linear growth, quadratic trend, a single
-// harmonic, ...; Dlm.scala:139-243) -- the shapes of the reference's first examples (FirstOrderDlm.scala) run over
-// very many series.
+// One LANE per series for the smallest models: d <= 5, p = 1 (local level, linear growth, quadratic trend, a trend with
+// one or two harmonics, ...; Dlm.scala:139-243) -- the shapes of the reference's first examples (FirstOrderDlm.scala)
+// run over very many series.
 //
-// With d <= 3 a wavefront per series (dlm_sparse16.hip) computes on a 16 x 16 tile that is 1-4 % full and moves
-// 16-96 bytes per step; the recursion of such a model is a few dozen scalar operations.  Here a lane owns a series:
+// With d <= 5 a wavefront per series (dlm_sparse16.hip) computes on a 16 x 16 tile that is 1-10 % full and moves
+// 16-240 bytes per step; the recursion of such a model is a few dozen to a few hundred scalar operations.  Here a lane owns a series:
 // the state (m, C) lives in a handful of registers, the model matrices are wave-uniform (scalar loads), and the only
 // traffic is the record stream -- the pass is bound by how well a lane's private, contiguous stream uses HBM, like
 // the AR(1) kernel (dlm_ar1.hip): observations / records are requested a TILE of steps ahead as 16-byte loads and
-// every step's record leaves as whole 16-byte stores (a record of d + d^2 doubles is 2, 6 or 12 doubles).
+// every step's record leaves as whole 16-byte stores (a record of d + d^2 = d (d + 1) doubles is an even number of doubles).
 //
 // Filter: KalmanFilter.scala:64-118, 262-294 (advance, forecast, masked update; dt == 0: identity advance);
 // log-likelihood :138-153.  Smoother: Smoothing.scala:31-64 in its textbook form
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
 template <int D>
 __global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
   constexpr int REC = D + D * D;
-  constexpr int RT = D == 3 ? 4 : 8;     // records requested per tile (128 / 384 / 384 bytes per lane)
+  constexpr int RT = D <= 2 ? 8 : (D == 3 ? 4 : (D == 4 ? 2 : 1));     // records requested per tile (128 - 384 bytes per lane)
   const int n = blockIdx.x * 64 + threadIdx.x;
   if (n >= a.N) return;
   const int T = a.T;
@@ -375,25 +375,37 @@ __global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
 
 }  // namespace lane
 
-// d <= 3, p = 1, enough series to fill the chip with lanes (below that a wavefront per series finishes sooner);
+constexpr int LANE_MAX_D = 5;   // at d = 6 the backward pass no longer fits the register file (78 spilled registers)
+
+// d <= 5, p = 1, enough series to fill the chip with lanes (below that a wavefront per series finishes sooner);
 // per-step V_t / W_t streams are read per lane, any time grid, time-varying F.
 bool lane_supported(const KArgs& a) {
-  return a.d >= 1 && a.d <= 3 && a.p == 1 && a.N >= 8192 && (((size_t)a.T + 1) * (a.d + a.d * a.d)) % 2 == 0;
+  return a.d >= 1 && a.d <= LANE_MAX_D && a.p == 1 && a.N >= 8192;
 }
 
 hipError_t launch_lane_filter(const KArgs& a, hipStream_t s) {
   const dim3 grid((a.N + 63) / 64), block(64);
-  if (a.d == 1) hipLaunchKernelGGL(lane::k_filter_lane<1>, grid, block, 0, s, a);
-  else if (a.d == 2) hipLaunchKernelGGL(lane::k_filter_lane<2>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(lane::k_filter_lane<3>, grid, block, 0, s, a);
+  switch (a.d) {
+    case 1: hipLaunchKernelGGL(lane::k_filter_lane<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(lane::k_filter_lane<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(lane::k_filter_lane<3>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(lane::k_filter_lane<4>, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(lane::k_filter_lane<5>, grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_lane_smoother(const KArgs& a, hipStream_t s) {
   const dim3 grid((a.N + 63) / 64), block(64);
-  if (a.d == 1) hipLaunchKernelGGL(lane::k_smoother_lane<1>, grid, block, 0, s, a);
-  else if (a.d == 2) hipLaunchKernelGGL(lane::k_smoother_lane<2>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(lane::k_smoother_lane<3>, grid, block, 0, s, a);
+  switch (a.d) {
+    case 1: hipLaunchKernelGGL(lane::k_smoother_lane<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(lane::k_smoother_lane<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(lane::k_smoother_lane<3>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(lane::k_smoother_lane<4>, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(lane::k_smoother_lane<5>, grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -1316,12 +1316,13 @@ def test_per_wave_kernels_edge_shapes_and_status(eng, shape):
     assert eng.filter_smooth(mat, bad, y[:1])["status"][0] & (_lib.ST_NOT_PD | _lib.ST_NONFINITE)
 
 
-@pytest.mark.parametrize("kind", ["local_level", "linear_growth_irregular", "harmonic_plus_level_d3", "regression_d2_timevarying_f"])
+@pytest.mark.parametrize("kind", ["local_level", "linear_growth_irregular", "harmonic_plus_level_d3", "regression_d2_timevarying_f",
+                                  "growth_plus_harmonic_d4", "level_plus_two_harmonics_d5"])
 def test_lane_per_series_small_models(eng, kind):
-    """d <= 3, p = 1 over thousands of series: one lane per series (dlm_lane.hip) -- filter with prior / forecast records,
+    """d <= 5, p = 1 over thousands of series: one lane per series (dlm_lane.hip) -- filter with prior / forecast records,
     log-likelihood, the textbook RTS smoother (fused and standalone) against the oracle and against the wavefront-per-series path."""
     rng = np.random.default_rng({"local_level": 11, "linear_growth_irregular": 12, "harmonic_plus_level_d3": 13,
-                                 "regression_d2_timevarying_f": 14}[kind])
+                                 "regression_d2_timevarying_f": 14, "growth_plus_harmonic_d4": 15, "level_plus_two_harmonics_d5": 16}[kind])
     N = 8192
     if kind == "local_level":
         mod = Dlm.polynomial(1); times = np.arange(1, 38, dtype=np.float64)
@@ -1329,6 +1330,10 @@ def test_lane_per_series_small_models(eng, kind):
         mod = Dlm.polynomial(2); times = np.cumsum(np.array([1, 2, 1, 0, 3, 1, 1] * 5, dtype=np.float64)) + 1.0
     elif kind == "harmonic_plus_level_d3":
         mod = Dlm.polynomial(1) + Dlm.seasonal(12, 1); times = np.arange(1, 30, dtype=np.float64)
+    elif kind == "growth_plus_harmonic_d4":
+        mod = Dlm.polynomial(2) + Dlm.seasonal(12, 1); times = np.cumsum(np.array([1, 1, 2, 1, 0, 1] * 5, dtype=np.float64)) + 1.0
+    elif kind == "level_plus_two_harmonics_d5":
+        mod = Dlm.polynomial(1) + Dlm.seasonal(12, 2); times = np.arange(1, 28, dtype=np.float64)
     else:
         xs = rng.standard_normal(33)
         mod = Dlm(lambda t: np.array([[1.0], [xs[int(t) - 1]]]), lambda dt: np.eye(2)); times = np.arange(1, 34, dtype=np.float64)

@@ -68,7 +68,8 @@ def main():
                           "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
     if "lane" in which:   # the smallest models over very many series: one lane per series (dlm_lane.hip)
         for name, mod, d, N in (("local level (polynomial(1)), d=1", Dlm.polynomial(1), 1, 500000),
-                                ("linear growth (polynomial(2)), d=2", Dlm.polynomial(2), 2, 200000)):
+                                ("linear growth (polynomial(2)), d=2", Dlm.polynomial(2), 2, 200000),
+                                ("level + two harmonics (polynomial(1) + seasonal(12, 2)), d=5", Dlm.polynomial(1) + Dlm.seasonal(12, 2), 5, 50000)):
             T = 1000
             mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
             p = DlmParameters([[2.0]], np.eye(d) * 0.5, np.zeros(d), np.eye(d) * 10.0)
