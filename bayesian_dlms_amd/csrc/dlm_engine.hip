@@ -597,6 +597,12 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if ((rc = st.commit())) return rc;
   if (forward) {
     if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
+    if (simflag && use_lane(k) && !k.v_tstride) {
+      if ((rc = ensure_xplus(e, k))) return rc;
+      e->variant = "lane-simsmooth";
+      HIP_TRY(e, dlm::launch_lane_simsmooth(k, e->xplus, e->stream));
+      return st.finish(opts->flags & DLM_OPT_ASYNC);
+    }
     if (simflag && e->sparse_k) {
       // Durbin-Koopman simulation smoother on the structured fast path
       if ((rc = ensure_side(e, k)) || (rc = ensure_xplus(e, k))) return rc;

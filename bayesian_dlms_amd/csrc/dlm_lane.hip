@@ -373,6 +373,284 @@ __global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
   if (a.status && st) atomicOr(&a.status[n], st);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// FFBS by the Durbin-Koopman simulation smoother, one lane per series (DLM_OPT_FFBS_SIMSMOOTH; the d <= 5 counterpart
+// of k_filter_sp16<SIM> / k_simsmooth_sp16): the forward kernel simulates (x+, y+) from the model, filters
+// y* = y - y+ from a zero prior mean and stores the filtered records and x+; the backward kernel runs the MEAN
+// recursion of the smoother on y*,  s*_t = m*_t + J_t (s*_{t+1} - a*_{t+1}),  theta_t = s*_t + x+_t, and accumulates
+// the Gibbs statistics (Gibbs.scala:23-78, GibbsWishart.scala:16-35).  Normals: (seed, series, record t, i), i < d
+// state noise (record 0: the initial state), i = d observation noise, or a.z [N][T+1][d+1].
+// ---------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ bool chol_small(const double (&A)[D][D], double (&L)[D][D]) {   // lower factor, true: not positive definite
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double sd = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sd = fma(-L[j][k], L[j][k], sd);
+    if (!(sd > 0.0)) { bad = true; sd = 0.0; }
+    const double ljj = sqrt(sd), inv = ljj > 0.0 ? 1.0 / ljj : 0.0;
+    L[j][j] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v = fma(-L[i][k], L[j][k], v);
+      L[i][j] = v * inv;
+    }
+#pragma unroll
+    for (int i = 0; i < j; ++i) L[i][j] = 0.0;
+  }
+  return bad;
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_simfilter_lane(KArgs a, double* __restrict__ xplus) {
+  constexpr int REC = D + D * D;
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= a.N) return;
+  const int T = a.T;
+  const double V = a.V[(size_t)n * a.v_stride], sqV = sqrt(V);
+  double W[D][D], Lw[D][D], m[D], C[D][D], x[D];
+  load_w<D>(a.W + (size_t)n * a.w_stride, W);
+  int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+  if (chol_small<D>(W, Lw)) st |= DLM_ST_NOT_PD;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * (D + 1) : nullptr;
+  {
+    const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+    const double* C0 = a.C0 + (size_t)n * a.c0_stride;
+    double L0[D][D], z0[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      z0[i] = zin ? zin[i] : philox_normal(a.seed, series, 0u, (unsigned)i);
+#pragma unroll
+      for (int j = 0; j < D; ++j) C[i][j] = C0[i + j * D];
+    }
+    if (chol_small<D>(C, L0)) st |= DLM_ST_NOT_PD;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double v = m0[i];
+#pragma unroll
+      for (int k = 0; k <= i; ++k) v = fma(L0[i][k], z0[k], v);
+      x[i] = v;
+      m[i] = 0.0;                 // y* is filtered from a zero prior mean
+    }
+  }
+  const double* y = a.y + (size_t)n * T;
+  double* out = a.filt + (size_t)n * (T + 1) * REC;
+  double* xo = xplus + (size_t)n * (T + 1) * D;
+  auto store = [&](int t) {
+    double r[REC];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = m[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int i = 0; i < D; ++i) r[D + i + j * D] = C[i][j];
+    dbl2* o = (dbl2*)(out + (size_t)t * REC);
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) o[q] = dbl2{r[2 * q], r[2 * q + 1]};
+#pragma unroll
+    for (int i = 0; i < D; ++i) xo[(size_t)t * D + i] = x[i];
+  };
+  store(0);
+  for (int t = 0; t < T; ++t) {
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
+    const double* Ft = a.F + (size_t)t * a.f_stride;
+    double z[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; ++i) z[i] = zin ? zin[(size_t)(t + 1) * (D + 1) + i] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)i);
+    double av[D], R[D][D];
+    advance<D>(Gt, dt, W, m, C, av, R);
+    if (dt != 0.0) {              // x+ = G x+ + sqrt(dt) chol(W) z ; a zero increment leaves x+ as it is
+      const double sdt = sqrt(dt);
+      double xn[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double v = 0.0, w_ = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) v = fma(Gt[i + k * D], x[k], v);
+#pragma unroll
+        for (int k = 0; k <= i; ++k) w_ = fma(Lw[i][k], z[k], w_);
+        xn[i] = fma(w_, sdt, v);
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) x[i] = xn[i];
+    }
+    double F[D], RF[D], f = 0.0, Q = V, yp = sqV * z[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { F[i] = Ft[i]; f = fma(F[i], av[i], f); yp = fma(F[i], x[i], yp); }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s_ = fma(R[i][k], F[k], s_);
+      RF[i] = s_;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) Q = fma(F[i], RF[i], Q);
+    const double ys = y[t] - yp;              // NaN (missing) stays NaN
+    if (ys == ys) {
+      const double e = ys - f, iq = 1.0 / Q;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        m[i] = fma(RF[i], e * iq, av[i]);
+#pragma unroll
+        for (int k = 0; k <= i; ++k) { const double c_ = fma(-RF[i] * iq, RF[k], R[i][k]); C[i][k] = c_; C[k][i] = c_; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        m[i] = av[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) C[i][k] = R[i][k];
+      }
+    }
+    store(t + 1);
+  }
+  if (a.status && st) atomicOr(&a.status[n], st);
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __restrict__ xplus) {
+  constexpr int REC = D + D * D;
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= a.N) return;
+  const int T = a.T;
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
+  double W[D][D];
+  load_w<D>(a.W + (size_t)n * a.w_stride, W);
+  const dbl2* in = (const dbl2*)(a.filt_in + (size_t)n * (T + 1) * REC);
+  const double* xp = xplus + (size_t)n * (T + 1) * D;
+  const double* y = a.y ? a.y + (size_t)n * T : nullptr;
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * D : nullptr;
+  int st = 0;
+  double s[D], thn[D], ssd[D], OUT[D][D], ssy = 0.0, nob = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    ssd[i] = 0.0; thn[i] = 0.0; s[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) OUT[i][k] = 0.0;
+  }
+  for (int t = T; t >= 0; --t) {
+    double m[D], C[D][D];
+    {
+      double v[REC];
+#pragma unroll
+      for (int q = 0; q < REC / 2; ++q) { const dbl2 r = in[(size_t)t * (REC / 2) + q]; v[2 * q] = r.x; v[2 * q + 1] = r.y; }
+#pragma unroll
+      for (int i = 0; i < D; ++i) m[i] = v[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int i = 0; i < D; ++i) C[i][j] = v[D + i + j * D];
+    }
+    const double dt = (t < T && a.dt) ? a.dt[t] : 1.0;                                     // the step t -> t + 1
+    const double* Gt = a.G + (size_t)((t < T && a.g_index) ? a.g_index[t] : 0) * (D * D);
+    if (t == T) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) s[i] = m[i];
+    } else if (dt != 0.0) {       // a zero increment was an identity advance for x+ and for the filter: s*_t = s*_{t+1}
+      double a1[D], R1[D][D], L[D][D];
+      advance<D>(Gt, dt, W, m, C, a1, R1);
+      if (chol_small<D>(R1, L)) st |= DLM_ST_NOT_PD;
+      // s = m + C G^T R+^-1 (s+ - a+): solve R+ u = s+ - a+, then s = m + C G^T u
+      double u[D];
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        double v = s[r] - a1[r];
+#pragma unroll
+        for (int k = 0; k < r; ++k) v = fma(-L[r][k], u[k], v);
+        u[r] = v / L[r][r];
+      }
+#pragma unroll
+      for (int r = D - 1; r >= 0; --r) {
+        double v = u[r];
+#pragma unroll
+        for (int k = r + 1; k < D; ++k) v = fma(-L[k][r], u[k], v);
+        u[r] = v / L[r][r];
+      }
+      double gu[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {     // (G^T u)[k]
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) v = fma(Gt[j + k * D], u[j], v);
+        gu[k] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double v = m[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) v = fma(C[i][k], gu[k], v);
+        s[i] = v;
+      }
+    }
+    double th[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { th[i] = s[i] + xp[(size_t)t * D + i]; if (thout) thout[(size_t)t * D + i] = th[i]; }
+    if (a.stats) {
+      if (t < T) {   // system residual (theta_{t+1} - G_{t+1} theta_t) / sqrt(dt)
+        const double dts = (dt == 0.0) ? 1.0 : dt, isd = 1.0 / sqrt(dts);
+        double df[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          double g_ = th[i];
+          if (dt != 0.0) {
+            g_ = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) g_ = fma(Gt[i + k * D], th[k], g_);
+          }
+          const double r_ = thn[i] - g_;
+          ssd[i] = fma(r_, r_ / dts, ssd[i]);
+          df[i] = r_ * isd;
+        }
+        if (outer) {
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int k = 0; k < D; ++k) OUT[i][k] = fma(df[i], df[k], OUT[i][k]);
+        }
+      }
+      if (t > 0 && y) {   // observation residual of theta_t against the original y_t
+        const double yv = y[t - 1];
+        if (yv == yv) {
+          const double* Ft = a.F + (size_t)(t - 1) * a.f_stride;
+          double f = 0.0;
+#pragma unroll
+          for (int i = 0; i < D; ++i) f = fma(Ft[i], th[i], f);
+          ssy = fma(yv - f, yv - f, ssy); nob += 1.0;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) thn[i] = th[i];
+  }
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < D; ++i) bad |= !isfinite(thn[i]);
+  if (bad) st |= DLM_ST_NONFINITE;
+  if (a.stats) {
+    const int L_ = stats_len(D, 1, a.flags);
+    double* so = a.stats + (size_t)n * L_;
+    so[0] = ssy; so[1] = nob; so[L_ - 1] = (double)T;
+    if (outer) {
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int k = 0; k < D; ++k) so[2 + i + k * D] = OUT[i][k];
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i) so[2 + i] = ssd[i];
+    }
+  }
+  if (a.status && st) atomicOr(&a.status[n], st);
+}
+
 }  // namespace lane
 
 constexpr int LANE_MAX_D = 5;   // at d = 6 the backward pass no longer fits the register file (78 spilled registers)
@@ -404,6 +682,23 @@ hipError_t launch_lane_smoother(const KArgs& a, hipStream_t s) {
     case 3: hipLaunchKernelGGL(lane::k_smoother_lane<3>, grid, block, 0, s, a); break;
     case 4: hipLaunchKernelGGL(lane::k_smoother_lane<4>, grid, block, 0, s, a); break;
     case 5: hipLaunchKernelGGL(lane::k_smoother_lane<5>, grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+
+// forward SIM pass (filt records + x+) followed by the mean-only backward pass; xplus [N][T+1][d] is engine workspace
+hipError_t launch_lane_simsmooth(const KArgs& a, double* xplus, hipStream_t s) {
+  const dim3 grid((a.N + 63) / 64), block(64);
+  KArgs b = a;
+  b.filt_in = a.filt;
+  switch (a.d) {
+    case 1: hipLaunchKernelGGL(lane::k_simfilter_lane<1>, grid, block, 0, s, a, xplus); hipLaunchKernelGGL(lane::k_simsmooth_lane<1>, grid, block, 0, s, b, (const double*)xplus); break;
+    case 2: hipLaunchKernelGGL(lane::k_simfilter_lane<2>, grid, block, 0, s, a, xplus); hipLaunchKernelGGL(lane::k_simsmooth_lane<2>, grid, block, 0, s, b, (const double*)xplus); break;
+    case 3: hipLaunchKernelGGL(lane::k_simfilter_lane<3>, grid, block, 0, s, a, xplus); hipLaunchKernelGGL(lane::k_simsmooth_lane<3>, grid, block, 0, s, b, (const double*)xplus); break;
+    case 4: hipLaunchKernelGGL(lane::k_simfilter_lane<4>, grid, block, 0, s, a, xplus); hipLaunchKernelGGL(lane::k_simsmooth_lane<4>, grid, block, 0, s, b, (const double*)xplus); break;
+    case 5: hipLaunchKernelGGL(lane::k_simfilter_lane<5>, grid, block, 0, s, a, xplus); hipLaunchKernelGGL(lane::k_simsmooth_lane<5>, grid, block, 0, s, b, (const double*)xplus); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -1366,14 +1366,32 @@ def test_lane_per_series_small_models(eng, kind):
         np.testing.assert_allclose(pf["fq"][n][1:, 0], np.asarray(f["f"])[1:].reshape(T), rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(pf["fq"][n][1:, 1], np.asarray(f["Q"])[1:].reshape(T), rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(ll["loglik"][n], oracle.loglik(omodel(mat), f, y[n]), rtol=1e-10, atol=1e-9)
+    # simulation-smoother FFBS + statistics on the lane kernels: injected normals against the reference construction
+    # (regular grids) and, Philox stream, against the wavefront-per-series implementation of the same draw
+    zs = rng.standard_normal((N, T + 1, d + 1))
+    dz = eng.ffbs(mat, p, y, z=zs, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_STATS_OUTER)
+    assert eng.last_variant == "lane-simsmooth" and np.all(dz["status"] == 0)
+    if mat.dt is None and mat.f_stride == 0:
+        for n in (0, 5, 64, N - 1):
+            refd = dk_reference_draw_mv(mat, p, y[n], zs[n])
+            np.testing.assert_allclose(dz["theta"][n], refd, rtol=1e-8, atol=1e-8)
+            stt = oracle.gibbs_stats(omodel(mat), y[n], refd, want_outer=True)
+            np.testing.assert_allclose(dz["stats"][n, 0], stt["ssy"][0], rtol=1e-8)
+            np.testing.assert_array_equal(dz["stats"][n, 1], stt["n"][0])
+            np.testing.assert_allclose(dz["stats"][n, 2:2 + d * d], stt["outer"], rtol=1e-7, atol=1e-8)
+    dp = eng.ffbs(mat, p, y, seed=9, series_offset=3, flags=_lib.OPT_FFBS_SIMSMOOTH)
     os.environ["DLM_NO_LANE"] = "1"
     try:
         ref = eng.filter_smooth(mat, p, y)
         assert eng.last_variant != "lane"
+        rp = eng.ffbs(mat, p, y, seed=9, series_offset=3, flags=_lib.OPT_FFBS_SIMSMOOTH)
+        assert eng.last_variant == "sparse16-simsmooth"
     finally:
         del os.environ["DLM_NO_LANE"]
     np.testing.assert_allclose(out["filt"], ref["filt"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(out["smooth"], ref["smooth"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(dp["theta"], rp["theta"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(dp["stats"], rp["stats"], rtol=1e-7, atol=1e-8)
 
 
 def test_simulation_smoother_with_scalar_variance_stream(eng):
