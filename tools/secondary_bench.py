@@ -83,6 +83,16 @@ def main():
             print(json.dumps({"config": f"filter+smooth, {name}, N={N}, T={T}", "variant": eng.last_variant, "ms": dt * 1e3,
                               "forward_ms": fwd, "backward_ms": bwd, "series_steps_per_s": N * T / dt,
                               "GBps_algorithmic": N * T * (8 + 3 * rec) / dt / 1e9}))
+    if "laneffbs" in which:   # FFBS + sufficient statistics for the smallest models (the Gibbs step of a local-level / linear-growth DLM)
+        from bayesian_dlms_amd import _lib
+        for name, mod, d, N in (("local level, d=1", Dlm.polynomial(1), 1, 200000), ("linear growth, d=2", Dlm.polynomial(2), 2, 100000)):
+            T = 1000
+            mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+            p = DlmParameters([[2.0]], np.eye(d) * 0.5, np.zeros(d), np.eye(d) * 10.0)
+            y = torch.randn((N, T, 1), device=dev, dtype=torch.float64).cumsum(dim=1)
+            dt = timeit(lambda: eng.ffbs(mat, p, y, seed=1, flags=_lib.OPT_FFBS_SIMSMOOTH), reps=2)
+            print(json.dumps({"config": f"FFBS (simulation smoother) + statistics, {name}, N={N}, T={T}", "variant": eng.last_variant,
+                              "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
     if "mv8" in which:   # a small multivariate model (d = 8, p = 4): per-wave kernels with one tile per dimension vs the generic path
         from bayesian_dlms_amd import _lib
         mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
