@@ -457,7 +457,25 @@ __global__ __launch_bounds__(64) void k_simfilter_lane(KArgs a, double* __restri
     for (int i = 0; i < D; ++i) xo[(size_t)t * D + i] = x[i];
   };
   store(0);
-  for (int t = 0; t < T; ++t) {
+  const int Tl = T - 1;
+  double yb[YT];
+  auto request = [&](int t0) {
+#pragma unroll
+    for (int j = 0; j < YT; ++j) { const int t = t0 + j < Tl ? t0 + j : Tl; yb[j] = y[t]; }
+  };
+  if (T > 0) request(0);
+  for (int t0 = 0; t0 < T; t0 += YT) {
+  double yc[YT];
+#pragma unroll
+  for (int j = 0; j < YT; ++j) yc[j] = yb[j];
+  if (t0 + YT < T) request(t0 + YT);
+#pragma unroll 1
+  for (int j = 0; j < YT; ++j) {
+    const int t = t0 + j;
+    if (t >= T) break;
+    double ycur = yc[0];
+#pragma unroll
+    for (int q = 1; q < YT; ++q) ycur = (j == q) ? yc[q] : ycur;
     const double dt = a.dt ? a.dt[t] : 1.0;
     const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
     const double* Ft = a.F + (size_t)t * a.f_stride;
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(64) void k_simfilter_lane(KArgs a, double* __restri
     }
 #pragma unroll
     for (int i = 0; i < D; ++i) Q = fma(F[i], RF[i], Q);
-    const double ys = y[t] - yp;              // NaN (missing) stays NaN
+    const double ys = ycur - yp;              // NaN (missing) stays NaN
     if (ys == ys) {
       const double e = ys - f, iq = 1.0 / Q;
 #pragma unroll
@@ -511,6 +529,7 @@ __global__ __launch_bounds__(64) void k_simfilter_lane(KArgs a, double* __restri
       }
     }
     store(t + 1);
+  }
   }
   if (a.status && st) atomicOr(&a.status[n], st);
 }
@@ -536,19 +555,32 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
 #pragma unroll
     for (int k = 0; k < D; ++k) OUT[i][k] = 0.0;
   }
+  // the record, x+ and the observation of the NEXT step (t - 1) are requested before step t is computed
+  dbl2 nrec[REC / 2];
+  double nx[D], ny = 0.0;
+  auto request = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) nrec[q] = in[(size_t)t * (REC / 2) + q];
+#pragma unroll
+    for (int i = 0; i < D; ++i) nx[i] = xp[(size_t)t * D + i];
+    ny = (y && t > 0) ? y[t - 1] : 0.0;
+  };
+  request(T);
   for (int t = T; t >= 0; --t) {
-    double m[D], C[D][D];
+    double m[D], C[D][D], xcur[D];
+    const double ycur = ny;
     {
       double v[REC];
 #pragma unroll
-      for (int q = 0; q < REC / 2; ++q) { const dbl2 r = in[(size_t)t * (REC / 2) + q]; v[2 * q] = r.x; v[2 * q + 1] = r.y; }
+      for (int q = 0; q < REC / 2; ++q) { v[2 * q] = nrec[q].x; v[2 * q + 1] = nrec[q].y; }
 #pragma unroll
-      for (int i = 0; i < D; ++i) m[i] = v[i];
+      for (int i = 0; i < D; ++i) { m[i] = v[i]; xcur[i] = nx[i]; }
 #pragma unroll
       for (int j = 0; j < D; ++j)
 #pragma unroll
         for (int i = 0; i < D; ++i) C[i][j] = v[D + i + j * D];
     }
+    request(t > 0 ? t - 1 : 0);
     const double dt = (t < T && a.dt) ? a.dt[t] : 1.0;                                     // the step t -> t + 1
     const double* Gt = a.G + (size_t)((t < T && a.g_index) ? a.g_index[t] : 0) * (D * D);
     if (t == T) {
@@ -592,7 +624,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
     }
     double th[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { th[i] = s[i] + xp[(size_t)t * D + i]; if (thout) thout[(size_t)t * D + i] = th[i]; }
+    for (int i = 0; i < D; ++i) { th[i] = s[i] + xcur[i]; if (thout) thout[(size_t)t * D + i] = th[i]; }
     if (a.stats) {
       if (t < T) {   // system residual (theta_{t+1} - G_{t+1} theta_t) / sqrt(dt)
         const double dts = (dt == 0.0) ? 1.0 : dt, isd = 1.0 / sqrt(dts);
@@ -617,7 +649,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
         }
       }
       if (t > 0 && y) {   // observation residual of theta_t against the original y_t
-        const double yv = y[t - 1];
+        const double yv = ycur;
         if (yv == yv) {
           const double* Ft = a.F + (size_t)(t - 1) * a.f_stride;
           double f = 0.0;
