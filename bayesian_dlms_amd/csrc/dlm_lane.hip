@@ -13,7 +13,7 @@
 // log-likelihood :138-153.  Smoother: Smoothing.scala:31-64 in its textbook form
 //   J = C G^T R^-1,  s = m + J (s+ - a+),  S = C - J (R+ - S+) J^T
 // with (a+, R+) recomputed from (m, C) exactly as the filter formed them -- no side buffer, so the same kernel serves
-// the fused call and dlm_smooth_batch.
+// the fused call and dlm_smooth_batch.  FFBS: the simulation smoother (k_simfilter_lane / k_simsmooth_lane, further down).
 #include "dlm_internal.h"
 #include "../../include/dlm_engine.h"
 

@@ -1,5 +1,5 @@
-// One WAVEFRONT per series for 16 <= d <= 48, p <= 32 with a structured G: the whole step lives in the registers of one
-// wave, in the fp64 MFMA accumulator layout, tile by tile.
+// One WAVEFRONT per series for multivariate models (16 <= d <= 48, or d <= 15 with p >= 2) with a structured G: the whole
+// step lives in the registers of one wave, in the fp64 MFMA accumulator layout, tile by tile.
 //
 // dlm_tiled.hip gives a series a workgroup of 8 waves that cooperate through LDS operands: 10-14 barrier-separated
 // phases per step, each as long as its busiest SIMD (19 % of the fp64 MFMA peak at d = 40, p = 20,
@@ -13,7 +13,12 @@
 // the upper tiles of a symmetric result, S = R F -> S^T) and the gather congruence G C G^T go through one wave-private
 // LDS image with an odd leading dimension.
 //
-// Recursion (KalmanFilter.scala:64-118, 262-294), per step, with Fm = F with the columns of missing observations zeroed:
+// Kernels: k_filter_w48 (below), k_smoother_w48 (information-form backward pass, fused call), k_sim_prologue_w48 +
+// k_simsmooth_w48 (Durbin-Koopman simulation-smoother FFBS with the Gibbs statistics).  Shapes: 16 <= d <= 48, p <= 32,
+// and d <= 15 with 2 <= p <= 32 (one tile per dimension); every LDS region is sized by the instantiation's tile counts.
+// With a structured F (SparseF) the products with F are gathers through the image as well.
+//
+// Forward recursion (KalmanFilter.scala:64-118, 262-294), per step, with Fm = F with the columns of missing observations zeroed:
 //   a = G m, R = G C G^T + W dt        two gather passes with the row tables of G (sparse48_analyse)
 //   S = R Fm, f = F^T a, Q = Fm^T S + Vm   (Vm: V with unit rows/columns for the missing observations)
 //   Qi = Qm^-1                          Newton-Schulz from the previous step's inverse, direct Cholesky otherwise
