@@ -463,7 +463,7 @@ __device__ __forceinline__ bool chol_rows(double* L, int n, int ld, int lane) { 
 // KF > 0: F is structured (at most KF nonzeros per column, SparseF): S = R F, f = F^T a and Q = F^T S are gathers through
 // the image instead of MFMA products (90 of the 190 MFMAs of a step at d = 40, p = 20).
 template <int DT, int PT, int K, int KF>
-__global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int zero_m0) {
+__global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k_filter_w48(KArgs a, double* innov, int zero_m0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int IL = il_of(DT, PT), IMG = img_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT), QL = 16 * PT + 1;
   double* img = sm;        double* Fl = sm + IMG;  double* vec0 = Fl + FIMG + inv_extra(DT, PT);   double* inv = inv_in_img(DT, PT) ? img + inv_of(PT) : Fl + FIMG;
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(64) void k_filter_w48(KArgs a, double* innov, int z
 // KF > 0: structured F -- F^T C, F^T K, X F^T and the three F-products of the update of P are gathers (220 of the 505 MFMAs
 // of a step at d = 40, p = 20).
 template <int DT, int PT, int K, int KF>
-__global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __restrict__ innov) {
+__global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k_smoother_w48(KArgs a, const double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int IL = il_of(DT, PT), IMG = img_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT);
   double* img = sm;        double* Fl = sm + IMG;  double* vec0 = Fl + FIMG + inv_extra(DT, PT);   double* inv = inv_in_img(DT, PT) ? img + inv_of(PT) : Fl + FIMG;
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(64) void k_smoother_w48(KArgs a, const double* __re
 // innov: the innovations of the forward pass on y* (NaN = missing), record t at innov[(t-1) p ..].
 // ---------------------------------------------------------------------------------------
 template <int DT, int PT, int K, int KF>
-__global__ __launch_bounds__(64) void k_simsmooth_w48(KArgs a, const double* __restrict__ xplus, const double* __restrict__ innov) {
+__global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k_simsmooth_w48(KArgs a, const double* __restrict__ xplus, const double* __restrict__ innov) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int IL = il_of(DT, PT), IMG = img_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT);
   double* img = sm;        double* Fl = sm + IMG;  double* vec0 = Fl + FIMG + inv_extra(DT, PT);   double* inv = inv_in_img(DT, PT) ? img + inv_of(PT) : Fl + FIMG;

@@ -93,6 +93,17 @@ def main():
             dt = timeit(lambda: eng.ffbs(mat, p, y, seed=1, flags=_lib.OPT_FFBS_SIMSMOOTH), reps=2)
             print(json.dumps({"config": f"FFBS (simulation smoother) + statistics, {name}, N={N}, T={T}", "variant": eng.last_variant,
                               "ms": dt * 1e3, "series_steps_per_s": N * T / dt}))
+    if "mv32" in which:   # d = 32, p = 16 (16 x linear growth): the two-tile instantiations of the per-wave kernels
+        mod = Dlm.polynomial(2)
+        for _ in range(15): mod = mod * Dlm.polynomial(2)
+        N, T = 4000, 1000
+        mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+        p = DlmParameters(np.eye(16), np.eye(32) * 0.2, np.zeros(32), np.eye(32))
+        y = torch.randn((N, T, 16), device=dev, dtype=torch.float64).cumsum(dim=1)
+        dt = timeit(lambda: eng.filter_smooth(mat, p, y), reps=2)
+        fwd, bwd = eng.last_timing()
+        print(json.dumps({"config": f"filter+smooth, d=32, p=16 (16 x linear growth), N={N}, T={T}", "variant": eng.last_variant,
+                          "ms": dt * 1e3, "forward_ms": fwd, "backward_ms": bwd, "series_steps_per_s": N * T / dt}))
     if "mv8" in which:   # a small multivariate model (d = 8, p = 4): per-wave kernels with one tile per dimension vs the generic path
         from bayesian_dlms_amd import _lib
         mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
