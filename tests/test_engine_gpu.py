@@ -667,7 +667,8 @@ def test_gibbs_per_series_engine_matches_oracle_ffbs(eng):
     mat = materialise(mod, times)
     p0 = DlmParameters([[2.0]], np.diag([0.5, 0.2]), [0.0, 0.0], np.eye(2) * 10)
     y = simulate(mat, p0, 5, seed=3, missing=0.1)
-    a = list(GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p0, times, y, eng, n_iter=3, seed=9))
+    a = list(GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p0, times, y, eng, n_iter=3, seed=9,
+                                  simulation_smoother=False))   # the literal backward sampler, draw for draw
     b = list(GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p0, times, y, None, n_iter=3, seed=9,
                                   ffbs=oracle_ffbs))
     for sa, sb in zip(a, b):
