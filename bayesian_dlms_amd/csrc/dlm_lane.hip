@@ -133,12 +133,17 @@ __global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
       for (int j = 0; j < YT; ++j) { const int t = t0 + j < Tl ? t0 + j : Tl; yb[j] = y[t]; }
     }
   };
+  // D <= 2: a record is 16 / 48 bytes; eight of them leave together as whole 128-byte lines (a line written piecemeal
+  // over eight steps is evicted from L2 in between, and HBM then sees 16-byte masked writes)
+  constexpr int OT = D <= 2 ? 8 : 1;
+  dbl2 ob[OT][REC / 2];
   if (T > 0) request(0);
   for (int t0 = 0; t0 < T; t0 += YT) {
     double yc[YT];
 #pragma unroll
     for (int j = 0; j < YT; ++j) yc[j] = yb[j];
     if (t0 + YT < T) request(t0 + YT);
+    const bool whole = t0 + YT <= T;
 #pragma unroll
     for (int j = 0; j < YT; ++j) {
       const int t = t0 + j;
@@ -183,7 +188,27 @@ __global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
             for (int k = 0; k < D; ++k) C[i][k] = R[i][k];
           }
         }
-        if (out) store(out, t + 1, m, C);
+        if (out) {
+          if (OT == 1 || !whole) store(out, t + 1, m, C);
+          else {
+            double r[REC];
+#pragma unroll
+            for (int i = 0; i < D; ++i) r[i] = m[i];
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj)
+#pragma unroll
+              for (int i = 0; i < D; ++i) r[D + i + jj * D] = C[i][jj];
+#pragma unroll
+            for (int q = 0; q < REC / 2; ++q) ob[j % OT][q] = dbl2{r[2 * q], r[2 * q + 1]};
+            if (j % OT == OT - 1) {
+              dbl2* o = (dbl2*)(out + (size_t)(t + 2 - OT) * REC);   // records t + 2 - OT .. t + 1
+#pragma unroll
+              for (int k = 0; k < OT; ++k)
+#pragma unroll
+                for (int q = 0; q < REC / 2; ++q) o[k * (REC / 2) + q] = ob[k][q];
+            }
+          }
+        }
       }
     }
   }
@@ -358,7 +383,25 @@ __global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
 #pragma unroll
           for (int k = 0; k < D; ++k) S[i][k] = Sn[i][k];
         }
-        store(t, s, S);
+        if (D > 2 || t0 + RT > T) store(t, s, S);
+        else {
+          double r[REC];
+#pragma unroll
+          for (int i = 0; i < D; ++i) r[i] = s[i];
+#pragma unroll
+          for (int jj = 0; jj < D; ++jj)
+#pragma unroll
+            for (int i = 0; i < D; ++i) r[D + i + jj * D] = S[i][jj];
+#pragma unroll
+          for (int q = 0; q < REC / 2; ++q) cur[j][q] = dbl2{r[2 * q], r[2 * q + 1]};   // cur[j] has been consumed: reuse it as the output tile
+          if (j == 0) {
+            dbl2* o = (dbl2*)(outp + (size_t)t0 * REC);
+#pragma unroll
+            for (int k = 0; k < RT; ++k)
+#pragma unroll
+              for (int q = 0; q < REC / 2; ++q) o[k * (REC / 2) + q] = cur[k][q];
+          }
+        }
       }
     }
   }
