@@ -143,4 +143,16 @@ __device__ __forceinline__ double philox_normal(unsigned long long seed, unsigne
   return (i & 1) ? r * sin(ang) : r * cos(ang);
 }
 
+// components 2 q and 2 q + 1 of record t share one Philox block and one Box-Muller pair: both at the cost of one
+__device__ __forceinline__ void philox_normal2(unsigned long long seed, unsigned long long series, unsigned t, unsigned q,
+                                               double& z_even, double& z_odd) {
+  unsigned c[4] = {(unsigned)series, (unsigned)(series >> 32), t, q};
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  double u1 = ((double)c[0] * 4294967296.0 + (double)c[1] + 1.0) * (1.0 / 18446744073709551616.0);
+  double u2 = ((double)c[2] * 4294967296.0 + (double)c[3]) * (1.0 / 18446744073709551616.0);
+  double r = sqrt(-2.0 * log(u1));
+  double ang = 6.283185307179586476925286766559 * u2;
+  z_even = r * cos(ang); z_odd = r * sin(ang);
+}
+
 }  // namespace dlm

@@ -522,9 +522,14 @@ __global__ __launch_bounds__(64) void k_simfilter_lane(KArgs a, double* __restri
     const double dt = a.dt ? a.dt[t] : 1.0;
     const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
     const double* Ft = a.F + (size_t)t * a.f_stride;
-    double z[D + 1];
+    double z[D + 2];   // D + 1 normals, drawn as Box-Muller pairs
+    if (zin) {
 #pragma unroll
-    for (int i = 0; i <= D; ++i) z[i] = zin ? zin[(size_t)(t + 1) * (D + 1) + i] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)i);
+      for (int i = 0; i <= D; ++i) z[i] = zin[(size_t)(t + 1) * (D + 1) + i];
+    } else {
+#pragma unroll
+      for (int q = 0; q < (D + 2) / 2; ++q) philox_normal2(a.seed, series, (unsigned)(t + 1), (unsigned)q, z[2 * q], z[2 * q + 1]);
+    }
     double av[D], R[D][D];
     advance<D>(Gt, dt, W, m, C, av, R);
     if (dt != 0.0) {              // x+ = G x+ + sqrt(dt) chol(W) z ; a zero increment leaves x+ as it is
@@ -598,32 +603,53 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
 #pragma unroll
     for (int k = 0; k < D; ++k) OUT[i][k] = 0.0;
   }
-  // the record, x+ and the observation of the NEXT step (t - 1) are requested before step t is computed
-  dbl2 nrec[REC / 2];
-  double nx[D], ny = 0.0;
-  auto request = [&](int t) {
+  // tiles of BT records walked downwards from record T: the tile below is requested before this one is computed, the
+  // tile's draws leave together (whole lines for d <= 2)
+  constexpr int BT = D <= 2 ? 8 : (D == 3 ? 4 : 2);
+  dbl2 nrec[BT][REC / 2];
+  double nx[BT][D], ny[BT];
+  auto request = [&](int t0) {
 #pragma unroll
-    for (int q = 0; q < REC / 2; ++q) nrec[q] = in[(size_t)t * (REC / 2) + q];
+    for (int j = 0; j < BT; ++j) {
+      const int t = t0 + j < T ? t0 + j : T;
 #pragma unroll
-    for (int i = 0; i < D; ++i) nx[i] = xp[(size_t)t * D + i];
-    ny = (y && t > 0) ? y[t - 1] : 0.0;
+      for (int q = 0; q < REC / 2; ++q) nrec[j][q] = in[(size_t)t * (REC / 2) + q];
+#pragma unroll
+      for (int i = 0; i < D; ++i) nx[j][i] = xp[(size_t)t * D + i];
+      ny[j] = (y && t > 0) ? y[t - 1] : 0.0;
+    }
   };
-  request(T);
-  for (int t = T; t >= 0; --t) {
+  int t0 = (T / BT) * BT;   // the tile that holds record T
+  request(t0);
+  for (; t0 >= 0; t0 -= BT) {
+  dbl2 crec[BT][REC / 2];
+  double cx[BT][D], cy[BT], thb[BT][D];
+#pragma unroll
+  for (int j = 0; j < BT; ++j) {
+    cy[j] = ny[j];
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) crec[j][q] = nrec[j][q];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { cx[j][i] = nx[j][i]; thb[j][i] = 0.0; }
+  }
+  if (t0 > 0) request(t0 - BT);
+#pragma unroll
+  for (int j = BT - 1; j >= 0; --j) {
+    const int t = t0 + j;
+    if (t > T) continue;
     double m[D], C[D][D], xcur[D];
-    const double ycur = ny;
+    const double ycur = cy[j];
     {
       double v[REC];
 #pragma unroll
-      for (int q = 0; q < REC / 2; ++q) { v[2 * q] = nrec[q].x; v[2 * q + 1] = nrec[q].y; }
+      for (int q = 0; q < REC / 2; ++q) { v[2 * q] = crec[j][q].x; v[2 * q + 1] = crec[j][q].y; }
 #pragma unroll
-      for (int i = 0; i < D; ++i) { m[i] = v[i]; xcur[i] = nx[i]; }
+      for (int i = 0; i < D; ++i) { m[i] = v[i]; xcur[i] = cx[j][i]; }
 #pragma unroll
-      for (int j = 0; j < D; ++j)
+      for (int jj = 0; jj < D; ++jj)
 #pragma unroll
-        for (int i = 0; i < D; ++i) C[i][j] = v[D + i + j * D];
+        for (int i = 0; i < D; ++i) C[i][jj] = v[D + i + jj * D];
     }
-    request(t > 0 ? t - 1 : 0);
     const double dt = (t < T && a.dt) ? a.dt[t] : 1.0;                                     // the step t -> t + 1
     const double* Gt = a.G + (size_t)((t < T && a.g_index) ? a.g_index[t] : 0) * (D * D);
     if (t == T) {
@@ -667,7 +693,7 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
     }
     double th[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { th[i] = s[i] + xcur[i]; if (thout) thout[(size_t)t * D + i] = th[i]; }
+    for (int i = 0; i < D; ++i) { th[i] = s[i] + xcur[i]; thb[j][i] = th[i]; }
     if (a.stats) {
       if (t < T) {   // system residual (theta_{t+1} - G_{t+1} theta_t) / sqrt(dt)
         const double dts = (dt == 0.0) ? 1.0 : dt, isd = 1.0 / sqrt(dts);
@@ -704,6 +730,13 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
     }
 #pragma unroll
     for (int i = 0; i < D; ++i) thn[i] = th[i];
+  }
+  if (thout) {
+#pragma unroll
+    for (int j = 0; j < BT; ++j)
+#pragma unroll
+      for (int i = 0; i < D; ++i) if (t0 + j <= T) thout[(size_t)(t0 + j) * D + i] = thb[j][i];
+  }
   }
   bool bad = false;
 #pragma unroll
