@@ -761,12 +761,12 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
 
 }  // namespace lane
 
+constexpr int LANE_MIN_N = 1;   // a lane's step is a few hundred cycles, a wavefront-per-series step a few thousand: faster at every batch size (tools/lane_small_n.py)
 constexpr int LANE_MAX_D = 5;   // at d = 6 the backward pass no longer fits the register file (78 spilled registers)
 
-// d <= 5, p = 1, enough series to fill the chip with lanes (below that a wavefront per series finishes sooner);
-// per-step V_t / W_t streams are read per lane, any time grid, time-varying F.
+// d <= 5, p = 1; per-step V_t / W_t streams are read per lane, any time grid, time-varying F.
 bool lane_supported(const KArgs& a) {
-  return a.d >= 1 && a.d <= LANE_MAX_D && a.p == 1 && a.N >= 8192;
+  return a.d >= 1 && a.d <= LANE_MAX_D && a.p == 1 && a.N >= LANE_MIN_N;
 }
 
 hipError_t launch_lane_filter(const KArgs& a, hipStream_t s) {

@@ -480,7 +480,7 @@ def test_ffbs_simulation_smoother_distribution(eng):
     y1 = simulate(mat, p, 1, seed=4)
     N = 6000
     out = eng.ffbs(mat, p, np.repeat(y1, N, axis=0), seed=123, flags=_lib.OPT_FFBS_SIMSMOOTH)
-    assert eng.last_variant == "sparse16-simsmooth"
+    assert eng.last_variant == "lane-simsmooth"   # d = 2, p = 1: one lane per series
     f, s = oracle_filter_smooth(mat, p, y1[0])
     for t in (0, 12, 30):
         th = out["theta"][:, t]
