@@ -80,7 +80,9 @@ __device__ __forceinline__ void load_w(const double* __restrict__ Wp, double (&W
 // ---------------------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------------------
-template <int D>
+// IRR = false: one G, one F, unit time increments -- the model is read once, before the time loop (a step of a single
+// series is then a chain of a few dozen dependent operations with no load in it)
+template <int D, bool IRR>
 __global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
   constexpr int REC = D + D * D;
   const int n = blockIdx.x * 64 + threadIdx.x;
@@ -122,6 +124,11 @@ __global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
   if (pri) store(pri, 0, m, C);
   if (fq) { fq[0] = __builtin_nan(""); fq[1] = __builtin_nan(""); }
 
+  double Gc[D * D], Fc[D];     // the time-invariant model (IRR = false)
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) Gc[i] = a.G[i];
+#pragma unroll
+  for (int i = 0; i < D; ++i) Fc[i] = a.F[i];
   const int Tl = T - 1;
   double yb[YT];
   auto request = [&](int t0) {
@@ -148,11 +155,11 @@ __global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
     for (int j = 0; j < YT; ++j) {
       const int t = t0 + j;
       if (t < T) {
-        const double dt = a.dt ? a.dt[t] : 1.0;
-        const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
-        const double* Ft = a.F + (size_t)t * a.f_stride;
-        if (a.v_tstride) V = V0[(size_t)t * a.v_tstride];
-        if (a.w_tstride) load_w<D>(W0 + (size_t)t * a.w_tstride, W);
+        const double dt = (IRR && a.dt) ? a.dt[t] : 1.0;
+        const double* Gt = IRR ? a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D) : Gc;
+        const double* Ft = IRR ? a.F + (size_t)t * a.f_stride : Fc;
+        if (IRR && a.v_tstride) V = V0[(size_t)t * a.v_tstride];
+        if (IRR && a.w_tstride) load_w<D>(W0 + (size_t)t * a.w_tstride, W);
         double av[D], R[D][D];
         advance<D>(Gt, dt, W, m, C, av, R);
         if (pri) store(pri, t + 1, av, R);
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(64) void k_filter_lane(KArgs a) {
 // ---------------------------------------------------------------------------------------
 // backward pass
 // ---------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool IRR>
 __global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
   constexpr int REC = D + D * D;
   constexpr int RT = D <= 2 ? 8 : (D == 3 ? 4 : (D == 4 ? 2 : 1));     // records requested per tile (128 - 384 bytes per lane)
@@ -241,6 +248,9 @@ __global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
   double* outp = a.smooth + (size_t)n * (T + 1) * REC;
   int st = 0;
   double s[D], S[D][D];
+  double Gc[D * D];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) Gc[i] = a.G[i];
   auto unpack = [&](const dbl2* r, double (&mm)[D], double (&CC)[D][D]) {
     double v[REC];
 #pragma unroll
@@ -296,9 +306,9 @@ __global__ __launch_bounds__(64) void k_smoother_lane(KArgs a) {
       if (t < T) {
         double m[D], C[D][D];
         unpack(cur[j], m, C);
-        const double dt = a.dt ? a.dt[t] : 1.0;
-        const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
-        if (a.w_tstride) load_w<D>(W0 + (size_t)t * a.w_tstride, W);
+        const double dt = (IRR && a.dt) ? a.dt[t] : 1.0;
+        const double* Gt = IRR ? a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D) : Gc;
+        if (IRR && a.w_tstride) load_w<D>(W0 + (size_t)t * a.w_tstride, W);
         double a1[D], R1[D][D];
         advance<D>(Gt, dt, W, m, C, a1, R1);
         // Cholesky of R+ (lower), B = C G^T, J = B R+^-1 row by row
@@ -771,12 +781,13 @@ bool lane_supported(const KArgs& a) {
 
 hipError_t launch_lane_filter(const KArgs& a, hipStream_t s) {
   const dim3 grid((a.N + 63) / 64), block(64);
+  const bool irr = a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride;
   switch (a.d) {
-    case 1: hipLaunchKernelGGL(lane::k_filter_lane<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(lane::k_filter_lane<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(lane::k_filter_lane<3>, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(lane::k_filter_lane<4>, grid, block, 0, s, a); break;
-    case 5: hipLaunchKernelGGL(lane::k_filter_lane<5>, grid, block, 0, s, a); break;
+    case 1: if (irr) hipLaunchKernelGGL((lane::k_filter_lane<1, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_filter_lane<1, false>), grid, block, 0, s, a); break;
+    case 2: if (irr) hipLaunchKernelGGL((lane::k_filter_lane<2, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_filter_lane<2, false>), grid, block, 0, s, a); break;
+    case 3: if (irr) hipLaunchKernelGGL((lane::k_filter_lane<3, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_filter_lane<3, false>), grid, block, 0, s, a); break;
+    case 4: if (irr) hipLaunchKernelGGL((lane::k_filter_lane<4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_filter_lane<4, false>), grid, block, 0, s, a); break;
+    case 5: if (irr) hipLaunchKernelGGL((lane::k_filter_lane<5, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_filter_lane<5, false>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -784,12 +795,13 @@ hipError_t launch_lane_filter(const KArgs& a, hipStream_t s) {
 
 hipError_t launch_lane_smoother(const KArgs& a, hipStream_t s) {
   const dim3 grid((a.N + 63) / 64), block(64);
+  const bool irr = a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride;
   switch (a.d) {
-    case 1: hipLaunchKernelGGL(lane::k_smoother_lane<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(lane::k_smoother_lane<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(lane::k_smoother_lane<3>, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(lane::k_smoother_lane<4>, grid, block, 0, s, a); break;
-    case 5: hipLaunchKernelGGL(lane::k_smoother_lane<5>, grid, block, 0, s, a); break;
+    case 1: if (irr) hipLaunchKernelGGL((lane::k_smoother_lane<1, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_smoother_lane<1, false>), grid, block, 0, s, a); break;
+    case 2: if (irr) hipLaunchKernelGGL((lane::k_smoother_lane<2, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_smoother_lane<2, false>), grid, block, 0, s, a); break;
+    case 3: if (irr) hipLaunchKernelGGL((lane::k_smoother_lane<3, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_smoother_lane<3, false>), grid, block, 0, s, a); break;
+    case 4: if (irr) hipLaunchKernelGGL((lane::k_smoother_lane<4, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_smoother_lane<4, false>), grid, block, 0, s, a); break;
+    case 5: if (irr) hipLaunchKernelGGL((lane::k_smoother_lane<5, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((lane::k_smoother_lane<5, false>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
