@@ -128,3 +128,34 @@ def test_c3_full_size_ffbs_properties(eng):
     sm = eng.filter_smooth(mat, p, y)["smooth"]
     zsc = (a["theta"] - sm[..., :13]) / torch.sqrt(sm[..., 13:].reshape(10000, 1001, 13, 13).diagonal(dim1=-2, dim2=-1))
     assert abs(float(zsc.mean())) < 2e-3 and abs(float(zsc.var()) - 1.0) < 5e-3   # 1.3e8 standardised draws
+
+
+def test_c1_shape_at_scale_lane_kernels(eng):
+    """BASELINE configs[0]'s model (first-order DLM, T = 1000) over 200 000 series, and a linear-growth model over 100 000
+    with an irregular grid: one lane per series (dlm_lane.hip) through the same properties."""
+    import torch
+    rng = np.random.default_rng(101)
+    mat = materialise(Dlm.polynomial(1), np.arange(1, 1001, dtype=np.float64))
+    p = DlmParameters([[2.0]], [[3.0]], [0.0], [[10.0]])
+    yh = rng.standard_normal((200000, 1000, 1)).cumsum(axis=1)
+    yh[rng.random(yh.shape) < 0.03] = np.nan
+    _properties(eng, mat, p, torch.as_tensor(yh, device="cuda"), [0, 199999, 63, 64, 123457], "lane", 1e-10, 1e-9)
+    gaps = np.tile(np.array([1.0, 2.0, 1.0, 0.5, 3.0, 1.0, 1.0, 0.5]), 125)
+    mat2 = materialise(Dlm.polynomial(2), np.cumsum(gaps))
+    p2 = DlmParameters([[1.5]], np.array([[0.4, 0.1], [0.1, 0.2]]), [0.0, 0.0], np.eye(2) * 5.0)
+    y2 = rng.standard_normal((100000, 1000, 1)).cumsum(axis=1)
+    y2[rng.random(y2.shape) < 0.03] = np.nan
+    _properties(eng, mat2, p2, torch.as_tensor(y2, device="cuda"), [0, 99999, 31415], "lane", 1e-9, 1e-8)
+
+
+def test_small_multivariate_full_size(eng):
+    """d = 8, p = 4 (four linear-growth components), 10 000 series x T = 1000 on the per-wave kernels with one tile per dimension."""
+    import torch
+    rng = np.random.default_rng(84)
+    mod = Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2) * Dlm.polynomial(2)
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    B = rng.standard_normal((4, 4)); A = rng.standard_normal((8, 8))
+    p = DlmParameters(B @ B.T / 4 + 0.5 * np.eye(4), A @ A.T / 8 * 0.2 + 0.05 * np.eye(8), np.zeros(8), np.eye(8) * 4.0)
+    yh = rng.standard_normal((10000, 1000, 4)).cumsum(axis=1)
+    yh[rng.random(yh.shape) < 0.03] = np.nan
+    _properties(eng, mat, p, torch.as_tensor(yh, device="cuda"), [0, 9999, 4242], "wave-mfma", 1e-8, 1e-7)
