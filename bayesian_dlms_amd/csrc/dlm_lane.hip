@@ -510,25 +510,29 @@ __global__ __launch_bounds__(64) void k_simfilter_lane(KArgs a, double* __restri
     for (int i = 0; i < D; ++i) xo[(size_t)t * D + i] = x[i];
   };
   store(0);
+  // tiles of ST steps: the tile's observations are requested one tile ahead, its records and x+ leave together (whole
+  // lines for d <= 2; the step body with its normal generator is unrolled ST times, hence the small tiles)
+  constexpr int ST = D == 1 ? 8 : (D == 2 ? 4 : 1);
   const int Tl = T - 1;
-  double yb[YT];
+  double yb[ST];
   auto request = [&](int t0) {
 #pragma unroll
-    for (int j = 0; j < YT; ++j) { const int t = t0 + j < Tl ? t0 + j : Tl; yb[j] = y[t]; }
+    for (int j = 0; j < ST; ++j) { const int t = t0 + j < Tl ? t0 + j : Tl; yb[j] = y[t]; }
   };
   if (T > 0) request(0);
-  for (int t0 = 0; t0 < T; t0 += YT) {
-  double yc[YT];
+  for (int t0 = 0; t0 < T; t0 += ST) {
+  double yc[ST];
 #pragma unroll
-  for (int j = 0; j < YT; ++j) yc[j] = yb[j];
-  if (t0 + YT < T) request(t0 + YT);
-#pragma unroll 1
-  for (int j = 0; j < YT; ++j) {
+  for (int j = 0; j < ST; ++j) yc[j] = yb[j];
+  if (t0 + ST < T) request(t0 + ST);
+  const bool whole = ST > 1 && t0 + ST <= T;
+  dbl2 ob[ST][REC / 2];
+  double xb[ST][D];
+#pragma unroll
+  for (int j = 0; j < ST; ++j) {
     const int t = t0 + j;
     if (t >= T) break;
-    double ycur = yc[0];
-#pragma unroll
-    for (int q = 1; q < YT; ++q) ycur = (j == q) ? yc[q] : ycur;
+    const double ycur = yc[j];
     const double dt = a.dt ? a.dt[t] : 1.0;
     const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
     const double* Ft = a.F + (size_t)t * a.f_stride;
@@ -586,7 +590,29 @@ __global__ __launch_bounds__(64) void k_simfilter_lane(KArgs a, double* __restri
         for (int k = 0; k < D; ++k) C[i][k] = R[i][k];
       }
     }
-    store(t + 1);
+    if (!whole) store(t + 1);
+    else {
+      double r[REC];
+#pragma unroll
+      for (int i = 0; i < D; ++i) { r[i] = m[i]; xb[j][i] = x[i]; }
+#pragma unroll
+      for (int jj = 0; jj < D; ++jj)
+#pragma unroll
+        for (int i = 0; i < D; ++i) r[D + i + jj * D] = C[i][jj];
+#pragma unroll
+      for (int q = 0; q < REC / 2; ++q) ob[j][q] = dbl2{r[2 * q], r[2 * q + 1]};
+    }
+  }
+  if (whole) {
+    dbl2* o = (dbl2*)(out + (size_t)(t0 + 1) * REC);
+#pragma unroll
+    for (int j = 0; j < ST; ++j)
+#pragma unroll
+      for (int q = 0; q < REC / 2; ++q) o[j * (REC / 2) + q] = ob[j][q];
+#pragma unroll
+    for (int j = 0; j < ST; ++j)
+#pragma unroll
+      for (int i = 0; i < D; ++i) xo[(size_t)(t0 + 1 + j) * D + i] = xb[j][i];
   }
   }
   if (a.status && st) atomicOr(&a.status[n], st);
