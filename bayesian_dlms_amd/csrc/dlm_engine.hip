@@ -624,6 +624,11 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }
+  if (use_lane(k)) {
+    e->variant = "lane-sampler";
+    HIP_TRY(e, dlm::launch_lane_sampler(k, e->stream));
+    return st.finish(opts->flags & DLM_OPT_ASYNC);
+  }
   e->variant = "generic";
   HIP_TRY(e, dlm::launch_generic_sampler(k, e->stream));
   return st.finish(opts->flags & DLM_OPT_ASYNC);

@@ -107,6 +107,7 @@ hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t
 bool lane_supported(const KArgs& a);
 hipError_t launch_lane_filter(const KArgs& a, hipStream_t s);
 hipError_t launch_lane_smoother(const KArgs& a, hipStream_t s);   // a.filt_in -> a.smooth; no side buffer
+hipError_t launch_lane_sampler(const KArgs& a, hipStream_t s);   // the literal backward sampler (a.filt_in -> theta / cond / stats)
 hipError_t launch_lane_simsmooth(const KArgs& a, double* xplus, hipStream_t s);   // simulation-smoother FFBS + statistics (time-invariant V, W)
 
 // ---- scalar AR(1) FFBS, one lane per series (FilterAr.scala:15-82), dlm_ar1.hip -----------------

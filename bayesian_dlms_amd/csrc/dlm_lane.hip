@@ -795,6 +795,219 @@ __global__ __launch_bounds__(64) void k_simsmooth_lane(KArgs a, const double* __
   if (a.status && st) atomicOr(&a.status[n], st);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The reference's backward sampler, literally (Smoothing.sampleDlm / backSampleStep, Smoothing.scala:74-122), one lane per
+// series: theta_T ~ N(m_T, C_T);  J = C G^T R+^-1,  h = m + J (theta+ - a+),  H = (I - J G) C (I - J G)^T + dt J W J^T
+// (symmetrised, :95),  theta_t = h + chol(H) z_t  (the engine's canonical factor), with the optional
+// conditional-moment records and the Gibbs statistics of k_sampler_generic.  Normals: a.z [N][T+1][d] or Philox
+// (seed, series, record t, i).
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void k_sampler_lane(KArgs a) {
+  constexpr int REC = D + D * D;
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= a.N) return;
+  const int T = a.T;
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
+  const double* W0 = a.W + (size_t)n * a.w_stride;
+  double W[D][D];
+  load_w<D>(W0, W);
+  const dbl2* in = (const dbl2*)(a.filt_in + (size_t)n * (T + 1) * REC);
+  const double* y = a.y ? a.y + (size_t)n * T : nullptr;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * D : nullptr;
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * D : nullptr;
+  double* cond = a.cond ? a.cond + (size_t)n * (T + 1) * REC : nullptr;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  int st = 0;
+  double th[D], ssd[D], OUT[D][D], ssy = 0.0, nob = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    ssd[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) OUT[i][k] = 0.0;
+  }
+  auto load_rec = [&](int t, double (&m)[D], double (&C)[D][D]) {
+    double v[REC];
+#pragma unroll
+    for (int q = 0; q < REC / 2; ++q) { const dbl2 r = in[(size_t)t * (REC / 2) + q]; v[2 * q] = r.x; v[2 * q + 1] = r.y; }
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = v[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int i = 0; i < D; ++i) C[i][j] = v[D + i + j * D];
+  };
+  auto normals = [&](int t, double (&z)[D + 1]) {
+    if (zin) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) z[i] = zin[(size_t)t * D + i];
+    } else {
+#pragma unroll
+      for (int q = 0; q < (D + 1) / 2; ++q) philox_normal2(a.seed, series, (unsigned)t, (unsigned)q, z[2 * q], z[2 * q + 1]);
+    }
+  };
+  auto emit = [&](int t, const double (&h)[D], const double (&H)[D][D], const double (&z)[D + 1], double (&out)[D]) {
+    if (cond) {
+      double* c = cond + (size_t)t * REC;
+#pragma unroll
+      for (int i = 0; i < D; ++i) c[i] = h[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int i = 0; i < D; ++i) c[D + i + j * D] = H[i][j];
+    }
+    double L[D][D];
+    if (chol_small<D>(H, L)) st |= DLM_ST_NOT_PD;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double v = h[i];
+#pragma unroll
+      for (int k = 0; k <= i; ++k) v = fma(L[i][k], z[k], v);
+      out[i] = v;
+      if (thout) thout[(size_t)t * D + i] = v;
+    }
+  };
+  {
+    double m[D], C[D][D], z[D + 1];
+    load_rec(T, m, C);
+    normals(T, z);
+    emit(T, m, C, z, th);
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * (D * D);
+    const double* Ft = a.F + (size_t)t * a.f_stride;
+    if (a.stats && y) {   // observation residual of theta_{t+1} (Gibbs.scala:29-39)
+      const double yv = y[t];
+      if (yv == yv) {
+        double f = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) f = fma(Ft[i], th[i], f);
+        ssy += (yv - f) * (yv - f); nob += 1.0;
+      }
+    }
+    double m[D], C[D][D], z[D + 1];
+    load_rec(t, m, C);
+    normals(t, z);
+    if (a.w_tstride) load_w<D>(W0 + (size_t)t * a.w_tstride, W);
+    double G[D][D], a1[D], R1[D][D], Lr[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int k = 0; k < D; ++k) G[i][k] = Gt[i + k * D];
+    advance<D>(Gt, dt, W, m, C, a1, R1);
+    if (chol_small<D>(R1, Lr)) st |= DLM_ST_NOT_PD;
+    // J^T = R+^-1 (G C): column i of J^T = row i of J solves R+ x = (G C)[:, i]
+    double J[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double x[D];
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        double b = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) b = fma(G[r][k], C[k][i], b);
+        x[r] = b;
+      }
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        double v = x[r];
+#pragma unroll
+        for (int k = 0; k < r; ++k) v = fma(-Lr[r][k], x[k], v);
+        x[r] = v / Lr[r][r];
+      }
+#pragma unroll
+      for (int r = D - 1; r >= 0; --r) {
+        double v = x[r];
+#pragma unroll
+        for (int k = r + 1; k < D; ++k) v = fma(-Lr[k][r], x[k], v);
+        x[r] = v / Lr[r][r];
+      }
+#pragma unroll
+      for (int r = 0; r < D; ++r) J[i][r] = x[r];
+    }
+    double h[D], Dm[D][D], DC[D][D], JW[D][D], H[D][D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double v = m[i];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v = fma(J[i][k], th[k] - a1[k], v);
+      h[i] = v;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int l = 0; l < D; ++l) acc = fma(-J[i][l], G[l][j], acc);
+        Dm[i][j] = acc;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double v = 0.0, w_ = 0.0;
+#pragma unroll
+        for (int l = 0; l < D; ++l) { v = fma(Dm[i][l], C[l][j], v); w_ = fma(J[i][l], W[l][j], w_); }
+        DC[i][j] = v; JW[i][j] = w_;
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double v = 0.0, w_ = 0.0;
+#pragma unroll
+        for (int l = 0; l < D; ++l) { v = fma(DC[i][l], Dm[j][l], v); w_ = fma(JW[i][l], J[j][l], w_); }
+        H[i][j] = fma(w_, dt, v);
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) { const double v = (H[i][j] + H[j][i]) / 2.0; H[i][j] = v; H[j][i] = v; }
+    double tn[D];
+    emit(t, h, H, z, tn);
+    if (a.stats) {   // system residual theta_{t+1} - G theta_t (always the table entry)
+      const double dts = (dt == 0.0) ? 1.0 : dt;
+      double df[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double v = th[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) v = fma(-G[i][k], tn[k], v);
+        df[i] = v;
+        ssd[i] += v * v / dts;
+      }
+      if (outer) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int k = 0; k < D; ++k) OUT[i][k] += df[i] * df[k] / dts;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) th[i] = tn[i];
+  }
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < D; ++i) bad |= !isfinite(th[i]);
+  if (bad) st |= DLM_ST_NONFINITE;
+  if (a.stats) {
+    const int L_ = stats_len(D, 1, a.flags);
+    double* so = a.stats + (size_t)n * L_;
+    so[0] = ssy; so[1] = nob; so[L_ - 1] = (double)T;
+    if (outer) {
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int k = 0; k < D; ++k) so[2 + i + k * D] = OUT[i][k];
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i) so[2 + i] = ssd[i];
+    }
+  }
+  if (a.status && st) atomicOr(&a.status[n], st);
+}
+
 }  // namespace lane
 
 constexpr int LANE_MIN_N = 1;   // a lane's step is a few hundred cycles, a wavefront-per-series step a few thousand: faster at every batch size (tools/lane_small_n.py)
@@ -833,6 +1046,19 @@ hipError_t launch_lane_smoother(const KArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+
+hipError_t launch_lane_sampler(const KArgs& a, hipStream_t s) {
+  const dim3 grid((a.N + 63) / 64), block(64);
+  switch (a.d) {
+    case 1: hipLaunchKernelGGL(lane::k_sampler_lane<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(lane::k_sampler_lane<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(lane::k_sampler_lane<3>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(lane::k_sampler_lane<4>, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(lane::k_sampler_lane<5>, grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 
 // forward SIM pass (filt records + x+) followed by the mean-only backward pass; xplus [N][T+1][d] is engine workspace
 hipError_t launch_lane_simsmooth(const KArgs& a, double* xplus, hipStream_t s) {

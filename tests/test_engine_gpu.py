@@ -1380,6 +1380,26 @@ def test_lane_per_series_small_models(eng, kind):
             np.testing.assert_allclose(dz["stats"][n, 0], stt["ssy"][0], rtol=1e-8)
             np.testing.assert_array_equal(dz["stats"][n, 1], stt["n"][0])
             np.testing.assert_allclose(dz["stats"][n, 2:2 + d * d], stt["outer"], rtol=1e-7, atol=1e-8)
+    # the literal backward sampler (Smoothing.sampleDlm) on lanes: draws, conditional moments and statistics equal the generic kernel's
+    zl = rng.standard_normal((N, T + 1, d))
+    lit = eng.ffbs(mat, p, y[:256], z=zl[:256], want_cond=True, flags=_lib.OPT_STATS_OUTER)
+    assert eng.last_variant == "lane-sampler"
+    gen = eng.ffbs(mat, p, y[:256], z=zl[:256], want_cond=True, flags=_lib.OPT_STATS_OUTER | _lib.OPT_FORCE_GENERIC)
+    assert eng.last_variant == "generic"
+    np.testing.assert_array_equal(lit["status"], gen["status"])
+    if mat.dt is None or not np.any(np.asarray(mat.dt) == 0.0):
+        # (a zero time increment makes the reference's conditional covariance H exactly singular when g(0) is not the identity:
+        # both kernels flag DLM_ST_NOT_PD there and the draw along the null directions is undefined)
+        assert np.all(lit["status"] == 0)
+        np.testing.assert_allclose(lit["theta"], gen["theta"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(lit["cond"], gen["cond"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(lit["stats"], gen["stats"], rtol=1e-8, atol=1e-9)
+        lp = eng.ffbs(mat, p, y[:256], seed=4, series_offset=7)
+        gp = eng.ffbs(mat, p, y[:256], seed=4, series_offset=7, flags=_lib.OPT_FORCE_GENERIC)
+        np.testing.assert_allclose(lp["theta"], gp["theta"], rtol=1e-9, atol=1e-9)
+        for n in (0, 5, 255):   # and the oracle's literal sampler with the canonical (Cholesky) factor
+            fo = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n])
+            np.testing.assert_allclose(lit["theta"][n], oracle.backward_sample(omodel(mat), p.w, fo, zl[n], factor="chol")["theta"], rtol=1e-8, atol=1e-8)
     dp = eng.ffbs(mat, p, y, seed=9, series_offset=3, flags=_lib.OPT_FFBS_SIMSMOOTH)
     os.environ["DLM_NO_LANE"] = "1"
     try:
