@@ -42,13 +42,16 @@ __device__ __forceinline__ void gemm(int lane, int m, int n, int k, const double
 
 // In-place lower Cholesky of the n x n LDS matrix A (column-major).  Returns true when a
 // non-positive pivot was met (the factor is then completed with a tiny pivot).
-__device__ bool chol_lds(int lane, int n, double* A) {
+// psd: the factor of a covariance to DRAW with -- a non-positive pivot gives a zero column (the direction has no variance:
+// what the oracle's chol_lower does) instead of the tiny pivot that keeps a later triangular solve finite.
+__device__ bool chol_lds(int lane, int n, double* A, bool psd = false) {
   bool bad = false;
   for (int k = 0; k < n; ++k) {
     wsync();
     double akk = A[CM(k, k, n)];
-    if (!(akk > 0.0)) { bad = true; akk = 1e-300; }
-    const double lkk = sqrt(akk), inv = 1.0 / lkk;
+    const bool np = !(akk > 0.0);
+    if (np) { bad = true; akk = 1e-300; }
+    const double lkk = (np && psd) ? 0.0 : sqrt(akk), inv = (np && psd) ? 0.0 : 1.0 / lkk;
     wsync();
     for (int i = k + lane; i < n; i += 64) A[CM(i, k, n)] = (i == k) ? lkk : A[CM(i, k, n)] * inv;
     wsync();
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(64) void k_sampler_generic(KArgs a) {
       for (int i = lane; i < dd; i += 64) c[d + i] = H[i];
     }
     wsync();
-    if (chol_lds(lane, d, H)) st |= DLM_ST_NOT_PD;
+    if (chol_lds(lane, d, H, true)) st |= DLM_ST_NOT_PD;
     for (int i = lane; i < d; i += 64) {
       double acc = h[i];
       for (int k = 0; k <= i; ++k) acc = fma(H[CM(i, k, d)], zv[k], acc);
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(64) void k_sampler_generic(KArgs a) {
       for (int i = lane; i < d; i += 64) c[i] = h[i];
       for (int i = lane; i < dd; i += 64) c[d + i] = T2[i];
     }
-    if (chol_lds(lane, d, T2)) st |= DLM_ST_NOT_PD;
+    if (chol_lds(lane, d, T2, true)) st |= DLM_ST_NOT_PD;
     // theta_t = h + L z ; system-innovation statistic of (theta_t, theta_{t+1})
     for (int i = lane; i < d; i += 64) {
       double acc = h[i];
