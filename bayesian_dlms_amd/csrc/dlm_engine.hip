@@ -624,9 +624,15 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }
+  if (!forward && (rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;   // the structure tables of G
   if (use_lane(k)) {
     e->variant = "lane-sampler";
     HIP_TRY(e, dlm::launch_lane_sampler(k, e->stream));
+    return st.finish(opts->flags & DLM_OPT_ASYNC);
+  }
+  if (fast_shape_ok(k) && e->sparse_k > 0 && !getenv("DLM_NO_SAMPLER16")) {
+    e->variant = "sparse16-sampler";
+    HIP_TRY(e, dlm::launch_sparse16_sampler(k, e->sparse_k, e->sp_dev, e->stream));
     return st.finish(opts->flags & DLM_OPT_ASYNC);
   }
   e->variant = "generic";

@@ -1,0 +1,373 @@
+// The reference's backward sampler, literally, for d <= 15 with a structured G -- one wavefront per series, every d x d
+// matrix one 16 x 16 tile in the fp64 MFMA accumulator layout (the single-tile case of dlm_wave48.hip).
+//
+// Smoothing.sampleDlm / backSampleStep (Smoothing.scala:74-122), per step t = T-1 .. 0, given theta_{t+1}:
+//   a+ = G m, R+ = G C G^T + W dt                      (dt == 0: a+ = m, R+ = C; KalmanFilter.scala:279-280)
+//   J  = C G^T R+^-1                                   (the table entry g(dt) also for dt == 0, Smoothing.scala:85)
+//   h  = m + J (theta_{t+1} - a+)
+//   H  = (I - J G) C (I - J G)^T + dt J W J^T          (:88-93), symmetrised (:95)
+//   theta_t = h + chol(H) z_t                          (the engine's canonical factor)
+// with the conditional-moment records and the Gibbs statistics of k_sampler_generic (dlm_generic.hip), whose draws it
+// reproduces.  What makes it fast: G C G^T, C G^T and J G are gathers through a wave-private LDS image (G has at most
+// four nonzeros per row and column), the five dense products are MFMA chains on registers, R+^-1 is a Newton-Schulz
+// refinement of the previous step's inverse (R+ changes slowly along a series; direct Cholesky inverse when the start
+// is too far off), and only the factor of H -- thirteen dependent pivots -- runs as a one-wave Cholesky in LDS.
+#include "dlm_internal.h"
+#include "../../include/dlm_engine.h"
+
+namespace dlm {
+namespace s16 {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+constexpr int IL = 17;
+constexpr int IMG = 16 * IL;
+constexpr int OOB = 0x7ffffff0;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double sum_g(double v) {   // sum over lanes c, c+16, c+32, c+48; all get it
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+  l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return __hiloint2double((int)v[1], (int)v[0]);
+}
+__device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x) {
+  const u2 v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+// X^T Y over the first `rows` rows (lane 16 g + c, register r <-> element (4 r + g, c))
+__device__ __forceinline__ d4 mm(const d4& x, const d4& y, int rows) {
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (4 * r < rows) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[r], y[r], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void to_img(const d4& x, double* img, int g, int c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) img[(4 * r + g) * IL + c] = x[r];
+}
+__device__ __forceinline__ d4 transposed(const d4& x, double* img, int g, int c) {
+  to_img(x, img, g, c);
+  wave_sync();
+  d4 y;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = img[c * IL + 4 * r + g];
+  wave_sync();
+  return y;
+}
+// y[c] = sum_i M[i][c] x[i]  (x: LDS vector, zero beyond its length)
+__device__ __forceinline__ double matTvec(const d4& M, const double* x, int g) {
+  double acc = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc = fma(M[r], x[4 * r + g], acc);
+  return sum_g(acc);
+}
+// in-place lower Cholesky of the n x n row-major LDS matrix (leading dimension IL).  psd: a non-positive pivot gives a zero
+// column (a direction without variance, as the oracle's factor) instead of failing the solve that follows.
+__device__ __forceinline__ bool chol_rows(double* L, int n, int lane, bool psd) {
+  bool bad = false;
+  for (int k = 0; k < n; ++k) {
+    double akk = L[k * IL + k];
+    const bool np = !(akk > 0.0);
+    if (np) { bad = true; akk = 1e-300; }
+    const double lkk = (np && psd) ? 0.0 : sqrt(akk), inv = (np && psd) ? 0.0 : 1.0 / lkk;
+    wave_sync();
+    if (lane >= k && lane < n) L[lane * IL + k] = (lane == k) ? lkk : L[lane * IL + k] * inv;
+    wave_sync();
+    const int rr = n - k - 1;
+    for (int idx = lane; idx < rr * rr; idx += 64) {
+      const int i = k + 1 + idx % rr, j = k + 1 + idx / rr;
+      if (i >= j) L[i * IL + j] = fma(-L[i * IL + k], L[j * IL + k], L[i * IL + j]);
+    }
+    wave_sync();
+  }
+  return bad;
+}
+// X = (SPD Q)^-1 by Cholesky and n triangular solves in LDS (img: factor, B: the inverse)
+__device__ __forceinline__ bool direct_inverse(const d4& Q, d4& X, int n, double* img, double* B, int lane, int g, int c) {
+  to_img(Q, img, g, c);
+  wave_sync();
+  const bool bad = chol_rows(img, n, lane, false);
+  if (lane < n) {
+    double* x = B + lane;
+    for (int i = 0; i < n; ++i) {
+      double s = (i == lane) ? 1.0 : 0.0;
+      for (int l = 0; l < i; ++l) s = fma(-img[i * IL + l], x[l * IL], s);
+      x[i * IL] = s / img[i * IL + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = x[i * IL];
+      for (int l = i + 1; l < n; ++l) s = fma(-img[l * IL + i], x[l * IL], s);
+      x[i * IL] = s / img[i * IL + i];
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    X[r] = (i < n && c < n) ? 0.5 * (B[i * IL + c] + B[c * IL + i]) : 0.0;
+  }
+  wave_sync();
+  return bad;
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __restrict__ sp) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16];
+  double* img = lds;       double* inv = lds + IMG;
+  double* mv = inv + IMG;  double* thv = mv + 16;   double* uv = thv + 16;   double* zv = uv + 16;
+  double* hv = zv + 16;    double* dfv = hv + 16;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int d = a.d, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  const bool vc = c < d;
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
+  for (int i = lane; i < 8 * 16; i += 64) mv[i] = 0.0;
+
+  int ridx[K], cidx[K];          // nonzeros of row c / column c of G
+  double rval[K], cval[K];
+  int gcur = -1;
+  auto load_tables = [&](int gi) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      ridx[s] = sp[2 * gi].idx[c][s];      rval[s] = vc ? sp[2 * gi].val[c][s] : 0.0;
+      cidx[s] = sp[2 * gi + 1].idx[c][s];  cval[s] = vc ? sp[2 * gi + 1].val[c][s] : 0.0;
+    }
+    gcur = gi;
+  };
+  const double* W0 = a.W + (size_t)n * a.w_stride;
+  d4 Wt;
+  bool va[4];
+  int offC[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    va[r] = i < d && vc;
+    offC[r] = va[r] ? (d + i + c * d) * 8 : OOB;      // C[i][c] of a record, column-major
+    Wt[r] = va[r] ? W0[i + c * d] : 0.0;
+  }
+  const int offM = (vc && g == 0) ? c * 8 : OOB;
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  double* cond = a.cond ? a.cond + (size_t)n * (T + 1) * rec : nullptr;
+  const __amdgpu_buffer_rsrc_t rco = mk_rsrc(cond, cond ? (size_t)(T + 1) * recb : 0);
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  const double* y = a.y ? a.y + (size_t)n * T : nullptr;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * d : nullptr;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  int st = 0;
+  d4 OUT = {0.0, 0.0, 0.0, 0.0}, Rinv = {0.0, 0.0, 0.0, 0.0};
+  double ssd = 0.0, ssy = 0.0, nob = 0.0;
+  bool warm = false;
+
+  // theta = h + chol(H) z, with the conditional record; leaves theta in thv and returns this lane's component
+  auto emit = [&](int t, double hcol, const d4& H, double zc) {
+    if (cond) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bst(rco, offC[r], t * recb, H[r]);
+      bst(rco, offM, t * recb, hcol);
+    }
+    to_img(H, img, g, c);
+    if (g == 0) zv[c] = vc ? zc : 0.0;
+    wave_sync();
+    if (chol_rows(img, d, lane, true)) st |= DLM_ST_NOT_PD;
+    double v = hcol;
+    if (vc) for (int k = 0; k <= c; ++k) v = fma(img[c * IL + k], zv[k], v);
+    wave_sync();
+    return vc ? v : 0.0;
+  };
+
+  {   // theta_T ~ N(m_T, C_T)
+    d4 C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[r] = bld(rin, offC[r], T * recb);
+    const double mc = bld(rin, vc ? c * 8 : OOB, T * recb);
+    const double zc = vc ? (zin ? zin[(size_t)T * d + c] : philox_normal(a.seed, series, (unsigned)T, (unsigned)c)) : 0.0;
+    const double th = emit(T, mc, C, zc);
+    if (g == 0) thv[c] = th;
+    if (thout && g == 0 && vc) thout[(size_t)T * d + c] = th;
+    wave_sync();
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    const int gi = a.g_index ? a.g_index[t] : 0;
+    if (gi != gcur) load_tables(gi);
+    const double Fc = vc ? (a.F + (size_t)t * a.f_stride)[c] : 0.0;
+    if (a.stats && y) {   // observation residual of theta_{t+1} (Gibbs.scala:29-39)
+      const double yv = y[t];
+      if (yv == yv) {
+        double f = (g == 0) ? Fc * thv[c] : 0.0;
+        for (int o_ = 8; o_ > 0; o_ >>= 1) f += __shfl_xor(f, o_);
+        f = __shfl(f, 0);
+        ssy += (yv - f) * (yv - f); nob += 1.0;
+      }
+    }
+    d4 C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[r] = bld(rin, offC[r], t * recb);
+    const double mc = bld(rin, vc ? c * 8 : OOB, t * recb);
+    const double zc = vc ? (zin ? zin[(size_t)t * d + c] : philox_normal(a.seed, series, (unsigned)t, (unsigned)c)) : 0.0;
+    if (a.w_tstride) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = va[r] ? (W0 + (size_t)t * a.w_tstride)[4 * r + g + c * d] : 0.0;
+    }
+    if (g == 0) mv[c] = mc;
+    to_img(C, img, g, c);
+    wave_sync();
+    // C G^T (pass 1), a+ and R+
+    d4 T1, R;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double* row = img + (4 * r + g) * IL;
+      double s_ = 0.0;
+#pragma unroll
+      for (int s = 0; s < K; ++s) s_ = fma(row[ridx[s]], rval[s], s_);
+      T1[r] = s_;
+    }
+    double a1 = mc;
+    if (dt != 0.0) {
+      double s_ = 0.0;
+#pragma unroll
+      for (int s = 0; s < K; ++s) s_ = fma(mv[ridx[s]], rval[s], s_);
+      a1 = s_;
+    }
+    wave_sync();
+    const d4 GC = transposed(T1, img, g, c);         // (C G^T)^T = G C
+    if (dt != 0.0) {
+      // pass 2 on the image of C G^T:  R[i][j] = sum_s (C G^T)[idx_s(j)][i] val_s(j) + W dt
+      to_img(T1, img, g, c);
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * r + g;
+        double s_ = Wt[r] * dt;
+#pragma unroll
+        for (int s = 0; s < K; ++s) s_ = fma(img[ridx[s] * IL + i], rval[s], s_);
+        R[r] = s_;
+      }
+      wave_sync();
+      const d4 Rt = transposed(R, img, g, c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R[r] = 0.5 * (R[r] + Rt[r]);
+    } else R = C;
+    // R+^-1: Newton-Schulz from the previous step's inverse, direct otherwise
+    {
+      bool done = false;
+      if (warm) {
+        for (int it = 0; it < 6 && !done; ++it) {
+          d4 E = mm(R, Rinv, d);
+          bool big = false, far = false;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 4 * r + g;
+            const double e = ((i == c) ? 1.0 : 0.0) - E[r];
+            E[r] = e;
+            if (i < d && vc) { big |= !(fabs(e) <= 2e-10); far |= !(fabs(e) * d < 0.5); }
+          }
+          const bool any_big = __ballot(big) != 0ull, any_far = __ballot(far) != 0ull;
+          if (any_far && any_big) break;
+          if (!any_big) done = true;
+          const d4 D = mm(Rinv, E, d);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Rinv[r] += D[r];
+          const d4 Xt = transposed(Rinv, img, g, c);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Rinv[r] = 0.5 * (Rinv[r] + Xt[r]);
+        }
+      }
+      if (!done && direct_inverse(R, Rinv, d, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
+      warm = true;
+    }
+    const d4 JT = mm(Rinv, GC, d);                    // J^T = R+^-1 G C
+    if (g == 0) uv[c] = vc ? thv[c] - a1 : 0.0;
+    wave_sync();
+    const double hcol = mc + matTvec(JT, uv, g);      // h = m + J (theta+ - a+)
+    // J G by columns of G on the image of J (= J^T written transposed), Dm = I - J G
+#pragma unroll
+    for (int r = 0; r < 4; ++r) img[c * IL + 4 * r + g] = JT[r];
+    wave_sync();
+    d4 Dm;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double* row = img + (4 * r + g) * IL;
+      double s_ = 0.0;
+#pragma unroll
+      for (int s = 0; s < K; ++s) s_ = fma(row[cidx[s]], cval[s], s_);
+      Dm[r] = ((4 * r + g == c && vc) ? 1.0 : 0.0) - s_;
+    }
+    wave_sync();
+    const d4 DmT = transposed(Dm, img, g, c);
+    const d4 CD = mm(C, DmT, d);                      // C Dm^T
+    d4 H = mm(DmT, CD, d);                            // Dm C Dm^T
+    const d4 WJ = mm(Wt, JT, d);                      // W J^T
+    const d4 H2 = mm(JT, WJ, d);                      // J W J^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) H[r] = fma(H2[r], dt, H[r]);
+    {
+      const d4 Ht = transposed(H, img, g, c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H[r] = (4 * r + g == c) ? H[r] : (H[r] + Ht[r]) / 2.0;
+    }
+    const double th = emit(t, hcol, H, zc);
+    if (a.stats) {   // system residual theta_{t+1} - G theta_t (always the table entry)
+      if (g == 0) hv[c] = th;
+      wave_sync();
+      double gth = 0.0;
+#pragma unroll
+      for (int s = 0; s < K; ++s) gth = fma(hv[ridx[s]], rval[s], gth);
+      const double dts = (dt == 0.0) ? 1.0 : dt;
+      const double df = vc ? thv[c] - gth : 0.0;
+      ssd += df * df / dts;
+      if (outer) {
+        if (g == 0) dfv[c] = df;
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) OUT[r] += dfv[4 * r + g] * df / dts;
+      }
+    }
+    wave_sync();
+    if (g == 0) thv[c] = th;
+    if (thout && g == 0 && vc) thout[(size_t)t * d + c] = th;
+    wave_sync();
+  }
+  if (__ballot(vc && !isfinite(thv[c])) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.stats) {
+    const int L = stats_len(d, 1, a.flags);
+    double* so = a.stats + (size_t)n * L;
+    if (lane == 0) { so[0] = ssy; so[1] = nob; so[L - 1] = (double)T; }
+    if (outer) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (va[r]) so[2 + 4 * r + g + c * d] = OUT[r];
+    } else if (g == 0 && vc) so[2 + c] = ssd;
+  }
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+}  // namespace s16
+
+hipError_t launch_sparse16_sampler(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s) {
+  switch (K) {
+    case 1: hipLaunchKernelGGL(s16::k_sampler_sp16<1>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 2: hipLaunchKernelGGL(s16::k_sampler_sp16<2>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 3: hipLaunchKernelGGL(s16::k_sampler_sp16<3>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 4: hipLaunchKernelGGL(s16::k_sampler_sp16<4>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace dlm
