@@ -90,10 +90,16 @@ __device__ __forceinline__ bool chol_rows(double* L, int n, int lane, bool psd) 
     wave_sync();
     if (lane >= k && lane < n) L[lane * IL + k] = (lane == k) ? lkk : L[lane * IL + k] * inv;
     wave_sync();
-    const int rr = n - k - 1;
-    for (int idx = lane; idx < rr * rr; idx += 64) {
-      const int i = k + 1 + idx % rr, j = k + 1 + idx / rr;
-      if (i >= j) L[i * IL + j] = fma(-L[i * IL + k], L[j * IL + k], L[i * IL + j]);
+    {   // trailing update, a lane's four elements (4 r + g, c) of the lower triangle
+      const int g_ = lane >> 4, j = lane & 15;
+      if (j > k && j < n) {
+        const double ljk = L[j * IL + k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * r + g_;
+          if (i >= j && i < n) L[i * IL + j] = fma(-L[i * IL + k], ljk, L[i * IL + j]);
+        }
+      }
     }
     wave_sync();
   }
