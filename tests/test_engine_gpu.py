@@ -261,7 +261,16 @@ def test_ffbs_moments_draws_and_stats(eng):
     y = simulate(mat, p, N, seed=77, missing=0.1)
     seed = 20240611
     out = eng.ffbs(mat, p, y, seed=seed, series_offset=5, want_cond=True)
-    assert np.all(out["status"] == 0)
+    assert eng.last_variant == "sparse16-sampler" and np.all(out["status"] == 0)   # register-tile literal sampler (dlm_sampler16.hip)
+    os.environ["DLM_NO_SAMPLER16"] = "1"
+    try:
+        gen = eng.ffbs(mat, p, y, seed=seed, series_offset=5, want_cond=True)
+        assert eng.last_variant == "generic"
+    finally:
+        del os.environ["DLM_NO_SAMPLER16"]
+    np.testing.assert_allclose(out["theta"], gen["theta"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(out["cond"], gen["cond"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(out["stats"], gen["stats"], rtol=1e-8, atol=1e-9)
     om = omodel(mat)
     for n in range(N):
         f = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y[n])
