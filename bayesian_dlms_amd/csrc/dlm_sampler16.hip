@@ -133,6 +133,37 @@ __device__ __forceinline__ bool direct_inverse(const d4& Q, d4& X, int n, double
   return bad;
 }
 
+// theta = h + chol(H) z with the factorisation in REGISTERS: lane i < d takes row i of H from the image, every pivot and
+// every multiplier travels by v_readlane (the indices are compile-time), so the thirteen dependent pivots cost no LDS
+// round trip and no barrier.  A non-positive pivot gives a zero column (a direction without variance, as the oracle's
+// factor) and is reported.  hcol / zc: h[lane], z[lane] in the lanes 0..d-1; returns theta[lane] there.
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane((int)__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane((int)__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double chol_draw(const double* img, int d, int lane, double hcol, double zc, bool& bad) {
+  double row[15];
+  const double* src = img + (lane < 16 ? lane : 0) * IL;
+#pragma unroll
+  for (int j = 0; j < 15; ++j) row[j] = src[j];
+  double th = hcol;
+#pragma unroll
+  for (int k = 0; k < 15; ++k)
+    if (k < d) {
+      const double akk = readlane_d(row[k], k);
+      const bool np = !(akk > 0.0);
+      bad |= np;
+      const double lkk = np ? 0.0 : sqrt(akk), inv = np ? 0.0 : 1.0 / lkk;
+      const double lik = (lane == k) ? lkk : row[k] * inv;      // L[lane][k] for lane >= k
+      th = fma((lane >= k) ? lik : 0.0, readlane_d(zc, k), th);
+#pragma unroll
+      for (int j = k + 1; j < 15; ++j)
+        if (j < d) row[j] = fma(-lik, readlane_d(lik, j), row[j]);
+    }
+  return th;
+}
+
 template <int K>
 __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __restrict__ sp) {
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16];
@@ -188,13 +219,12 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
       bst(rco, offM, t * recb, hcol);
     }
     to_img(H, img, g, c);
-    if (g == 0) zv[c] = vc ? zc : 0.0;
     wave_sync();
-    if (chol_rows(img, d, lane, true)) st |= DLM_ST_NOT_PD;
-    double v = hcol;
-    if (vc) for (int k = 0; k <= c; ++k) v = fma(img[c * IL + k], zv[k], v);
+    bool bad = false;
+    const double v = chol_draw(img, d, lane, hcol, vc ? zc : 0.0, bad);   // lanes 0..15 hold (h, z, theta)[lane]
+    if (bad) st |= DLM_ST_NOT_PD;
     wave_sync();
-    return vc ? v : 0.0;
+    return (vc && g == 0) ? v : 0.0;
   };
 
   {   // theta_T ~ N(m_T, C_T)
@@ -207,6 +237,15 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
     if (g == 0) thv[c] = th;
     if (thout && g == 0 && vc) thout[(size_t)T * d + c] = th;
     wave_sync();
+  }
+  // the record of the next step travels while this one is computed
+  d4 nC;
+  double nm;
+  {
+    const int tp = T > 0 ? T - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
+    nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
   }
   for (int t = T - 1; t >= 0; --t) {
     const double dt = a.dt ? a.dt[t] : 1.0;
@@ -222,10 +261,14 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
         ssy += (yv - f) * (yv - f); nob += 1.0;
       }
     }
-    d4 C;
+    const d4 C = nC;
+    const double mc = nm;
+    {
+      const int tp = t > 0 ? t - 1 : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) C[r] = bld(rin, offC[r], t * recb);
-    const double mc = bld(rin, vc ? c * 8 : OOB, t * recb);
+      for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
+      nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
+    }
     const double zc = vc ? (zin ? zin[(size_t)t * d + c] : philox_normal(a.seed, series, (unsigned)t, (unsigned)c)) : 0.0;
     if (a.w_tstride) {
 #pragma unroll
