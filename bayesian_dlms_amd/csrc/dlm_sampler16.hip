@@ -154,8 +154,11 @@ __device__ __forceinline__ double chol_draw(const double* img, int d, int lane, 
       const double akk = readlane_d(row[k], k);
       const bool np = !(akk > 0.0);
       bad |= np;
-      const double lkk = np ? 0.0 : sqrt(akk), inv = np ? 0.0 : 1.0 / lkk;
-      const double lik = (lane == k) ? lkk : row[k] * inv;      // L[lane][k] for lane >= k
+      double inv = __builtin_amdgcn_rsq(np ? 1.0 : akk);         // 1/sqrt by the hardware estimate and two Newton steps (about 1 ulp)
+      inv = inv * fma(-0.5 * akk * inv, inv, 1.5);
+      inv = inv * fma(-0.5 * akk * inv, inv, 1.5);
+      inv = np ? 0.0 : inv;
+      const double lik = row[k] * inv;                            // L[lane][k] for lane >= k (the pivot itself: akk / sqrt(akk))
       th = fma((lane >= k) ? lik : 0.0, readlane_d(zc, k), th);
 #pragma unroll
       for (int j = k + 1; j < 15; ++j)
@@ -166,10 +169,10 @@ __device__ __forceinline__ double chol_draw(const double* img, int d, int lane, 
 
 template <int K>
 __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __restrict__ sp) {
-  __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16];
+  __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16 + 64];
   double* img = lds;       double* inv = lds + IMG;
   double* mv = inv + IMG;  double* thv = mv + 16;   double* uv = thv + 16;   double* zv = uv + 16;
-  double* hv = zv + 16;    double* dfv = hv + 16;
+  double* hv = zv + 16;    double* dfv = hv + 16;   double* zq = mv + 8 * 16;   // zq: 64 normals, four records x 16 components
   const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
   const bool vc = c < d;
@@ -248,6 +251,13 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
     nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
   }
   for (int t = T - 1; t >= 0; --t) {
+    // the normals of records t, t-1, t-2, t-3 (16 components each) are drawn together, one per lane, every fourth step:
+    // the generator is the same few hundred instructions whether 13 lanes or 64 need a value
+    if (!zin && ((T - 1 - t) & 3) == 0) {
+      const int tr = t - g;
+      zq[lane] = (vc && tr >= 0) ? philox_normal(a.seed, series, (unsigned)tr, (unsigned)c) : 0.0;
+      wave_sync();
+    }
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
       for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
       nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
     }
-    const double zc = vc ? (zin ? zin[(size_t)t * d + c] : philox_normal(a.seed, series, (unsigned)t, (unsigned)c)) : 0.0;
+    const double zc = vc ? (zin ? zin[(size_t)t * d + c] : zq[16 * ((T - 1 - t) & 3) + c]) : 0.0;
     if (a.w_tstride) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wt[r] = va[r] ? (W0 + (size_t)t * a.w_tstride)[4 * r + g + c * d] : 0.0;
