@@ -11,7 +11,8 @@
 // reproduces.  What makes it fast: G C G^T, C G^T and J G are gathers through a wave-private LDS image (G has at most
 // four nonzeros per row and column), the five dense products are MFMA chains on registers, R+^-1 is a Newton-Schulz
 // refinement of the previous step's inverse (R+ changes slowly along a series; direct Cholesky inverse when the start
-// is too far off), and only the factor of H -- thirteen dependent pivots -- runs as a one-wave Cholesky in LDS.
+// is too far off), and the factor of H -- thirteen dependent pivots -- is taken in registers, lane i holding row i, with
+// pivots and multipliers broadcast by v_readlane (chol_draw).
 #include "dlm_internal.h"
 #include "../../include/dlm_engine.h"
 
