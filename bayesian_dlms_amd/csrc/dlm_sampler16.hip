@@ -143,12 +143,10 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
   const int hi = __builtin_amdgcn_readlane((int)__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double chol_draw(const double* img, int d, int lane, double hcol, double zc, bool& bad) {
-  double row[15];
+__device__ __forceinline__ void chol_factor(const double* img, int d, int lane, double (&row)[15], bool& bad) {
   const double* src = img + (lane < 16 ? lane : 0) * IL;
 #pragma unroll
   for (int j = 0; j < 15; ++j) row[j] = src[j];
-  double th = hcol;
 #pragma unroll
   for (int k = 0; k < 15; ++k)
     if (k < d) {
@@ -160,11 +158,18 @@ __device__ __forceinline__ double chol_draw(const double* img, int d, int lane, 
       inv = inv * fma(-0.5 * akk * inv, inv, 1.5);
       inv = np ? 0.0 : inv;
       const double lik = row[k] * inv;                            // L[lane][k] for lane >= k (the pivot itself: akk / sqrt(akk))
-      th = fma((lane >= k) ? lik : 0.0, readlane_d(zc, k), th);
+      row[k] = lik;
 #pragma unroll
       for (int j = k + 1; j < 15; ++j)
         if (j < d) row[j] = fma(-lik, readlane_d(lik, j), row[j]);
     }
+}
+// theta[lane] = h[lane] + sum_{k <= lane} L[lane][k] z[k]   (lanes 0..d-1)
+__device__ __forceinline__ double chol_draw(const double (&row)[15], int d, int lane, double hcol, double zc) {
+  double th = hcol;
+#pragma unroll
+  for (int k = 0; k < 15; ++k)
+    if (k < d) th = fma((lane >= k) ? row[k] : 0.0, readlane_d(zc, k), th);
   return th;
 }
 
@@ -216,19 +221,23 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
   bool warm = false;
 
   // theta = h + chol(H) z, with the conditional record; leaves theta in thv and returns this lane's component
-  auto emit = [&](int t, double hcol, const d4& H, double zc) {
+  // conditional record, then theta = h + L z with the factor rows L (lanes 0..15); leaves nothing in LDS
+  auto emit = [&](int t, double hcol, const d4& H, double zc, const double (&rows)[15]) {
     if (cond) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bst(rco, offC[r], t * recb, H[r]);
       bst(rco, offM, t * recb, hcol);
     }
+    const double v = chol_draw(rows, d, lane, hcol, vc ? zc : 0.0);
+    return (vc && g == 0) ? v : 0.0;
+  };
+  auto factor = [&](const d4& H, double (&rows)[15]) {
     to_img(H, img, g, c);
     wave_sync();
     bool bad = false;
-    const double v = chol_draw(img, d, lane, hcol, vc ? zc : 0.0, bad);   // lanes 0..15 hold (h, z, theta)[lane]
+    chol_factor(img, d, lane, rows, bad);
     if (bad) st |= DLM_ST_NOT_PD;
     wave_sync();
-    return (vc && g == 0) ? v : 0.0;
   };
 
   {   // theta_T ~ N(m_T, C_T)
@@ -237,11 +246,20 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
     for (int r = 0; r < 4; ++r) C[r] = bld(rin, offC[r], T * recb);
     const double mc = bld(rin, vc ? c * 8 : OOB, T * recb);
     const double zc = vc ? (zin ? zin[(size_t)T * d + c] : philox_normal(a.seed, series, (unsigned)T, (unsigned)c)) : 0.0;
-    const double th = emit(T, mc, C, zc);
+    double rows[15];
+    factor(C, rows);
+    const double th = emit(T, mc, C, zc, rows);
     if (g == 0) thv[c] = th;
     if (thout && g == 0 && vc) thout[(size_t)T * d + c] = th;
     wave_sync();
   }
+  d4 Cp = {0.0, 0.0, 0.0, 0.0}, JTs = Cp, Hs = Cp;   // steady-state reuse: the covariance, J^T, H and the factor of the last full step
+  double Ls[15];
+#pragma unroll
+  for (int j = 0; j < 15; ++j) Ls[j] = 0.0;
+  bool have = false;
+  int gprev = -1;
+  double dtprev = 0.0, cmaxp = 0.0;
   // the record of the next step travels while this one is computed
   d4 nC;
   double nm;
@@ -286,6 +304,31 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
       for (int r = 0; r < 4; ++r) Wt[r] = va[r] ? (W0 + (size_t)t * a.w_tstride)[4 * r + g + c * d] : 0.0;
     }
     if (g == 0) mv[c] = mc;
+    // Steady state: once the filtered covariance has stopped moving (a regular stretch without missing observations), J, H
+    // and its factor are those of the step before -- only a+, h and the draw are left to do.
+    bool reuse = false;
+    if (have && gi == gprev && dt == dtprev && !a.w_tstride) {
+      bool moved = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) moved |= !(fabs(C[r] - Cp[r]) <= 1e-13 * cmaxp);   // relative to the largest entry of C
+      reuse = __ballot(moved) == 0ull;
+    }
+    d4 JT, H;
+    double hcol;
+    if (reuse) {
+      wave_sync();
+      double a1 = mc;
+      if (dt != 0.0) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) s_ = fma(mv[ridx[s]], rval[s], s_);
+        a1 = s_;
+      }
+      JT = JTs; H = Hs;
+      if (g == 0) uv[c] = vc ? thv[c] - a1 : 0.0;
+      wave_sync();
+      hcol = mc + matTvec(JT, uv, g);
+    } else {
     to_img(C, img, g, c);
     wave_sync();
     // C G^T (pass 1), a+ and R+
@@ -352,10 +395,10 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
       if (!done && direct_inverse(R, Rinv, d, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
       warm = true;
     }
-    const d4 JT = mm(Rinv, GC, d);                    // J^T = R+^-1 G C
+    JT = mm(Rinv, GC, d);                             // J^T = R+^-1 G C
     if (g == 0) uv[c] = vc ? thv[c] - a1 : 0.0;
     wave_sync();
-    const double hcol = mc + matTvec(JT, uv, g);      // h = m + J (theta+ - a+)
+    hcol = mc + matTvec(JT, uv, g);                   // h = m + J (theta+ - a+)
     // J G by columns of G on the image of J (= J^T written transposed), Dm = I - J G
 #pragma unroll
     for (int r = 0; r < 4; ++r) img[c * IL + 4 * r + g] = JT[r];
@@ -372,7 +415,7 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
     wave_sync();
     const d4 DmT = transposed(Dm, img, g, c);
     const d4 CD = mm(C, DmT, d);                      // C Dm^T
-    d4 H = mm(DmT, CD, d);                            // Dm C Dm^T
+    H = mm(DmT, CD, d);                               // Dm C Dm^T
     const d4 WJ = mm(Wt, JT, d);                      // W J^T
     const d4 H2 = mm(JT, WJ, d);                      // J W J^T
 #pragma unroll
@@ -382,7 +425,15 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
 #pragma unroll
       for (int r = 0; r < 4; ++r) H[r] = (4 * r + g == c) ? H[r] : (H[r] + Ht[r]) / 2.0;
     }
-    const double th = emit(t, hcol, H, zc);
+    factor(H, Ls);
+    Cp = C; JTs = JT; Hs = H; have = true; gprev = gi; dtprev = dt;
+    {
+      double mx = fmax(fmax(fabs(C[0]), fabs(C[1])), fmax(fabs(C[2]), fabs(C[3])));
+      for (int o_ = 32; o_ > 0; o_ >>= 1) mx = fmax(mx, __shfl_xor(mx, o_));
+      cmaxp = mx;
+    }
+    }
+    const double th = emit(t, hcol, H, zc, Ls);
     if (a.stats) {   // system residual theta_{t+1} - G theta_t (always the table entry)
       if (g == 0) hv[c] = th;
       wave_sync();

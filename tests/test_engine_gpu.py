@@ -1504,3 +1504,26 @@ def test_small_multivariate_models_on_per_wave_kernels(eng, shape):
             st = oracle.gibbs_stats(om, y[n], ref, want_outer=True)
             np.testing.assert_allclose(dr["stats"][n, :q], st["ssy"], rtol=1e-7)
             np.testing.assert_allclose(dr["stats"][n, 2 * q:2 * q + d * d], st["outer"], rtol=1e-6, atol=1e-7)
+
+
+def test_reference_form_sampler_steady_state_reuse(eng):
+    """A long regular series without missing values: once the filtered covariance has stopped moving the register-tile sampler
+    reuses J, H and its factor (dlm_sampler16.hip); draws and conditional moments still equal the generic kernel's."""
+    mod, mat, p = seasonal_model(T=900)
+    y = simulate(mat, p, 3, seed=12)
+    y[1, 300:310, 0] = np.nan                      # a gap in one series: its covariance moves again, then settles
+    z = np.random.default_rng(5).standard_normal((3, 901, 13))
+    out = eng.ffbs(mat, p, y, z=z, want_cond=True)
+    assert eng.last_variant == "sparse16-sampler" and np.all(out["status"] == 0)
+    os.environ["DLM_NO_SAMPLER16"] = "1"
+    try:
+        gen = eng.ffbs(mat, p, y, z=z, want_cond=True)
+        assert eng.last_variant == "generic"
+    finally:
+        del os.environ["DLM_NO_SAMPLER16"]
+    np.testing.assert_allclose(out["theta"], gen["theta"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(out["cond"], gen["cond"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out["stats"], gen["stats"], rtol=1e-9)
+    # the covariance of the undisturbed series is stationary over the second half: the conditional covariances repeat
+    H = out["cond"][0][:, 13:]
+    assert np.abs(H[700] - H[500]).max() <= 1e-12 * np.abs(H[500]).max()
