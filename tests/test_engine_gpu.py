@@ -1527,3 +1527,34 @@ def test_reference_form_sampler_steady_state_reuse(eng):
     # the covariance of the undisturbed series is stationary over the second half: the conditional covariances repeat
     H = out["cond"][0][:, 13:]
     assert np.abs(H[700] - H[500]).max() <= 1e-12 * np.abs(H[500]).max()
+
+
+@pytest.mark.parametrize("shape", ["seasonal_d13", "linear_growth_d2", "multivariate_d20_p10"])
+def test_backward_sampling_from_existing_filter_records(eng, shape):
+    """dlm_backward_sample_batch (Smoothing.sampleDlm on a stored filter, Smoothing.scala:151-180): the same draws, conditional
+    moments and statistics as dlm_ffbs_batch, whichever sampler kernel the shape selects (register tiles, lanes, generic)."""
+    rng = np.random.default_rng({"seasonal_d13": 1, "linear_growth_d2": 2, "multivariate_d20_p10": 3}[shape])
+    if shape == "seasonal_d13":
+        mod, mat, p = seasonal_model(T=60); expect = "sparse16-sampler"
+    elif shape == "linear_growth_d2":
+        mat = materialise(Dlm.polynomial(2), np.cumsum(np.array([1, 2, 1, 1, 3] * 10, dtype=np.float64)))
+        p = DlmParameters([[1.3]], np.array([[0.5, 0.1], [0.1, 0.2]]), [0.0, 0.0], np.eye(2) * 4.0); expect = "lane-sampler"
+    else:
+        mod = Dlm.polynomial(2)
+        for _ in range(9):
+            mod = mod * Dlm.polynomial(2)
+        mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
+        A = rng.standard_normal((20, 20))
+        p = DlmParameters(np.eye(10) * 1.2, A @ A.T / 20 + 0.1 * np.eye(20), np.zeros(20), np.eye(20)); expect = "generic"
+    d, q, T = mat.d, mat.p, mat.T
+    y = rng.standard_normal((4, T, q)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    z = rng.standard_normal((4, T + 1, d))
+    full = eng.ffbs(mat, p, y, z=z, want_cond=True, flags=_lib.OPT_STATS_OUTER)
+    assert eng.last_variant == expect
+    filt = eng.filter(mat, p, y)["filt"]
+    again = eng.ffbs(mat, p, y, z=z, want_cond=True, flags=_lib.OPT_STATS_OUTER, filt=filt)
+    assert eng.last_variant == expect
+    np.testing.assert_allclose(again["theta"], full["theta"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(again["cond"], full["cond"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(again["stats"], full["stats"], rtol=1e-9, atol=1e-10)
