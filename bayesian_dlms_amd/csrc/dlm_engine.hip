@@ -635,6 +635,11 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     HIP_TRY(e, dlm::launch_sparse16_sampler(k, e->sparse_k, e->sp_dev, e->stream));
     return st.finish(opts->flags & DLM_OPT_ASYNC);
   }
+  if (!(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::wave48_small_ok(k) && !getenv("DLM_NO_SAMPLER16")) {
+    e->variant = "sparse16-sampler";
+    HIP_TRY(e, dlm::launch_small_mv_sampler(k, e->stream));
+    return st.finish(opts->flags & DLM_OPT_ASYNC);
+  }
   e->variant = "generic";
   HIP_TRY(e, dlm::launch_generic_sampler(k, e->stream));
   return st.finish(opts->flags & DLM_OPT_ASYNC);

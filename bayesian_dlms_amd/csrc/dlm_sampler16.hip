@@ -173,14 +173,16 @@ __device__ __forceinline__ double chol_draw(const double (&row)[15], int d, int 
   return th;
 }
 
-template <int K>
-__global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __restrict__ sp) {
+// Tab: SparseT (the d <= 15, p = 1 tables) or SparseBig (the tables of the multivariate paths); any p <= 64 -- the
+// observations only enter the statistics.
+template <int K, class Tab>
+__global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const Tab* __restrict__ sp) {
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16 + 64];
   double* img = lds;       double* inv = lds + IMG;
   double* mv = inv + IMG;  double* thv = mv + 16;   double* uv = thv + 16;   double* zv = uv + 16;
   double* hv = zv + 16;    double* dfv = hv + 16;   double* zq = mv + 8 * 16;   // zq: 64 normals, four records x 16 components
   const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-  const int d = a.d, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
   const bool vc = c < d;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
   for (int i = lane; i < 8 * 16; i += 64) mv[i] = 0.0;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
   double* cond = a.cond ? a.cond + (size_t)n * (T + 1) * rec : nullptr;
   const __amdgpu_buffer_rsrc_t rco = mk_rsrc(cond, cond ? (size_t)(T + 1) * recb : 0);
   double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
-  const double* y = a.y ? a.y + (size_t)n * T : nullptr;
+  const double* y = a.y ? a.y + (size_t)n * T * p : nullptr;
   const double* zin = a.z ? a.z + (size_t)n * (T + 1) * d : nullptr;
   const unsigned long long series = a.series_offset + (unsigned long long)n;
   int st = 0;
@@ -280,13 +282,12 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
-    const double Fc = vc ? (a.F + (size_t)t * a.f_stride)[c] : 0.0;
-    if (a.stats && y) {   // observation residual of theta_{t+1} (Gibbs.scala:29-39)
-      const double yv = y[t];
+    if (a.stats && y && lane < p) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
+      const double yv = y[(size_t)t * p + lane];
       if (yv == yv) {
-        double f = (g == 0) ? Fc * thv[c] : 0.0;
-        for (int o_ = 8; o_ > 0; o_ >>= 1) f += __shfl_xor(f, o_);
-        f = __shfl(f, 0);
+        const double* Fj = a.F + (size_t)t * a.f_stride + (size_t)lane * d;
+        double f = 0.0;
+        for (int k = 0; k < d; ++k) f = fma(Fj[k], thv[k], f);
         ssy += (yv - f) * (yv - f); nob += 1.0;
       }
     }
@@ -457,28 +458,33 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const SparseT* __r
   }
   if (__ballot(vc && !isfinite(thv[c])) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.stats) {
-    const int L = stats_len(d, 1, a.flags);
+    const int L = stats_len(d, p, a.flags);
     double* so = a.stats + (size_t)n * L;
-    if (lane == 0) { so[0] = ssy; so[1] = nob; so[L - 1] = (double)T; }
+    if (lane < p) { so[lane] = ssy; so[p + lane] = nob; }
+    if (lane == 0) so[L - 1] = (double)T;
     if (outer) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (va[r]) so[2 + 4 * r + g + c * d] = OUT[r];
-    } else if (g == 0 && vc) so[2 + c] = ssd;
+      for (int r = 0; r < 4; ++r) if (va[r]) so[2 * p + 4 * r + g + c * d] = OUT[r];
+    } else if (g == 0 && vc) so[2 * p + c] = ssd;
   }
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
 }  // namespace s16
 
-hipError_t launch_sparse16_sampler(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s) {
+template <class Tab>
+static hipError_t launch_sampler_t(const KArgs& a, int K, const Tab* tabs_dev, hipStream_t s) {
   switch (K) {
-    case 1: hipLaunchKernelGGL(s16::k_sampler_sp16<1>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 2: hipLaunchKernelGGL(s16::k_sampler_sp16<2>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 3: hipLaunchKernelGGL(s16::k_sampler_sp16<3>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 4: hipLaunchKernelGGL(s16::k_sampler_sp16<4>, dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 3: hipLaunchKernelGGL((s16::k_sampler_sp16<3, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 4: hipLaunchKernelGGL((s16::k_sampler_sp16<4, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
+hipError_t launch_sparse16_sampler(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s) { return launch_sampler_t(a, K, tabs_dev, s); }
+// d <= 15 with several observation components: the tables of the multivariate paths (a.spb, [2 gi] rows / [2 gi + 1] columns)
+hipError_t launch_small_mv_sampler(const KArgs& a, hipStream_t s) { return launch_sampler_t(a, a.spb_k, a.spb, s); }
 
 }  // namespace dlm

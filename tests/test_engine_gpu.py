@@ -1489,6 +1489,17 @@ def test_small_multivariate_models_on_per_wave_kernels(eng, shape):
     z = rng.standard_normal((N, T + 1, d + q))
     dr = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_STATS_OUTER)
     assert eng.last_variant == "wave-simsmooth" and np.all(dr["status"] == 0)
+    # the reference-form sampler on register tiles (dlm_sampler16.hip with the multivariate tables) against the generic kernel
+    zl = rng.standard_normal((N, T + 1, d))
+    lit = eng.ffbs(mat, p, y, z=zl, want_cond=True, flags=_lib.OPT_STATS_OUTER)
+    assert eng.last_variant == "sparse16-sampler"
+    gl = eng.ffbs(mat, p, y, z=zl, want_cond=True, flags=_lib.OPT_STATS_OUTER | _lib.OPT_FORCE_GENERIC)
+    assert eng.last_variant == "generic"
+    np.testing.assert_array_equal(lit["status"], gl["status"])
+    if mat.dt is None:
+        np.testing.assert_allclose(lit["theta"], gl["theta"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(lit["cond"], gl["cond"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(lit["stats"], gl["stats"], rtol=1e-8, atol=1e-9)
     om = omodel(mat)
     for n in range(N):
         f, s = oracle_filter_smooth(mat, p, y[n])
