@@ -39,15 +39,21 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, "dlm_internal.h"), os.path.join(HERE, "..", "include", "dlm_engine.h")]
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    todo = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FILE_FLAGS.get(src, FLAGS) + ["-c", s, "-o", o]
+            todo.append([HIPCC] + FILE_FLAGS.get(src, FLAGS) + ["-c", s, "-o", o])
+    if todo:   # the translation units are independent: compile them side by side (the largest takes about two minutes)
+        from concurrent.futures import ThreadPoolExecutor
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(todo), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(run, todo))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:
