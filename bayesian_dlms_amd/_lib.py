@@ -15,6 +15,13 @@ OPT_FORCE_GENERIC = 1 << 3
 OPT_STATS_OUTER = 1 << 4
 OPT_ASYNC = 1 << 5
 OPT_FFBS_SIMSMOOTH = 1 << 6
+OPT_PACKED_SYM = 1 << 7
+OPT_NO_LANE = 1 << 16
+OPT_NO_SAMPLER16 = 1 << 17
+OPT_NO_WAVE = 1 << 18
+OPT_FORCE_WAVE = 1 << 19
+OPT_NO_SPARSE_F = 1 << 20
+OPT_NO_SMALL_BATCH = 1 << 21
 ST_NONFINITE, ST_NOT_PD, ST_NOCONV = 1, 2, 4
 COMM_ID_BYTES = 128
 
@@ -53,6 +60,16 @@ SYMBOLS = [
     ("dlm_engine_set_stream", ctypes.c_int, [_V, _V]),
     ("dlm_engine_sync", ctypes.c_int, [_V]),
     ("dlm_last_variant", ctypes.c_char_p, [_V]),
+    ("dlm_engine_wait_stream", ctypes.c_int, [_V, _V]),
+    ("dlm_stream_wait_engine", ctypes.c_int, [_V, _V]),
+    ("dlm_buffer_alloc", ctypes.c_int, [_V, ctypes.c_uint64, ctypes.POINTER(_V)]),
+    ("dlm_buffer_free", ctypes.c_int, [_V, _V]),
+    ("dlm_buffer_upload", ctypes.c_int, [_V, _V, ctypes.c_uint64, _V, ctypes.c_uint64]),
+    ("dlm_buffer_download", ctypes.c_int, [_V, _V, ctypes.c_uint64, _V, ctypes.c_uint64]),
+    ("dlm_buffer_fill", ctypes.c_int, [_V, _V, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64]),
+    ("dlm_device_mem_info", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("dlm_packed_record_doubles", ctypes.c_int32, [ctypes.c_int32]),
+    ("dlm_unpack_records", ctypes.c_int, [_V, ctypes.c_int32, ctypes.c_int64, _V, _OP, _V]),
     ("dlm_filter_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V, _V, _V]),
     ("dlm_loglik_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V]),
     ("dlm_simulate_batch", ctypes.c_int, [_V, _MP, _PP, _OP, _V, _V, _V]),

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -39,6 +40,8 @@ struct dlm_engine {
   size_t ystar_bytes = 0;
   ncclComm_t comm = nullptr;
   bool has_comm = false;
+  std::set<void*> buffers;     // dlm_buffer_alloc allocations still owned by the caller (released at destroy)
+  hipEvent_t order_ev = nullptr;   // dlm_engine_wait_stream / dlm_stream_wait_engine
 };
 
 namespace {
@@ -150,8 +153,8 @@ void stage_model(Stager& st, KArgs& k, const dlm_model_desc* m, const dlm_params
 bool fast_shape_ok(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::fast_shape(k); }
 // d <= 15, p = 1 fast path: the structured kernels take any time grid, the dense-G MFMA kernels a regular one
 bool use_fast(const dlm_engine* e, const KArgs& k) { return fast_shape_ok(k) && (e->sparse_k > 0 || dlm::mfma16_supported(k)); }
-// d <= 3, p = 1 and thousands of series: one lane per series (DLM_NO_LANE in the environment: A/B measurements)
-bool use_lane(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::lane_supported(k) && !getenv("DLM_NO_LANE"); }
+// d <= 5, p = 1: one lane per series (DLM_OPT_NO_LANE: A/B measurements)
+bool use_lane(const KArgs& k) { return !(k.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_LANE)) && dlm::lane_supported(k); }
 // the d >= 16 kernels, or -- d <= 15 with several observation components and a structured G -- the per-wave kernels
 bool use_tiled(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && (dlm::tiled_supported(k) || dlm::wave48_small_ok(k)); }
 bool tiled_analysis_wanted(const KArgs& k) { return !(k.flags & DLM_OPT_FORCE_GENERIC) && (dlm::tiled_supported(k) || dlm::wave48_small_shape(k)); }
@@ -318,6 +321,20 @@ int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
   return DLM_OK;
 }
 
+// packed [m | lower triangle by rows] -> dense [m | C column-major]; one thread per dense element
+__global__ void k_unpack_records(int d, long long count, int prec, const double* __restrict__ packed, double* __restrict__ dense) {
+  const int rec = d + d * d;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count * rec) return;
+  const long long r = i / rec;
+  const int e = (int)(i - r * rec);
+  const double* src = packed + r * prec;
+  if (e < d) { dense[i] = src[e]; return; }
+  const int a = (e - d) % d, b = (e - d) / d;           // element (row a, column b) of C
+  const int hi = a > b ? a : b, lo = a > b ? b : a;
+  dense[i] = src[d + hi * (hi + 1) / 2 + lo];
+}
+
 }  // namespace
 
 extern "C" {
@@ -337,6 +354,7 @@ int dlm_engine_create(int device, dlm_engine** out) {
   }
   e->stream = e->own_stream;
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
+  (void)hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming);
   *out = e;
   return DLM_OK;
 }
@@ -353,6 +371,8 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->fws) (void)hipFree(e->fws);
   if (e->spb_dev) (void)hipFree(e->spb_dev);
   if (e->spf_dev) (void)hipFree(e->spf_dev);
+  for (void* b : e->buffers) (void)hipFree(b);
+  if (e->order_ev) (void)hipEventDestroy(e->order_ev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -373,6 +393,88 @@ int dlm_engine_sync(dlm_engine* e) {
   return DLM_OK;
 }
 
+int dlm_engine_wait_stream(dlm_engine* e, void* hip_stream) {
+  if (!e) return DLM_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  if ((hipStream_t)hip_stream == e->stream) return DLM_OK;
+  HIP_TRY(e, hipEventRecord(e->order_ev, (hipStream_t)hip_stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->order_ev, 0));
+  return DLM_OK;
+}
+
+int dlm_stream_wait_engine(dlm_engine* e, void* hip_stream) {
+  if (!e) return DLM_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  if ((hipStream_t)hip_stream == e->stream) return DLM_OK;
+  HIP_TRY(e, hipEventRecord(e->order_ev, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent((hipStream_t)hip_stream, e->order_ev, 0));
+  return DLM_OK;
+}
+
+int dlm_buffer_alloc(dlm_engine* e, uint64_t bytes, void** dev_ptr) {
+  if (!e) return DLM_ERR_ARG;
+  if (!dev_ptr || bytes == 0) return fail(e, DLM_ERR_ARG, "dlm_buffer_alloc: dev_ptr and a non-zero size are required");
+  *dev_ptr = nullptr;
+  HIP_TRY(e, hipSetDevice(e->device));
+  void* p = nullptr;
+  HIP_TRY(e, hipMalloc(&p, (size_t)bytes));
+  e->buffers.insert(p);
+  *dev_ptr = p;
+  return DLM_OK;
+}
+
+int dlm_buffer_free(dlm_engine* e, void* dev_ptr) {
+  if (!e) return DLM_ERR_ARG;
+  if (!dev_ptr) return DLM_OK;
+  auto it = e->buffers.find(dev_ptr);
+  if (it == e->buffers.end()) return fail(e, DLM_ERR_ARG, "dlm_buffer_free: not a buffer of this engine");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));   // no engine work may still use it
+  HIP_TRY(e, hipFree(dev_ptr));
+  e->buffers.erase(it);
+  return DLM_OK;
+}
+
+int dlm_buffer_upload(dlm_engine* e, void* dst_dev, uint64_t dst_offset, const void* src_host, uint64_t bytes) {
+  if (!e) return DLM_ERR_ARG;
+  if (!dst_dev || (!src_host && bytes)) return fail(e, DLM_ERR_ARG, "dlm_buffer_upload: null pointer");
+  if (!bytes) return DLM_OK;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpyAsync((char*)dst_dev + dst_offset, src_host, (size_t)bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return DLM_OK;
+}
+
+int dlm_buffer_download(dlm_engine* e, const void* src_dev, uint64_t src_offset, void* dst_host, uint64_t bytes) {
+  if (!e) return DLM_ERR_ARG;
+  if (!src_dev || (!dst_host && bytes)) return fail(e, DLM_ERR_ARG, "dlm_buffer_download: null pointer");
+  if (!bytes) return DLM_OK;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpyAsync(dst_host, (const char*)src_dev + src_offset, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return DLM_OK;
+}
+
+int dlm_buffer_fill(dlm_engine* e, void* dst_dev, uint64_t dst_offset, int byte_value, uint64_t bytes) {
+  if (!e) return DLM_ERR_ARG;
+  if (!dst_dev) return fail(e, DLM_ERR_ARG, "dlm_buffer_fill: null pointer");
+  if (!bytes) return DLM_OK;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemsetAsync((char*)dst_dev + dst_offset, byte_value, (size_t)bytes, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return DLM_OK;
+}
+
+int dlm_device_mem_info(dlm_engine* e, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!e) return DLM_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  size_t f = 0, t = 0;
+  HIP_TRY(e, hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return DLM_OK;
+}
+
 int dlm_last_timing(dlm_engine* e, double ms[2]) {
   if (!e || !ms) return DLM_ERR_ARG;
   if (!e->timed) return fail(e, DLM_ERR_ARG, "no fused call has been timed yet");
@@ -385,6 +487,26 @@ int dlm_last_timing(dlm_engine* e, double ms[2]) {
 }
 
 int32_t dlm_stats_len(int32_t d, int32_t p, uint32_t flags) { return dlm::stats_len(d, p, flags); }
+
+int32_t dlm_packed_record_doubles(int32_t d) { return d < 1 ? 0 : dlm::packed_rec_bytes(d) / 8; }
+
+int dlm_unpack_records(dlm_engine* e, int32_t d, int64_t count, const double* packed, const dlm_options* opts, double* dense) {
+  if (!e) return DLM_ERR_ARG;
+  if (!opts || (opts->mem != DLM_MEM_DEVICE && opts->mem != DLM_MEM_HOST)) return fail(e, DLM_ERR_ARG, "opts");
+  if (d < 1 || d > 64 || count < 1 || !packed || !dense) return fail(e, DLM_ERR_ARG, "dlm_unpack_records arguments");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t prec = (size_t)dlm_packed_record_doubles(d), rec = (size_t)d + (size_t)d * d;
+  const double* src = nullptr; double* dst = nullptr;
+  Stager st(e, opts->mem == DLM_MEM_HOST);
+  st.in(&src, packed, (size_t)count * prec);
+  st.out(&dst, dense, (size_t)count * rec);
+  int rc = st.commit();
+  if (rc) return rc;
+  const long long total = (long long)count * (long long)rec;
+  hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, (int)d, (long long)count, (int)prec, src, dst);
+  HIP_TRY(e, hipGetLastError());
+  return st.finish(opts->flags & DLM_OPT_ASYNC);
+}
 
 int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
                      const double* y, const dlm_options* opts, double* filt, double* prior,
@@ -630,12 +752,12 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     HIP_TRY(e, dlm::launch_lane_sampler(k, e->stream));
     return st.finish(opts->flags & DLM_OPT_ASYNC);
   }
-  if (fast_shape_ok(k) && e->sparse_k > 0 && !getenv("DLM_NO_SAMPLER16")) {
+  if (fast_shape_ok(k) && e->sparse_k > 0 && !(k.flags & DLM_OPT_NO_SAMPLER16)) {
     e->variant = "sparse16-sampler";
     HIP_TRY(e, dlm::launch_sparse16_sampler(k, e->sparse_k, e->sp_dev, e->stream));
     return st.finish(opts->flags & DLM_OPT_ASYNC);
   }
-  if (!(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::wave48_small_ok(k) && !getenv("DLM_NO_SAMPLER16")) {
+  if (!(k.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16)) && dlm::wave48_small_ok(k)) {
     e->variant = "sparse16-sampler";
     HIP_TRY(e, dlm::launch_small_mv_sampler(k, e->stream));
     return st.finish(opts->flags & DLM_OPT_ASYNC);

@@ -1494,11 +1494,11 @@ bool wave48_small_shape(const KArgs& a) {
   return a.d >= 1 && a.d <= 15 && a.p >= 2 && a.p <= 32 && ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);
 }
 static bool wave48_wanted(const KArgs& a) {
-  if (getenv("DLM_NO_WAVE48")) return false;
-  return wave48_small_shape(a) || a.N > 256 || getenv("DLM_FORCE_WAVE48");
+  if (a.flags & DLM_OPT_NO_WAVE) return false;
+  return wave48_small_shape(a) || a.N > 256 || (a.flags & DLM_OPT_FORCE_WAVE);
 }
 static bool shape_ok(const KArgs& a) { return tiled_supported(a) || wave48_small_shape(a); }
-bool wave48_small_ok(const KArgs& a) { return wave48_small_shape(a) && a.spb && !getenv("DLM_NO_WAVE48"); }
+bool wave48_small_ok(const KArgs& a) { return wave48_small_shape(a) && a.spb && !(a.flags & DLM_OPT_NO_WAVE); }
 bool wave48_filter_supported(const KArgs& a) {
   return shape_ok(a) && a.spb && wave48_wanted(a);
 }
@@ -1506,7 +1506,7 @@ bool wave48_filter_supported(const KArgs& a) {
 template <int DT, int PT>
 static hipError_t launch_w48_filter_k(const KArgs& a, int K, double* innov, int zero_m0, hipStream_t s) {
   const size_t lds = sizeof(double) * w48::lds_doubles(DT, PT);
-  const int kf = (a.spf && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
+  const int kf = (a.spf && !(a.flags & DLM_OPT_NO_SPARSE_F)) ? a.spf_k : 0;   // 0: dense (or time-varying) F
   if (K <= 2) {
     if (kf == 1) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
     else if (kf > 1) hipLaunchKernelGGL((w48::k_filter_w48<DT, PT, 2, 4>), dim3(a.N), dim3(64), lds, s, a, innov, zero_m0);
@@ -1523,7 +1523,7 @@ bool wave48_smoother_supported(const KArgs& a) { return shape_ok(a) && a.spb && 
 template <int DT, int PT>
 static hipError_t launch_w48_smoother_k(const KArgs& a, int K, const double* innov, hipStream_t s) {
   const size_t lds = sizeof(double) * w48::lds_doubles(DT, PT);
-  const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
+  const int kf = (a.spf && !a.f_stride && !(a.flags & DLM_OPT_NO_SPARSE_F)) ? a.spf_k : 0;   // 0: dense (or time-varying) F
   if (K <= 2) {
     if (kf == 1) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, innov);
     else if (kf > 1) hipLaunchKernelGGL((w48::k_smoother_w48<DT, PT, 2, 4>), dim3(a.N), dim3(64), lds, s, a, innov);
@@ -1566,7 +1566,7 @@ bool wave48_simsmooth_supported(const KArgs& a) {
 template <int DT, int PT>
 static hipError_t launch_w48_sims_k(const KArgs& a, int K, const double* xplus, const double* innov, hipStream_t s) {
   const size_t lds = sizeof(double) * w48::lds_doubles(DT, PT);
-  const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;   // 0: dense (or time-varying) F
+  const int kf = (a.spf && !a.f_stride && !(a.flags & DLM_OPT_NO_SPARSE_F)) ? a.spf_k : 0;   // 0: dense (or time-varying) F
   if (K <= 2) {
     if (kf == 1) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
     else if (kf > 1) hipLaunchKernelGGL((w48::k_simsmooth_w48<DT, PT, 2, 4>), dim3(a.N), dim3(64), lds, s, a, xplus, innov);
@@ -1580,7 +1580,7 @@ static hipError_t launch_w48_sims_k(const KArgs& a, int K, const double* xplus, 
 
 hipError_t launch_wave48_simsmooth(const KArgs& a, int K, double* xplus, double* ystar, hipStream_t s) {
   {
-    const int kf = (a.spf && !a.f_stride && !getenv("DLM_NO_SPARSE_F")) ? a.spf_k : 0;
+    const int kf = (a.spf && !a.f_stride && !(a.flags & DLM_OPT_NO_SPARSE_F)) ? a.spf_k : 0;
     const size_t lds = sizeof(double) * (48 * 49 + 32 * 33 + (kf ? 0 : w48::FIMG) + 48 + 48 + 96);
     if (K <= 2) {
       if (kf == 1) hipLaunchKernelGGL((w48::k_sim_prologue_w48<2, 1>), dim3(a.N), dim3(64), lds, s, a, xplus, ystar);

@@ -128,11 +128,54 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.dlm_engine_sync(self.h))
+        self._keep.clear()
 
     def _backend(self, y):
         if isinstance(y, np.ndarray) or y is None:
             return _Host()
-        return _Device(self.device)
+        be = _Device(self.device)
+        # Device mode takes torch tensors that were produced (or whose memory was last used) on torch's current stream,
+        # while the engine launches on its own: order the engine's stream behind it (an event, no host wait).  The other
+        # direction needs nothing for synchronous calls (the engine stream is drained on return); after DLM_OPT_ASYNC
+        # calls sync() -- or stream_wait_engine() -- before torch touches the outputs.
+        self._check(self.lib.dlm_engine_wait_stream(self.h, ctypes.c_void_p(be.torch.cuda.current_stream(be.device).cuda_stream or 0)))
+        return be
+
+    def stream_wait_engine(self, stream_ptr: Optional[int] = None):
+        """Make `stream_ptr` (default: torch's current stream) wait for the engine work submitted so far."""
+        if stream_ptr is None:
+            import torch
+            stream_ptr = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.dlm_stream_wait_engine(self.h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def _hold(self, flags, *objs):
+        """Under DLM_OPT_ASYNC the kernels may still be reading the staged model / parameter tables and the inputs when
+        the call returns: keep them alive until sync()."""
+        if flags & _lib.OPT_ASYNC:
+            self._keep.append(objs)
+
+    # -- engine-owned device buffers (what a caller without torch uses; also exercised by the tests) ----------------
+    def buffer_alloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._check(self.lib.dlm_buffer_alloc(self.h, int(nbytes), ctypes.byref(p)))
+        return int(p.value)
+
+    def buffer_free(self, ptr: int):
+        self._check(self.lib.dlm_buffer_free(self.h, ctypes.c_void_p(ptr)))
+
+    def buffer_upload(self, ptr: int, a: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(a)
+        self._check(self.lib.dlm_buffer_upload(self.h, ctypes.c_void_p(ptr), int(offset), ctypes.c_void_p(a.ctypes.data), a.nbytes))
+
+    def buffer_download(self, ptr: int, out: np.ndarray, offset: int = 0):
+        assert out.flags["C_CONTIGUOUS"]
+        self._check(self.lib.dlm_buffer_download(self.h, ctypes.c_void_p(ptr), int(offset), ctypes.c_void_p(out.ctypes.data), out.nbytes))
+        return out
+
+    def mem_info(self):
+        f, t = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.lib.dlm_device_mem_info(self.h, ctypes.byref(f), ctypes.byref(t)))
+        return int(f.value), int(t.value)
 
     def prepare(self, mat: MaterialisedModel, params, N: int, be, flags=0, seed=0, series_offset=0):
         """Build the descriptors; returns (model, params, opts, keepalive list)."""
@@ -162,6 +205,7 @@ class Engine:
             P = lambda name: (base + offs[name]) if name in offs else None
             md = _lib.ModelDesc(mat.d, mat.p, mat.T, N, P("F"), mat.f_stride, P("G"), mat.n_g, P("gi"), P("dt"))
             pd = _lib.ParamsDesc(P("V"), vs, P("W"), ws, P("m0"), m0s, P("C0"), c0s, vts, wts)
+            self._hold(flags, bufs)
             return md, pd, _lib.Options(flags, be.mem, seed, series_offset), bufs
         bufs = {name: be.put(a, dt) for name, (a, dt) in items.items()}
         P = lambda a: (be.ptr(a).value if a is not None else None)
@@ -169,6 +213,7 @@ class Engine:
                             P(bufs["gi"]), P(bufs["dt"]))
         pd = _lib.ParamsDesc(P(bufs["V"]), vs, P(bufs["W"]), ws, P(bufs["m0"]), m0s, P(bufs["C0"]), c0s, vts, wts)
         op = _lib.Options(flags, be.mem, seed, series_offset)
+        self._hold(flags, bufs)
         return md, pd, op, bufs
 
     # -- entry points --------------------------------------------------------------
@@ -178,6 +223,7 @@ class Engine:
         rec = d + d * d
         yb = be.put(y).reshape(N, T, p)
         md, pd, op, keep = self.prepare(mat, params, N, be, flags)
+        self._hold(flags, yb)
         filt = be.empty((N, T + 1, rec))
         prior = be.empty((N, T + 1, rec)) if want_prior else None
         fq = be.empty((N, T + 1, p + p * p)) if want_fq else None
@@ -267,6 +313,7 @@ class Engine:
         N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
         yb = be.put(y).reshape(N, T, p)
         md, pd, op, keep = self.prepare(mat, params, N, be, flags)
+        self._hold(flags, yb)
         filt = (out["filt"] if out else be.empty((N, T + 1, d + d * d))) if want_filt else None
         smooth = out["smooth"] if out else be.empty((N, T + 1, d + d * d))
         status = out["status"] if out else be.empty((N,), np.int32)
@@ -289,6 +336,7 @@ class Engine:
         yb = be.put(y).reshape(N, T, p)
         zb = be.put(z)
         md, pd, op, keep = self.prepare(mat, params, N, be, flags, seed, series_offset)
+        self._hold(flags, yb, zb)
         theta = be.empty((N, T + 1, d)) if want_theta else None
         cond = be.empty((N, T + 1, rec)) if want_cond else None
         L = self.lib.dlm_stats_len(d, p, flags & ~_lib.OPT_FFBS_SIMSMOOTH)

@@ -51,7 +51,16 @@ enum {
   DLM_OPT_FORCE_GENERIC = 1u << 3,      /* disable the specialised (MFMA) kernels           */
   DLM_OPT_STATS_OUTER = 1u << 4,        /* Gibbs stats: full outer product (GibbsWishart)   */
   DLM_OPT_ASYNC = 1u << 5,              /* do not synchronise the stream before returning   */
-  DLM_OPT_FFBS_SIMSMOOTH = 1u << 6      /* draw with the Durbin-Koopman simulation smoother */
+  DLM_OPT_FFBS_SIMSMOOTH = 1u << 6,     /* draw with the Durbin-Koopman simulation smoother */
+  DLM_OPT_PACKED_SYM = 1u << 7,         /* state records leave PACKED: [mean (d) | lower triangle of the covariance by rows],
+                                           dlm_packed_record_doubles(d) doubles per record (see below)              */
+  /* Kernel-selection overrides: measurements and tests only, results do not depend on them.           */
+  DLM_OPT_NO_LANE = 1u << 16,           /* no lane-per-series kernels (d <= 5, p = 1)                                  */
+  DLM_OPT_NO_SAMPLER16 = 1u << 17,      /* no register-tile backward sampler: the generic kernel                       */
+  DLM_OPT_NO_WAVE = 1u << 18,           /* 16 <= d <= 48: the workgroup-per-series kernels instead of wave-per-series  */
+  DLM_OPT_FORCE_WAVE = 1u << 19,        /* 16 <= d <= 48: wave-per-series kernels also for batches of <= 256 series    */
+  DLM_OPT_NO_SPARSE_F = 1u << 20,       /* treat F as dense                                                            */
+  DLM_OPT_NO_SMALL_BATCH = 1u << 21     /* d <= 15: the throughput kernels also for batches that leave SIMDs idle      */
 };
 
 /* per-series status bits */
@@ -107,6 +116,41 @@ int dlm_engine_set_stream(dlm_engine *e, void *hip_stream);
 int dlm_engine_sync(dlm_engine *e);
 /* Name of the kernel variant the last call dispatched to ("generic", "mfma16", ...). */
 const char *dlm_last_variant(const dlm_engine *e);
+
+/* ---- ordering against the caller's streams ------------------------------------------
+ * The engine launches on its own stream.  A caller that produces inputs (or frees / reuses buffers) on another
+ * HIP stream orders the two with events, without a host synchronisation:
+ *   dlm_engine_wait_stream   work submitted to `hip_stream` so far completes before any later engine work starts;
+ *   dlm_stream_wait_engine   engine work submitted so far completes before later work on `hip_stream` starts
+ *                            (needed only after DLM_OPT_ASYNC calls: synchronous calls have drained the engine stream).
+ * hip_stream == NULL means the legacy default stream (what `torch.cuda.current_stream()` is unless changed). */
+int dlm_engine_wait_stream(dlm_engine *e, void *hip_stream);
+int dlm_stream_wait_engine(dlm_engine *e, void *hip_stream);
+
+/* ---- engine-owned device buffers ------------------------------------------------------
+ * For callers without a device allocator of their own (the JVM through JNI, plain C / C++): allocate once, keep
+ * inputs and results in HBM across calls (opts->mem = DLM_MEM_DEVICE, the measured path) and move only what is
+ * needed.  A buffer is an ordinary HIP device pointer (arithmetic on it is allowed: base + offset is what the
+ * descriptors take).  Upload / download are synchronous on return and ordered after all engine work submitted
+ * before them; offsets and sizes in bytes.  Buffers still allocated are released by dlm_engine_destroy. */
+int dlm_buffer_alloc(dlm_engine *e, uint64_t bytes, void **dev_ptr);
+int dlm_buffer_free(dlm_engine *e, void *dev_ptr);
+int dlm_buffer_upload(dlm_engine *e, void *dst_dev, uint64_t dst_offset, const void *src_host, uint64_t bytes);
+int dlm_buffer_download(dlm_engine *e, const void *src_dev, uint64_t src_offset, void *dst_host, uint64_t bytes);
+int dlm_buffer_fill(dlm_engine *e, void *dst_dev, uint64_t dst_offset, int byte_value, uint64_t bytes);
+int dlm_device_mem_info(dlm_engine *e, uint64_t *free_bytes, uint64_t *total_bytes);
+
+/* ---- packed symmetric records (DLM_OPT_PACKED_SYM) --------------------------------------
+ * A packed state record is [mean (d) | C(0,0) | C(1,0) C(1,1) | C(2,0) ... C(d-1,d-1)] -- the lower triangle by
+ * rows -- padded with zeros to an even number of doubles: dlm_packed_record_doubles(d) = d + d (d + 1) / 2 rounded
+ * up to even (104 at d = 13 against 182 dense).  With the flag, dlm_filter_batch (filt, prior), dlm_smooth_batch
+ * (filt in, smooth out) and dlm_filter_smooth_batch (filt, smooth) read and write packed records; algorithmic
+ * traffic of the fused pass drops from 8p + 24 (d + d^2) to 8p + 24 (d + d (d + 1) / 2) bytes per series-step
+ * (2504 instead of 4376 at d = 13).  dlm_unpack_records expands [count] packed records into dense ones
+ * (host or device memory according to opts->mem). */
+int32_t dlm_packed_record_doubles(int32_t d);
+int dlm_unpack_records(dlm_engine *e, int32_t d, int64_t count, const double *packed, const dlm_options *opts,
+                       double *dense);
 
 /* ---- Kalman filter ----------------------------------------------------------------
  * Replaces KalmanFilter(KalmanFilter.advanceState(p, mod.g)).filter(mod, ys, p)
