@@ -2,7 +2,13 @@
 //   1. KalmanFilterTest table (core/src/test/scala/KalmanFilter.scala:78-189), tol 1e-4
 //   2. first_order_dlm golden CSVs (examples/src/main/scala/dlm/FirstOrderDlm.scala:52-77,237-255)
 //   3. seasonal d = 13 batch: filterDlm drops the initial state, smoothed == filtered at T
+//   4. the same golden CSVs through the DEVICE-RESIDENT path (engine-owned buffers, records fetched on demand)
+//   5. a C2-sized batch (10 000 series x T = 1000, d = 13) device-resident: 29 GB of records never leave HBM; spot checks
+//      against the host-mode path, throughput printed (the number a caller without its own device allocator gets)
+//   6. Smoothing.backwardsSmoother on .filter's states, SvdFilter.filterDlm (U D^2 U^T == C), SvdSampler.ffbsDlm
+//   7. GibbsSampling.sample / sampleSvd and GibbsWishart.sample chains
 // usage: host_api_check <tests/golden dir>; prints "HOST API OK" and returns 0 on success.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,6 +96,136 @@ int main(int argc, char** argv) {
     auto th2 = Smoothing::ffbsDlm(eng, mod, ys, p, 42);
     expect(th.size() == 3 && th[0].size() == 51 && th[0][0].sample.size() == 13, "ffbs shapes");
     expect(th[1][7].sample == th2[1][7].sample, "draws are a pure function of the seed");
+  }
+  {  // 4. config C1 through the device-resident path
+    auto obs = read_csv(golden + "/first_order_dlm.csv");
+    auto fr = read_csv(golden + "/first_order_dlm_filtered.csv");
+    auto sr = read_csv(golden + "/first_order_dlm_smoothed.csv");
+    std::vector<Data> ys;
+    for (auto& r : obs) ys.push_back(Data{r[0], {r[1]}});
+    DlmParameters p{Matrix::diag({2.0}), Matrix::diag({3.0}), {0.0}, Matrix::diag({10.0})};
+    DeviceSeries dys(eng, Dlm::polynomial(1), {ys});
+    DeviceParameters dp(eng, p);
+    DeviceFilterSmooth r = Smoothing::filterSmooth(dys, dp);
+    auto filt = r.filtered.series(0), sm = r.smoothed.series(0);
+    double ef = 0, es = 0;
+    for (size_t t = 0; t < 1001; ++t) {
+      ef = std::max(ef, std::fabs(filt[t].mt[0] - fr[t][1])); ef = std::max(ef, std::fabs(filt[t].ct(0, 0) - fr[t][2]));
+      es = std::max(es, std::fabs(sm[t].mt[0] - sr[t][1])); es = std::max(es, std::fabs(sm[t].ct(0, 0) - sr[t][2]));
+    }
+    std::printf("device-resident first_order_dlm: max |filtered - golden| = %.3g, max |smoothed - golden| = %.3g\n", ef, es);
+    expect(ef < 1e-11 && es < 1e-10 && r.status[0] == 0, "golden CSVs reproduced device-resident");
+    KfState one = r.smoothed.at(0, 500);
+    expect(one.time == 500.0 && one.mt[0] == sm[500].mt[0], "single-record fetch");
+    const double ll = KalmanFilter::logLikelihood(dys, dp)[0], llh = KalmanFilter::logLikelihood(eng, Dlm::polynomial(1), {ys}, p)[0];
+    expect(ll == llh, "device-resident log-likelihood equals the host-mode one");
+  }
+  {  // 5. C2-sized batch, device-resident
+    uint64_t freeb = 0, total = 0;
+    eng.check(dlm_device_mem_info(eng.get(), &freeb, &total));
+    const int N = 10000, T = 1000, d = 13;
+    const size_t need = 2 * (size_t)N * (T + 1) * (d + d * d) * 8 + ((size_t)1 << 30);
+    if (freeb < need) std::printf("SKIP C2-sized device-resident run: %.1f GB free, %.1f GB needed\n", freeb / 1e9, need / 1e9);
+    else {
+      Dlm mod = Dlm::polynomial(1).compose(Dlm::seasonal(24, 6));
+      DlmParameters p{Matrix::diag({1.0}), Matrix::diag({0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4}),
+                      std::vector<double>(13, 0.0), Matrix::eye(13)};
+      std::vector<double> times(T), y((size_t)N * T);
+      for (int t = 0; t < T; ++t) times[t] = t + 1.0;
+      std::mt19937_64 rng(0xD1A5EED0ull); std::normal_distribution<double> nrm;
+      for (int n = 0; n < N; ++n) { double level = nrm(rng); for (int t = 0; t < T; ++t) { level += 0.1 * nrm(rng); y[(size_t)n * T + t] = level + std::sin(2.0 * M_PI * (t + n) / 24.0) + nrm(rng); } }
+      for (int n : {3, 4999}) for (int t = 100; t < 110; ++t) y[(size_t)n * T + t] = std::numeric_limits<double>::quiet_NaN();   // a gap in two series
+      DeviceSeries dys(eng, mod, times, y.data(), N);
+      DeviceParameters dp(eng, p);
+      DeviceFilterSmooth r = Smoothing::filterSmooth(dys, dp);
+      const std::string variant = eng.lastVariant();
+      int bad = 0; for (int s : r.status) bad += s != 0;
+      expect(bad == 0, "C2-sized batch: status clean");
+      double best = 1e30, fwd = 0, bwd = 0;
+      for (int it = 0; it < 5; ++it) {
+        const auto t0 = std::chrono::steady_clock::now();
+        Smoothing::filterSmoothInto(dys, dp, r);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms < best) { best = ms; fwd = r.forwardMs; bwd = r.backwardMs; }
+      }
+      std::printf("C2 device-resident from C++ (%s): %d x %d, d = %d: best %.3f ms per fused call (kernels %.3f + %.3f ms) = %.4g series*steps/s; %.1f GB of records in HBM\n",
+                  variant.c_str(), N, T, d, best, fwd, bwd, (double)N * T / (best * 1e-3), (r.filtered.bytes() + r.smoothed.bytes()) / 1e9);
+      // spot checks against the host-mode path on the same observations
+      for (int n : {0, 3, 4999, 9999}) {
+        std::vector<Data> one;
+        for (int t = 0; t < T; ++t) { const double v = y[(size_t)n * T + t]; one.push_back(Data{times[t], {std::isnan(v) ? std::nullopt : std::optional<double>(v)}}); }
+        std::vector<std::vector<KfState>> hf;
+        auto hs = Smoothing::filterSmooth(eng, mod, {one}, p, &hf)[0];
+        auto df = r.filtered.series(n), ds = r.smoothed.series(n);
+        double e1 = 0, e2 = 0;
+        for (int t = 0; t <= T; ++t) for (int i = 0; i < d; ++i) {
+          e1 = std::max(e1, std::fabs(df[t].mt[i] - hf[0][t].mt[i])); e2 = std::max(e2, std::fabs(ds[t].mt[i] - hs[t].mean[i]));
+          for (int j = 0; j < d; ++j) { e1 = std::max(e1, std::fabs(df[t].ct(i, j) - hf[0][t].ct(i, j))); e2 = std::max(e2, std::fabs(ds[t].ct(i, j) - hs[t].covariance(i, j))); }
+        }
+        expect(e1 < 1e-12 && e2 < 1e-11, "C2-sized batch: device-resident records equal the host-mode ones");
+        double dl = 0; for (int i = 0; i < d; ++i) dl = std::max(dl, std::fabs(ds[T].mt[i] - df[T].mt[i]));
+        expect(dl < 1e-12, "C2-sized batch: smoothed state at T equals the filtered state");
+      }
+    }
+  }
+  {  // 6. backwardsSmoother on .filter's states; SVD filter and sampler
+    Dlm mod = Dlm::polynomial(1).compose(Dlm::seasonal(24, 6));
+    DlmParameters p{Matrix::diag({1.0}), Matrix::diag({0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4}),
+                    std::vector<double>(13, 0.0), Matrix::eye(13)};
+    std::vector<std::vector<Data>> ys(2);
+    for (int n = 0; n < 2; ++n) for (int t = 1; t <= 60; ++t) ys[n].push_back(Data{(double)t, {std::cos(0.2 * t + n)}});
+    auto kf = KalmanFilter::filter(eng, mod, ys, p);
+    auto sm = Smoothing::backwardsSmoother(eng, mod, kf, p);
+    auto fused = Smoothing::filterSmooth(eng, mod, ys, p);
+    double e = 0;
+    for (int n = 0; n < 2; ++n) for (int t = 0; t <= 60; ++t) for (int i = 0; i < 13; ++i) {
+      e = std::max(e, std::fabs(sm[n][t].mean[i] - fused[n][t].mean[i]));
+      for (int j = 0; j < 13; ++j) e = std::max(e, std::fabs(sm[n][t].covariance(i, j) - fused[n][t].covariance(i, j)));
+    }
+    std::printf("backwardsSmoother (RTS from records) vs fused information-form pass: max diff %.3g\n", e);
+    expect(e < 1e-8, "backwardsSmoother on .filter's states equals the fused call");
+    auto q1 = Smoothing::backwardsSmoother(eng, mod, kf, p, DLM_OPT_SMOOTHER_COMPAT_Q1);   // literal J X J: means unchanged
+    double em = 0, ec = 0;
+    for (int t = 0; t <= 60; ++t) for (int i = 0; i < 13; ++i) { em = std::max(em, std::fabs(q1[0][t].mean[i] - sm[0][t].mean[i])); ec = std::max(ec, std::fabs(q1[0][t].covariance(i, (i + 1) % 13) - sm[0][t].covariance(i, (i + 1) % 13))); }
+    expect(em < 1e-9 && ec > 1e-6, "Q1 switch: same means, different covariances at d = 13");
+    // SvdFilterTest (core/src/test/scala/SvdFilter.scala:102-158): U D^2 U^T equals the Kalman filter's C
+    Dlm biv = Dlm::polynomial(1).outer(Dlm::polynomial(1));
+    DlmParameters pb{Matrix::diag({3.0, 3.0}), Matrix::diag({1.0, 1.0}), {0.0, 0.0}, Matrix::diag({1.0, 1.0})};
+    std::vector<Data> data = {{1.0, {4.5, 4.5}}, {2.0, {3.0, 3.0}}, {3.0, {6.3, 6.3}}, {4.0, {std::nullopt, std::nullopt}}, {5.0, {10.1, std::nullopt}}, {7.0, {15.2, 15.2}}};
+    auto kfb = KalmanFilter::filterDlm(eng, biv, {data}, pb)[0];
+    auto svb = SvdFilter::filterDlm(eng, biv, {data}, pb)[0];
+    double es = 0;
+    for (size_t t = 0; t < data.size(); ++t) for (int i = 0; i < 2; ++i) {
+      es = std::max(es, std::fabs(svb[t].mt[i] - kfb[t].mt[i]));
+      for (int j = 0; j < 2; ++j) { double c = 0; for (int k = 0; k < 2; ++k) c += svb[t].uc(i, k) * svb[t].dc[k] * svb[t].dc[k] * svb[t].uc(j, k); es = std::max(es, std::fabs(c - kfb[t].ct(i, j))); }
+    }
+    expect(svb.size() == data.size() && es < 1e-6, "SVD filter equals the Kalman filter (means and U D^2 U^T)");
+    auto ths = SvdSampler::ffbsDlm(eng, biv, {data}, pb, 7);
+    expect(ths[0].size() == data.size() + 1 && std::isfinite(ths[0][3].sample[1]), "SvdSampler.ffbsDlm shapes");
+  }
+  {  // 7. Gibbs chains on device-resident series (local level, V = 2, W = 3 as in FirstOrderDlm.scala)
+    const int N = 4, T = 300;
+    std::mt19937_64 rng(11); std::normal_distribution<double> nrm;
+    std::vector<double> times(T), y((size_t)N * T);
+    for (int t = 0; t < T; ++t) times[t] = t + 1.0;
+    for (int n = 0; n < N; ++n) { double x = 0; for (int t = 0; t < T; ++t) { x += std::sqrt(3.0) * nrm(rng); y[(size_t)n * T + t] = x + std::sqrt(2.0) * nrm(rng); } }
+    DeviceSeries dys(eng, Dlm::polynomial(1), times, y.data(), N);
+    DlmParameters init{Matrix::diag({1.0}), Matrix::diag({1.0}), {0.0}, Matrix::diag({10.0})};
+    for (int kind = 0; kind < 3; ++kind) {
+      InverseWishart iw{3.0, Matrix::diag({3.0})};
+      GibbsSampling::Chain chain = kind == 0 ? GibbsSampling::sample(InverseGamma{4.0, 6.0}, InverseGamma{4.0, 9.0}, init, dys, 5)
+                                 : kind == 1 ? GibbsSampling::sampleSvd(InverseGamma{4.0, 6.0}, InverseGamma{4.0, 9.0}, init, dys, 5)
+                                             : GibbsWishart::sample(InverseGamma{4.0, 6.0}, iw, init, dys, 5);
+      double mv = 0, mw = 0; int cnt = 0; bool ok = true;
+      for (int it = 0; it < 150; ++it) {
+        const GibbsSampling::State& s = chain.next();
+        for (int n = 0; n < N; ++n) { const double v = s.p[n].v(0, 0), w = s.p[n].w(0, 0); ok = ok && std::isfinite(v) && std::isfinite(w) && v > 0 && w > 0; if (it >= 50) { mv += v; mw += w; ++cnt; } }
+      }
+      mv /= cnt; mw /= cnt;
+      std::printf("Gibbs kind %d: posterior means V = %.3f (truth 2), W = %.3f (truth 3)\n", kind, mv, mw);
+      expect(ok && mv > 1.0 && mv < 3.5 && mw > 1.5 && mw < 5.0, "Gibbs chain: finite, positive, posterior means near the simulation truth");
+      expect(chain.theta(1).size() == (size_t)T + 1, "Gibbs chain: state draw available");
+    }
   }
   try {  // empty input is an error, as in the reference (t0.get on None)
     KalmanFilter::filterDlm(eng, Dlm::polynomial(1), {}, DlmParameters{Matrix::diag({1.0}), Matrix::diag({1.0}), {0.0}, Matrix::diag({1.0})});

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
+from bayesian_dlms_amd import _lib
 from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
 
 pytestmark = pytest.mark.gpu
@@ -39,7 +40,8 @@ def _properties(eng, mat, p, y, pick, expect_variant, tol_f, tol_s):
     S = sm[:64, :, d:].reshape(64, T1, d, d)
     assert float((S - S.transpose(-1, -2)).abs().max()) <= 1e-9 * float(S.abs().max())
     # (i) independence: the picked series on their own, bit for bit
-    sub = eng.filter_smooth(mat, p, y[pick])
+    # the same kernels as the full batch: a handful of series alone would take the workgroup-per-series kernels at d >= 16
+    sub = eng.filter_smooth(mat, p, y[pick], flags=_lib.OPT_FORCE_WAVE)
     assert torch.equal(sub["filt"], filt[pick]) and torch.equal(sub["smooth"], sm[pick])
     # (iv) oracle at full length
     for n in pick[:2]:
