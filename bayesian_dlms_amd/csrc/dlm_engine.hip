@@ -231,6 +231,13 @@ int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   return DLM_OK;
 }
 
+// HIP events around the forward (0 -> 1) and backward (1 -> 2) part of a call, read back by dlm_last_timing
+int mark(dlm_engine* e, int i) {
+  HIP_TRY(e, hipEventRecord(e->ev[i], e->stream));
+  if (i == 2) e->timed = true;
+  return DLM_OK;
+}
+
 int ensure_fws(dlm_engine* e, size_t need) {
   if (need > e->fws_bytes) {
     if (e->fws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->fws)); e->fws = nullptr; e->fws_bytes = 0; }
@@ -267,6 +274,14 @@ int ensure_ystar(dlm_engine* e, const KArgs& k) {
     HIP_TRY(e, hipMalloc((void**)&e->ystar, need));
     e->ystar_bytes = need;
   }
+  return DLM_OK;
+}
+
+// DLM_OPT_PACKED_SYM is served by the structured d <= 15, p = 1 kernels (the lane kernels step aside for it)
+int packed_path(dlm_engine* e, KArgs& k) {
+  k.flags |= DLM_OPT_NO_LANE;
+  if (!(fast_shape_ok(k) && e->sparse_k > 0) || (k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1))
+    return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_PACKED_SYM needs the structured d <= 15, p = 1 path (time-invariant F, <= 4 nonzeros per row and column of G) without DLM_OPT_FORCE_GENERIC / DLM_OPT_SMOOTHER_COMPAT_Q1; use dense records otherwise");
   return DLM_OK;
 }
 
@@ -477,7 +492,7 @@ int dlm_device_mem_info(dlm_engine* e, uint64_t* free_bytes, uint64_t* total_byt
 
 int dlm_last_timing(dlm_engine* e, double ms[2]) {
   if (!e || !ms) return DLM_ERR_ARG;
-  if (!e->timed) return fail(e, DLM_ERR_ARG, "no fused call has been timed yet");
+  if (!e->timed) return fail(e, DLM_ERR_ARG, "no forward / backward call has been timed yet");
   float f = 0.f, b = 0.f;
   HIP_TRY(e, hipEventSynchronize(e->ev[2]));
   HIP_TRY(e, hipEventElapsedTime(&f, e->ev[0], e->ev[1]));
@@ -515,16 +530,22 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   if (rc) return rc;
   if (!y || !filt) return fail(e, DLM_ERR_ARG, "y and filt are required");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, rec = d + d * d;
+  const bool want_packed = (opts->flags & DLM_OPT_PACKED_SYM) != 0;
+  if (want_packed && prior) return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_PACKED_SYM: prior records are not available packed");
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
   st.in(&k.y, y, N * T * p);
-  st.out(&k.filt, filt, N * (T + 1) * rec);
+  st.out(&k.filt, filt, N * (T + 1) * (want_packed ? (size_t)dlm_packed_record_doubles((int)d) : rec));
   st.out(&k.prior, prior, N * (T + 1) * rec);
   st.out(&k.fq, fq, N * (T + 1) * (p + p * p));
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
+  if (want_packed) {
+    if ((rc = packed_path(e, k))) return rc;
+    k.packed = 1;
+  }
   if ((rc = run_filter(e, k, false))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
@@ -644,6 +665,7 @@ int dlm_smooth_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
   if (!filt || !smooth) return fail(e, DLM_ERR_ARG, "filt and smooth are required");
+  if (opts->flags & DLM_OPT_PACKED_SYM) return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_PACKED_SYM: packed records are read by the fused call only (dlm_filter_smooth_batch); dlm_smooth_batch takes dense records (dlm_unpack_records)");
   const size_t d = model->d, T = model->T, N = model->N, rec = d + d * d;
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);
@@ -667,25 +689,28 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
+  const bool want_packed = (opts->flags & DLM_OPT_PACKED_SYM) != 0;
+  const size_t orec = want_packed ? (size_t)dlm_packed_record_doubles((int)d) : rec;
   st.in(&k.y, y, N * T * p);
-  st.out(&k.filt, filt, filt ? N * (T + 1) * rec : 0);
-  st.out(&k.smooth, smooth, N * (T + 1) * rec);
+  st.out(&k.filt, filt, filt ? N * (T + 1) * orec : 0);
+  st.out(&k.smooth, smooth, N * (T + 1) * orec);
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
+  if (want_packed && (rc = packed_path(e, k))) return rc;
   const bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
+  if (want_packed) k.packed = 3;   // filtered and smoothed records both leave packed
   if (!filt) {   // smoothed moments only: the filtered records stay in an engine workspace, packed on the structured path
-    k.packed = (fast_smoother_ok(e, k) && e->sparse_k > 0 && !use_lane(k)) ? 1 : 0;
-    if ((rc = ensure_fws(e, k.packed ? N * (T + 1) * (size_t)dlm::packed_rec_bytes((int)d) : N * (T + 1) * rec * sizeof(double)))) return rc;
+    k.packed |= (fast_smoother_ok(e, k) && e->sparse_k > 0 && !use_lane(k)) ? 1 : 0;
+    if ((rc = ensure_fws(e, (k.packed & 1) ? N * (T + 1) * (size_t)dlm::packed_rec_bytes((int)d) : N * (T + 1) * rec * sizeof(double)))) return rc;
     k.filt = e->fws;
   }
-  HIP_TRY(e, hipEventRecord(e->ev[0], e->stream));
+  if ((rc = mark(e, 0))) return rc;
   if ((rc = run_filter(e, k, fused_fast))) return rc;
-  HIP_TRY(e, hipEventRecord(e->ev[1], e->stream));
+  if ((rc = mark(e, 1))) return rc;
   k.filt_in = k.filt;
   if ((rc = run_smoother(e, k, fused_fast))) return rc;
-  HIP_TRY(e, hipEventRecord(e->ev[2], e->stream));
-  e->timed = true;
+  if ((rc = mark(e, 2))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
@@ -719,10 +744,12 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if ((rc = st.commit())) return rc;
   if (forward) {
     if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
+    if ((rc = mark(e, 0))) return rc;
     if (simflag && use_lane(k) && !k.v_tstride) {
       if ((rc = ensure_xplus(e, k))) return rc;
       e->variant = "lane-simsmooth";
       HIP_TRY(e, dlm::launch_lane_simsmooth(k, e->xplus, e->stream));
+      if ((rc = mark(e, 1)) || (rc = mark(e, 2))) return rc;
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
     if (simflag && e->sparse_k) {
@@ -730,8 +757,10 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       if ((rc = ensure_side(e, k)) || (rc = ensure_xplus(e, k))) return rc;
       e->variant = "sparse16-simsmooth";
       HIP_TRY(e, dlm::launch_sparse16_filter(k, e->sparse_k, e->sp_dev, e->side, e->xplus, e->stream));
+      if ((rc = mark(e, 1))) return rc;
       k.filt_in = k.filt;
       HIP_TRY(e, dlm::launch_sparse16_simsmooth(k, e->sparse_k, e->sp_dev, e->side, e->xplus, e->stream));
+      if ((rc = mark(e, 2))) return rc;
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
     if (simflag && k.v_tstride)
@@ -740,31 +769,34 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       if ((rc = ensure_xplus(e, k)) || (rc = ensure_ystar(e, k))) return rc;
       e->variant = dlm::wave48_simsmooth_supported(k) ? "wave-simsmooth" : "tiled-simsmooth";
       HIP_TRY(e, dlm::launch_tiled_simsmooth(k, e->xplus, e->ystar, e->stream));
+      if ((rc = mark(e, 1)) || (rc = mark(e, 2))) return rc;
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
     if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need a fast path (structured d <= 15 or 16 <= d <= 48)");
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }
-  if (!forward && (rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;   // the structure tables of G
+  if (!forward && ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST)) || (rc = mark(e, 0)))) return rc;   // the structure tables of G
+  if ((rc = mark(e, 1))) return rc;
+  auto done = [&]() { const int r = mark(e, 2); return r ? r : st.finish(opts->flags & DLM_OPT_ASYNC); };
   if (use_lane(k)) {
     e->variant = "lane-sampler";
     HIP_TRY(e, dlm::launch_lane_sampler(k, e->stream));
-    return st.finish(opts->flags & DLM_OPT_ASYNC);
+    return done();
   }
   if (fast_shape_ok(k) && e->sparse_k > 0 && !(k.flags & DLM_OPT_NO_SAMPLER16)) {
     e->variant = "sparse16-sampler";
     HIP_TRY(e, dlm::launch_sparse16_sampler(k, e->sparse_k, e->sp_dev, e->stream));
-    return st.finish(opts->flags & DLM_OPT_ASYNC);
+    return done();
   }
   if (!(k.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16)) && dlm::wave48_small_ok(k)) {
     e->variant = "sparse16-sampler";
     HIP_TRY(e, dlm::launch_small_mv_sampler(k, e->stream));
-    return st.finish(opts->flags & DLM_OPT_ASYNC);
+    return done();
   }
   e->variant = "generic";
   HIP_TRY(e, dlm::launch_generic_sampler(k, e->stream));
-  return st.finish(opts->flags & DLM_OPT_ASYNC);
+  return done();
 }
 
 int dlm_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
@@ -798,7 +830,9 @@ int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   e->variant = "svd-jacobi";
+  if ((rc = mark(e, 0))) return rc;
   HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
+  if ((rc = mark(e, 1)) || (rc = mark(e, 2))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 
@@ -822,8 +856,11 @@ int dlm_svd_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_par
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   e->variant = "svd-jacobi";
+  if ((rc = mark(e, 0))) return rc;
   HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
+  if ((rc = mark(e, 1))) return rc;
   HIP_TRY(e, dlm::launch_svd_sampler(k, rec_dev, e->stream));
+  if ((rc = mark(e, 2))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 

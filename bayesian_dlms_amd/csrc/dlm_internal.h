@@ -27,7 +27,8 @@ struct KArgs {
   double* stats;
   double* loglik;      // [N] prediction-error log-likelihood (nullable); with it, filt may be null (nothing stored)
   int* status;
-  int packed;          // structured d <= 15 fast path only: filt / filt_in hold PACKED records (engine-internal workspace)
+  int packed;          // structured d <= 15 fast path only.  bit 0: filt / filt_in hold PACKED records (engine-internal workspace,
+                       // or DLM_OPT_PACKED_SYM); bit 1: the smoothed records are written packed too (DLM_OPT_PACKED_SYM)
   const struct SparseBig* spb;   // tiled path: [2 n_g] row / column tables of a structured G, or nullptr (dense G)
   int spb_k;           // largest nonzero count per row / column over those tables (1..4)
   const struct SparseF* spf;     // structured (time-invariant) F of the tiled path: column / row tables, or nullptr

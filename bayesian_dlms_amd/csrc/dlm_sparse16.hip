@@ -549,11 +549,12 @@ __global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const 
 
   const double V = a.V[(size_t)n * a.v_stride];
   double rV = 1.0 / V;   // 1 / V_t of the record's observation when time-varying (IRR instantiation)
-  const int recb = rec * 8;                                       // smoothed records (output): always dense
-  const int rinb = a.packed ? packed_rec_bytes(d) : recb;         // filtered records (input): packed when engine-internal
+  const bool pout = (a.packed & 2) != 0;                          // smoothed records (output): packed with DLM_OPT_PACKED_SYM, dense otherwise
+  const int recb = pout ? packed_rec_bytes(d) : rec * 8;
+  const int rinb = (a.packed & 1) ? packed_rec_bytes(d) : rec * 8; // filtered records (input): packed when engine-internal or DLM_OPT_PACKED_SYM
   const char* bin = (const char*)a.filt_in + (size_t)n * (T + 1) * rinb;
-  char* bout = (char*)(a.smooth + (size_t)n * (T + 1) * rec);
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * rec * 8);
+  char* bout = (char*)a.smooth + (size_t)n * (T + 1) * recb;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * recb);
   const double* sd = side + (size_t)n * (T + 1) * 2;
 
   int idx[K];
@@ -571,9 +572,10 @@ __global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const 
     const int i = 4 * r + g;
     Fr[r] = i < d ? a.F[i] : 0.0;
     va[r] = i < d && (vc || col15);
-    offA[r] = i < d ? (vc ? (d + i * d + c) * 8 : (col15 ? i * 8 : OOB)) : OOB;
-    if (a.packed) { const int hi = i > c ? i : c, lo = i > c ? c : i; ldsA[r] = va[r] ? (vc ? (d + hi * (hi + 1) / 2 + lo) * 8 : i * 8) : rinb; }
-    else ldsA[r] = va[r] ? offA[r] : rinb;
+    const int offD = i < d ? (vc ? (d + i * d + c) * 8 : (col15 ? i * 8 : OOB)) : OOB;   // dense record
+    offA[r] = !pout ? offD : (i < d ? ((vc && c <= i) ? (d + i * (i + 1) / 2 + c) * 8 : (col15 ? i * 8 : OOB)) : OOB);
+    if (a.packed & 1) { const int hi = i > c ? i : c, lo = i > c ? c : i; ldsA[r] = va[r] ? (vc ? (d + hi * (hi + 1) / 2 + lo) * 8 : i * 8) : rinb; }
+    else ldsA[r] = va[r] ? offD : rinb;
   }
   d4 P = {0.0, 0.0, 0.0, 0.0};
   double qcol = 0.0;
@@ -960,7 +962,7 @@ static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* sid
 }
 template <int K>
 static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
-  const size_t ring = (size_t)4 * 2 * ((a.packed ? packed_rec_bytes(a.d) : (a.d + a.d * a.d) * 8) + 16);   // dynamic LDS: DMA ring, 2 slots per wave
+  const size_t ring = (size_t)4 * 2 * (((a.packed & 1) ? packed_rec_bytes(a.d) : (a.d + a.d * a.d) * 8) + 16);   // dynamic LDS: DMA ring, 2 slots per wave
   if (a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
   return hipGetLastError();

@@ -224,7 +224,7 @@ class Engine:
         yb = be.put(y).reshape(N, T, p)
         md, pd, op, keep = self.prepare(mat, params, N, be, flags)
         self._hold(flags, yb)
-        filt = be.empty((N, T + 1, rec))
+        filt = be.empty((N, T + 1, self.lib.dlm_packed_record_doubles(d) if flags & _lib.OPT_PACKED_SYM else rec))
         prior = be.empty((N, T + 1, rec)) if want_prior else None
         fq = be.empty((N, T + 1, p + p * p)) if want_fq else None
         status = be.empty((N,), np.int32)
@@ -308,18 +308,30 @@ class Engine:
 
     def filter_smooth(self, mat, params, y, *, flags=0, out=None, want_filt=True):
         """Fused filter + smoother.  want_filt=False keeps the filtered records inside the engine (packed on the
-        structured fast path) and returns only the smoothed moments."""
+        structured fast path) and returns only the smoothed moments.  flags & OPT_PACKED_SYM: both outputs are packed
+        records [mean | lower triangle by rows] (dlm_packed_record_doubles(d) doubles; unpack_records expands them)."""
         be = self._backend(y)
         N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
+        recw = self.lib.dlm_packed_record_doubles(d) if flags & _lib.OPT_PACKED_SYM else d + d * d
         yb = be.put(y).reshape(N, T, p)
         md, pd, op, keep = self.prepare(mat, params, N, be, flags)
         self._hold(flags, yb)
-        filt = (out["filt"] if out else be.empty((N, T + 1, d + d * d))) if want_filt else None
-        smooth = out["smooth"] if out else be.empty((N, T + 1, d + d * d))
+        filt = (out["filt"] if out else be.empty((N, T + 1, recw))) if want_filt else None
+        smooth = out["smooth"] if out else be.empty((N, T + 1, recw))
         status = out["status"] if out else be.empty((N,), np.int32)
         self._check(self.lib.dlm_filter_smooth_batch(self.h, md, pd, be.ptr(yb), op, be.ptr(filt),
                                                      be.ptr(smooth), be.ptr(status)))
         return {"filt": filt, "smooth": smooth, "status": status}
+
+    def unpack_records(self, d, packed):
+        """Packed records [..., dlm_packed_record_doubles(d)] -> dense [..., d + d*d] (dlm_unpack_records)."""
+        be = self._backend(packed)
+        pb = be.put(packed)
+        count = int(np.prod(pb.shape[:-1]))
+        dense = be.empty(tuple(pb.shape[:-1]) + (d + d * d,))
+        op = _lib.Options(0, be.mem, 0, 0)
+        self._check(self.lib.dlm_unpack_records(self.h, int(d), count, be.ptr(pb), op, be.ptr(dense)))
+        return dense
 
     def last_timing(self):
         """(forward_ms, backward_ms) of the last fused call, from HIP events on the engine stream."""

@@ -106,19 +106,34 @@ class GibbsSampling:
                *, n_iter: int, seed: int = 0, pooled: bool = False, series_offset: int = 0,
                allreduce: Optional[Callable[[np.ndarray], np.ndarray]] = None,
                keep_theta: bool = False, ffbs: Optional[Callable] = None,
-               simulation_smoother: bool = True) -> Iterator[GibbsState]:
-        """d-Inverse-Gamma Gibbs (GibbsSampling.sample).  `y` is this rank's shard [N][T][p];
-        `series_offset` its first global series index (keeps the Philox streams identical to a
-        single-GPU run).  Yields one GibbsState per iteration.
-        simulation_smoother (default): the state draw of every iteration is the Durbin-Koopman simulation smoother, which
-        every fast path has (20x the literal backward sampler at d = 13) and which samples the same conditional
-        distribution; False reproduces the reference's operation sequence (Smoothing.ffbsDlm) on the generic kernels."""
+               simulation_smoother: bool = False) -> Iterator[GibbsState]:
+        """d-Inverse-Gamma Gibbs (GibbsSampling.sample, Gibbs.scala:165-180).  `y` is this rank's shard [N][T][p] (numpy:
+        host mode; a torch device tensor: everything stays in HBM); `series_offset` its first global series index (keeps
+        the Philox streams identical to a single-GPU run).  Yields one GibbsState per iteration.
+        Default: the reference's operation sequence -- forward filter, then the backward sampler of Smoothing.step
+        (register-tile kernels for structured d <= 15 and lanes for d <= 5, the generic kernel elsewhere).
+        simulation_smoother=True draws the states with the Durbin-Koopman simulation smoother instead: the same
+        conditional distribution without a factorisation per step (4x faster at C3), not the reference's construction."""
         return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
                       series_offset, allreduce, keep_theta, ffbs, wishart=False, simsmooth=simulation_smoother)
 
+    @staticmethod
+    def sample_svd(mod: Dlm, prior_v: InverseGamma, prior_w: InverseGamma, init_params, times, y, engine,
+                   *, n_iter: int, seed: int = 0, pooled: bool = False, series_offset: int = 0,
+                   allreduce: Optional[Callable] = None, keep_theta: bool = False, literal: bool = False) -> Iterator[GibbsState]:
+        """GibbsSampling.sampleSvd / stepSvd (Gibbs.scala:182-217): the same conjugate updates with the state draw from
+        the SVD filter and SvdSampler (dlm_svd_ffbs_batch, statistics accumulated on the device).  literal=True runs
+        the reference's arithmetic: raw W in the time update and sqrt(W) in the sampler (Q9)."""
+        quirks = (_lib.OPT_SVD_RAW_W_Q2 | _lib.OPT_SVD_SAMPLER_Q9) if literal else 0
+
+        def run(mat, params, yy, seed, series_offset, flags, want_theta, want_stats):
+            return engine.svd_ffbs(mat, params, yy, seed=seed, series_offset=series_offset, flags=flags | quirks, want_stats=want_stats)
+        return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
+                      series_offset, allreduce, keep_theta, run, wishart=False, simsmooth=False)
+
 
 def gibbs_dinvgamma_device(mod: Dlm, prior_v: InverseGamma, prior_w: InverseGamma, init_params: DlmParameters, times, y,
-                           engine, *, n_iter: int, seed: int = 0, series_offset: int = 0, simulation_smoother: bool = True,
+                           engine, *, n_iter: int, seed: int = 0, series_offset: int = 0, simulation_smoother: bool = False,
                            on_iteration: Optional[Callable] = None):
     """Per-series d-Inverse-Gamma Gibbs that never leaves the GPU: FFBS + statistics (dlm_ffbs_batch) and the conjugate
     draws (dlm_dinvgamma_step_batch) alternate on device-resident parameter arrays; nothing crosses PCIe per iteration.
@@ -151,7 +166,7 @@ class GibbsWishart:
     def sample(mod: Dlm, prior_v: InverseGamma, prior_w: InverseWishart, init_params, times, y, engine,
                *, n_iter: int, seed: int = 0, pooled: bool = False, series_offset: int = 0,
                allreduce=None, keep_theta: bool = False, ffbs=None,
-               simulation_smoother: bool = True) -> Iterator[GibbsState]:
+               simulation_smoother: bool = False) -> Iterator[GibbsState]:
         """Inverse-Wishart Gibbs for W (GibbsWishart.sample; order theta, W, V as wishartStep)."""
         return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
                       series_offset, allreduce, keep_theta, ffbs, wishart=True, simsmooth=simulation_smoother)
@@ -159,7 +174,9 @@ class GibbsWishart:
 
 def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled, series_offset,
            allreduce, keep_theta, ffbs, wishart, simsmooth=False):
-    y = np.asarray(y, dtype=np.float64)
+    on_device = hasattr(y, "data_ptr")          # a torch device tensor: statistics are pooled and reduced in HBM
+    if not on_device:
+        y = np.asarray(y, dtype=np.float64)
     N = y.shape[0]
     mat = materialise(mod, times)
     d, p = mat.d, mat.p
@@ -170,11 +187,13 @@ def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, p
     for it in range(n_iter):
         out = run(mat, params, y, seed=seed * 1000003 + it, series_offset=series_offset, flags=flags,
                   want_theta=keep_theta, want_stats=True)
-        stats = np.asarray(out["stats"])
+        stats = out["stats"] if on_device else np.asarray(out["stats"])
         if pooled:
-            tot = stats.sum(axis=0) if engine is None else np.asarray(engine.stats_pool(stats))
+            # sum over the series of this shard (dlm_stats_pool), then over the ranks: the only collective on the path
+            tot = stats.sum(axis=0) if engine is None else engine.stats_pool(stats)
             if allreduce is not None:
                 tot = allreduce(tot)
+            tot = tot.cpu().numpy() if hasattr(tot, "cpu") else np.asarray(tot)
             ssy, n, body, tcount = split_stats(tot, d, p, wishart)
             base = _params_list(params, 1)[0]
             if wishart:
@@ -186,7 +205,7 @@ def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, p
         else:
             # independent V, W per series; the draws of series n use a generator keyed by its
             # GLOBAL index so that sharding does not change them
-            ssy, n, body, tcount = split_stats(stats, d, p, wishart)
+            ssy, n, body, tcount = split_stats(stats.cpu().numpy() if on_device else stats, d, p, wishart)
             old = _params_list(params, N)
             new = []
             for k in range(N):
@@ -199,4 +218,4 @@ def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, p
                     w = np.diag(draw_w_diag(prior_w, body[k], tcount[k], r))
                 new.append(DlmParameters(v, w, old[k].m0, old[k].c0))
             params = new
-        yield GibbsState(params, np.asarray(out["theta"]) if keep_theta else None, stats)
+        yield GibbsState(params, (out["theta"] if on_device else np.asarray(out["theta"])) if keep_theta else None, stats)

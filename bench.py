@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Kalman filter + smoother throughput (series*timesteps / second).
+"""Benchmark of the hot path through the C ABI.  Headline (default): Kalman filter + smoother throughput,
+series*timesteps / second, on BASELINE.json configs[1] (SURVEY.md 8d "C2"): seasonal DLM `polynomial(1) |+|
+seasonal(24, 6)` (d = 13, p = 1), 10 000 series x T = 1000, fused filter + smoother (dlm_filter_smooth_batch),
+inputs and outputs resident in HBM.  A "step" is one pass of the hot path over the whole batch.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): seasonal DLM `polynomial(1) |+|
-seasonal(24, 6)` (d = 13, p = 1), 10 000 series x T = 1000, fused filter + smoother on one
-MI355X through the C ABI (dlm_filter_smooth_batch), inputs and outputs resident in HBM.
-A "step" is one pass of the hot path over the whole batch.
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scaling strong|weak] ...
 
-  python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU).  Series are
-independent, so ranks shard them with no data-path collective: each rank filters+smooths its
-own 10 000 series (weak scaling) and the whole-job value is the sum over ranks.
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU).  Series are independent, so ranks
+shard them with no data-path collective.  The contract case (BASELINE.json `metric`) is STRONG scaling --
+the 10 000 series are split into contiguous blocks (gibbs.shard_bounds), 1250 per GPU at 8 -- and that is the default;
+`--scaling weak` gives every rank the full batch instead.  `value` = all series of the job x T x steps / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with the extra objects
-  roofline     -- the dominant kernel (backward pass) against the HBM roof, timed with HIP
-                  events on the engine's stream inside the timed region
-  cpu_baseline -- the oracle's batched filter+smoother (a C port of the Scala operation
-                  sequence; the Scala/Breeze reference cannot run: no JVM on the box)
+Other configs (so that the driver can time them; each prints the same one-line contract):
+  c3  pooled d-Inverse-Gamma Gibbs (GibbsSampling.sample, Gibbs.scala:134-180): per iteration FFBS with on-device
+      sufficient statistics, dlm_stats_pool, ONE RCCL all-reduce of 2p + d + 1 doubles (dlm_gibbs_suffstats_allreduce on a
+      communicator whose id travels through the torch.distributed store), the same conjugate draw on every rank
+  c4  d = 40, p = 20 (20 x polynomial(2) under |*|), 2000 series: fused filter + smoother, fp64-MFMA bound
+  c5  SVD (square-root) filter, d = 13, 10 000 series
+
+Prints ONE JSON line on rank 0 with the extra objects
+  roofline     -- the dominant kernel against its roof (HBM bytes or fp64 MFMA flops per SURVEY 8d), timed with HIP
+                  events on the engine's stream inside the timed region; `peak_measured` is a device copy on this box
+  cpu_baseline -- the oracle's C port of the Scala operation sequence on the host cores (N = 1 only; the Scala/Breeze
+                  reference cannot run: no JVM on the box)
 """
 import argparse
 import json
@@ -28,31 +35,30 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
-
-
-def measured_traffic(kernel, N, T):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_hbm_traffic.json: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), valid
-    for the default workload only; None otherwise (PMC counters cannot be read from in here)."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if not os.path.exists(path) or (N, T) != (10000, 1000):
-        return None
-    k = json.load(open(path))["kernels"].get(kernel)
-    return None if k is None else k["hbm_bytes_per_launch"]
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); a device copy reaches 5.3-6.3 TB/s
+MFMA_F64_PEAK_TFLOPS = 78.6  # fp64 vector / matrix peak per MI355X
+W_C2 = [0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4]   # SeasonalModel.scala:18
 
 
 def seasonal_c2():
-    from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
+    from bayesian_dlms_amd.dlm import Dlm, DlmParameters
     mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
-    w = np.diag([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4])
-    p = DlmParameters([[1.0]], w, np.zeros(13), np.eye(13))
-    return mod, p
+    return mod, DlmParameters([[1.0]], np.diag(W_C2), np.zeros(13), np.eye(13))
+
+
+def multivariate_c4():
+    """|*| of 20 polynomial(2): d = 40, p = 20; V = I, W = A A^T / 40 + 0.1 I (seed 40), m0 = 0, C0 = I."""
+    from bayesian_dlms_amd.dlm import Dlm, DlmParameters
+    mod = Dlm.polynomial(2)
+    for _ in range(19):
+        mod = mod * Dlm.polynomial(2)
+    A = np.random.default_rng(40).standard_normal((40, 40))
+    return mod, DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
 
 
 def simulate(mat, p, N, seed):
-    """x0 ~ N(m0, C0), x_t = G x_{t-1} + w_t, y_t = F^T x_t + v_t (Dlm.scala:245-292), vectorised
-    over series; Philox-keyed numpy generator."""
+    """x0 ~ N(m0, C0), x_t = G x_{t-1} + w_t, y_t = F^T x_t + v_t (Dlm.scala:245-292) on the host, vectorised over series
+    (diagonal W, C0, p = 1: tools and tests; the bench itself simulates on the device, dlm_simulate_batch)."""
     rng = np.random.Generator(np.random.Philox(key=seed))
     d, T = mat.d, mat.T
     G = mat.G[: d * d].reshape(d, d).T
@@ -66,121 +72,262 @@ def simulate(mat, p, N, seed):
     return y
 
 
-def cpu_baseline(mat, p, y_host, budget_s=12.0):
-    """Oracle (C port of the reference's per-series op sequence) on the host cores, OpenMP over
-    series, on a bounded sample of the same workload."""
+def traffic_from_profiles(kernel, N, T, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note +
+    WRITE_SIZE, profiles/r0X_hbm_traffic.json), valid for the default workload only; None otherwise (PMC counters cannot be
+    read from inside the run)."""
+    if config != "c2" or (N, T) != (10000, 1000):
+        return None
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            k = json.load(open(path))["kernels"].get(kernel)
+            if k is not None:
+                return k["hbm_bytes_per_launch"]
+    return None
+
+
+def measure_copy_peak(torch, dev, nbytes=4 << 30):
+    """Device copy rate on this box, GB/s counting read + write (the ceiling a streaming kernel can reach here)."""
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device=dev).fill_(1.0)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    del a, b
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def cpu_baseline(config, mat, p, y_host, budget_s=12.0):
+    """Oracle (C port of the reference's per-series op sequence) on the host cores, on a bounded sample of the same
+    workload: OpenMP over series for the filter + smoother; the sampler / SVD legs loop over series on one core."""
     import oracle
     om = oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
-    cores = os.cpu_count() or 1
-    n = min(y_host.shape[0], 2 * cores)
-    t0 = time.perf_counter()
-    oracle.filter_smooth_batch(n, om, p.v, p.w, p.m0, p.c0, y_host[:n], want_out=False)
-    dt = time.perf_counter() - t0
-    rate = n * mat.T / dt
-    n2 = int(min(y_host.shape[0], max(n, rate * budget_s / mat.T)))
-    n2 = max(cores, (n2 // cores) * cores)
-    t0 = time.perf_counter()
-    oracle.filter_smooth_batch(n2, om, p.v, p.w, p.m0, p.c0, y_host[:n2], want_out=False)
-    dt = time.perf_counter() - t0
+    if config in ("c2", "c4"):
+        cores = os.cpu_count() or 1
+        n = min(y_host.shape[0], 2 * cores)
+        t0 = time.perf_counter()
+        oracle.filter_smooth_batch(n, om, p.v, p.w, p.m0, p.c0, y_host[:n], want_out=False)
+        rate = n * mat.T / (time.perf_counter() - t0)
+        n2 = int(min(y_host.shape[0], max(n, rate * budget_s / mat.T)))
+        n2 = max(min(cores, y_host.shape[0]), (n2 // cores) * cores)
+        t0 = time.perf_counter()
+        oracle.filter_smooth_batch(n2, om, p.v, p.w, p.m0, p.c0, y_host[:n2], want_out=False)
+        dt = time.perf_counter() - t0
+        what = "oracle/dlm_oracle.c filter + RTS smoother: Joseph-form update + LU solves, OpenMP over series"
+    else:
+        cores, n2, t0 = 1, 0, time.perf_counter()
+        while n2 < y_host.shape[0] and time.perf_counter() - t0 < budget_s:
+            if config == "c3":
+                f = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y_host[n2])
+                z = oracle.normals(1, n2, mat.T + 1, mat.d)
+                th = oracle.backward_sample(om, p.w, f, z, factor="chol")["theta"]
+                oracle.gibbs_stats(om, y_host[n2], th)
+            else:
+                oracle.svd_filter(om, p.v, p.w, p.m0, p.c0, y_host[n2])
+            n2 += 1
+        dt = time.perf_counter() - t0
+        what = ("oracle/dlm_oracle.c filter + backward sampler (Smoothing.step) + Gibbs sums" if config == "c3"
+                else "oracle/dlm_oracle.c SVD filter (two one-sided Jacobi SVDs per step)") + ", one core, series after series"
     return {"value": n2 * mat.T / dt, "unit": "series*timesteps/s", "cores": cores, "kind": "port",
-            "sample": f"{n2} of the {y_host.shape[0]} series x T={mat.T} (same inputs), {dt:.1f} s, "
-                      "oracle/dlm_oracle.c: Joseph-form update + LU solves, OpenMP over series"}
+            "sample": f"{n2} of the {y_host.shape[0]} series x T={mat.T} (same inputs), {dt:.1f} s, {what}",
+            "scala_reference": "unavailable (no JVM / Breeze jars on the box)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--series", type=int, default=10000, help="series per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the series of the job are sharded over the ranks (the contract case), weak = every rank runs all of them")
+    ap.add_argument("--series", type=int, default=None, help="series of the whole job (strong) / per GPU (weak); default 10000 (c4: 2000)")
     ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--missing", type=float, default=0.0, help="fraction of observations set missing (SURVEY 8d: a second run at 0.05)")
+    ap.add_argument("--records", choices=["dense", "packed"], default="dense", help="c2: packed = DLM_OPT_PACKED_SYM records (2504 B / series-step)")
+    ap.add_argument("--semantics", choices=["textbook", "literal-q1"], default="textbook",
+                    help="c2/c4 smoother covariance: textbook J X J^T (default) or the reference's literal J X J (Smoothing.scala:44)")
+    ap.add_argument("--sampler", choices=["reference", "simsmooth"], default="reference", help="c3: Smoothing.step backward sampler or the simulation smoother")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--flags", type=int, default=0, help="DLM_OPT_* bits (e.g. 8 = force generic kernels)")
+    ap.add_argument("--flags", type=int, default=0, help="extra DLM_OPT_* bits (e.g. 8 = force generic kernels)")
     args = ap.parse_args()
+    cfg = args.config
+    steps = args.steps if args.steps is not None else {"c2": 20, "c3": 5, "c4": 5, "c5": 3}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"c2": 3, "c3": 1, "c4": 1, "c5": 1}[cfg]
 
     import torch
     import torch.distributed as dist
+    from bayesian_dlms_amd import _lib
     from bayesian_dlms_amd.dlm import materialise
     from bayesian_dlms_amd.engine import Engine
+    from bayesian_dlms_amd.gibbs import GibbsSampling, InverseGamma, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    mod, p = seasonal_c2()
-    N, T = args.series, args.T
+    mod, p = multivariate_c4() if cfg == "c4" else seasonal_c2()
+    total = args.series if args.series is not None else (2000 if cfg == "c4" else 10000)
+    T = args.T
+    if world > 1 and args.scaling == "strong":
+        lo, hi = shard_bounds(total, world, rank)
+        job_series = total
+    else:
+        lo, hi = rank * total, (rank + 1) * total        # weak: every rank its own `total` series (distinct global indices)
+        job_series = world * total
+    N = hi - lo
     mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
-    d = mat.d
+    d, q = mat.d, mat.p
     rec = d + d * d
-    y_host = simulate(mat, p, N, seed=0xD1A5EED0 + rank)
-    y = torch.as_tensor(y_host, device=dev)
 
     eng = Engine(local)
-    out = {"filt": torch.empty((N, T + 1, rec), dtype=torch.float64, device=dev),
-           "smooth": torch.empty((N, T + 1, rec), dtype=torch.float64, device=dev),
-           "status": torch.empty((N,), dtype=torch.int32, device=dev)}
+    # synthetic inputs, simulated from the model itself ON the device (dlm_simulate_batch: Philox keyed by the GLOBAL
+    # series index, so the data of series i does not depend on the sharding)
+    y = eng.simulate(mat, p, N, seed=0xD1A5EED0, series_offset=lo, device=True, want_x=False)["y"]
+    if args.missing > 0.0:
+        g = torch.Generator(device=dev); g.manual_seed(0xD1A5EED1 + lo)
+        y[torch.rand(y.shape, device=dev, generator=g) < args.missing] = float("nan")
 
-    def step():
-        eng.filter_smooth(mat, p, y, flags=args.flags, out=out)
+    flags = args.flags
+    if args.semantics == "literal-q1":
+        flags |= _lib.OPT_SMOOTHER_COMPAT_Q1
+    packed = cfg == "c2" and args.records == "packed"
+    if packed:
+        flags |= _lib.OPT_PACKED_SYM
+    recw = eng.lib.dlm_packed_record_doubles(d) if packed else rec
 
-    for _ in range(args.warmup):
-        step()
     fwd_ms, bwd_ms = [], []
+    status = torch.zeros((N,), dtype=torch.int32, device=dev)
+    comm_world = None
+    if cfg in ("c2", "c4"):
+        out = {"filt": torch.empty((N, T + 1, recw), dtype=torch.float64, device=dev),
+               "smooth": torch.empty((N, T + 1, recw), dtype=torch.float64, device=dev), "status": status}
+
+        def step():
+            eng.filter_smooth(mat, p, y, flags=flags, out=out)
+    elif cfg == "c5":
+        def step():
+            status.copy_(eng.svd_filter(mat, p, y, flags=flags)["status"])
+    else:
+        # pooled-parameter Gibbs over all ranks: the communicator id goes through the torch.distributed store
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)            # RCCL prints a version banner on stdout when a communicator is created: keep stdout to the ONE JSON line
+        try:
+            eng.comm_init_rank(world, rank, uid[0])
+        finally:
+            os.dup2(saved, 1); os.close(saved)
+        comm_world = world
+        sim = args.sampler == "simsmooth"
+        chain = GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p, mat.times, y, eng,
+                                     n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
+                                     allreduce=eng.allreduce_stats, simulation_smoother=sim)   # priors: SeasonalModel.scala:127
+        last = {}
+
+        def step():
+            last["state"] = next(chain)
+
+    for _ in range(warmup):
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()                       # synchronous on return (engine stream is drained)
-        f, b = eng.last_timing()     # HIP events recorded by the engine around its two kernels
+        f, b = eng.last_timing()     # HIP events recorded by the engine around its forward / backward kernels
         fwd_ms.append(f); bwd_ms.append(b)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    variant = eng.last_variant
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    status_bad = int((out["status"] != 0).sum().item())
-    units = world * N * T * args.steps
-    value = units / elapsed
+    status_bad = int((status != 0).sum().item())
+    value = job_series * T * steps / elapsed
 
     if rank == 0:
-        # dominant kernel = backward pass: reads [m|C], writes [s|S] -> 16 (d + d^2) B per series-step
         f_ms, b_ms = float(np.mean(fwd_ms)), float(np.mean(bwd_ms))
-        bwd_bytes = 16.0 * rec * N * T
-        fwd_bytes = (8.0 + 8.0 * rec) * N * T
-        dom_is_bwd = b_ms >= f_ms
-        dom_bytes, dom_ms = (bwd_bytes, b_ms) if dom_is_bwd else (fwd_bytes, f_ms)
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        kname = ("k_smoother_" if dom_is_bwd else "k_filter_") + {"sparse16": "sp16", "mfma16": "mfma16"}.get(eng.last_variant, eng.last_variant)
+        nt = float(N) * T
+        if cfg == "c2":
+            # forward: read y, write [m|C]; backward: read [m|C], write [s|S] (SURVEY 8d: 8p + 24 (d + d^2) = 4376 B, packed 2504)
+            fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * recw, 16.0 * recw, "GB/s", HBM_PEAK_GBS, "hbm"
+            names = ("k_filter_", "k_smoother_")
+        elif cfg == "c3":
+            # FFBS with on-device statistics: write + re-read the filtered records, theta never written (8p + 16 (d + d^2) = 2920 B)
+            fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * rec, 8.0 * rec, "GB/s", HBM_PEAK_GBS, "hbm"
+            names = ("k_filter_", "k_sampler_")
+        elif cfg == "c4":
+            # algorithmic flops (SURVEY 8d): filter 8 d^3 + 6 d^2 p + 2 p^3 / 3, RTS 8.67 d^3
+            fwd_u, bwd_u, unit, peak, bound = 8.0 * d ** 3 + 6.0 * d * d * q + 2.0 * q ** 3 / 3.0, 8.67 * d ** 3, "TFLOP/s", MFMA_F64_PEAK_TFLOPS, "mfma"
+            names = ("k_filter_", "k_smoother_")
+        else:
+            fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * (2 * d + d * d), 0.0, "GB/s", HBM_PEAK_GBS, "hbm"
+            names = ("k_svd_filter_", "")
+        dom_is_bwd = b_ms >= f_ms and bwd_u > 0
+        dom_u, dom_ms = (bwd_u, b_ms) if dom_is_bwd else (fwd_u, f_ms)
+        scale = 1e9 if unit == "GB/s" else 1e12
+        achieved = dom_u * nt / (dom_ms * 1e-3) / scale
+        short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16",
+                 "sparse16-simsmooth": "sp16", "svd-jacobi": "jacobi"}.get(variant, variant)
+        kname = (names[1] if dom_is_bwd else names[0]) + short
+        workloads = {
+            "c2": f"C2: seasonal DLM polynomial(1)|+|seasonal(24,6), d=13, p=1, {job_series} series x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
+            "c3": f"C3: the C2 model inside pooled d-Inverse-Gamma Gibbs, {job_series} series x T={T}: FFBS + on-device statistics + dlm_stats_pool + RCCL all-reduce + conjugate draw per iteration",
+            "c4": f"C4: 20 x polynomial(2) under |*|, d=40, p=20, {job_series} series x T={T}, fused filter+smooth",
+            "c5": f"C5: SVD (square-root) filter on the C2 model, d=13, {job_series} series x T={T} (dlm_svd_filter_batch)",
+        }
         line = {
-            "metric": "Kalman filter+smooth series*timesteps/sec", "value": value,
-            "unit": "series*timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": {"c2": "Kalman filter+smooth series*timesteps/sec", "c3": "Gibbs (FFBS + conjugate step) series*timesteps/sec",
+                       "c4": "Kalman filter+smooth series*timesteps/sec (d=40)", "c5": "SVD filter series*timesteps/sec"}[cfg],
+            "value": value, "unit": "series*timesteps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if (world > 1 and args.scaling == "weak") else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: seasonal DLM polynomial(1)|+|seasonal(24,6), d=13, p=1, "
-                                   f"{N} series/GPU x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
-                       "series_per_gpu": N, "T": T, "d": d, "p": 1, "variant": eng.last_variant,
-                       "parallelism": f"series-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": kname,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kname, N, T),
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                         "forward_ms": f_ms, "backward_ms": b_ms,
-                         "path_GBps": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9},
+            "config": {"workload": workloads[cfg], "series_total": job_series, "series_per_gpu": N, "T": T, "d": d, "p": q,
+                       "variant": variant, "records": args.records if cfg == "c2" else "dense",
+                       "semantics": ({"textbook": "textbook (S = C - J (R+ - S+) J^T)", "literal-q1": "literal-q1 (Smoothing.scala:44: J X J)"}[args.semantics]
+                                     if cfg in ("c2", "c4") else ("Smoothing.step backward sampler" if cfg == "c3" and args.sampler == "reference"
+                                                                  else "simulation smoother" if cfg == "c3" else "sqrt(W) in the time update (Q2 off)")),
+                       "missing_fraction": args.missing,
+                       "parallelism": f"series-sharded x{world}" + (", one RCCL all-reduce of %d doubles per iteration (comm world %d)" % (2 * q + d + 1, comm_world)
+                                                                    if cfg == "c3" else ", no collective")},
+            "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": traffic_from_profiles(kname, N, T, cfg) if not packed and args.missing == 0.0 else None,
+                         "algorithmic_units_per_launch": dom_u * nt, "avg_launch_ms": dom_ms,
+                         "forward_ms": f_ms, "backward_ms": b_ms},
             "status_nonzero_series": status_bad,
         }
+        if bound == "hbm":
+            pm = measure_copy_peak(torch, dev)
+            line["roofline"]["peak_measured"] = pm
+            line["roofline"]["frac_of_measured"] = achieved / pm
+            line["roofline"]["path_GBps"] = (fwd_u + bwd_u) * nt / ((f_ms + b_ms) * 1e-3) / 1e9
+        if cfg == "c3":
+            st = last["state"]
+            line["config"]["pooled_V"] = float(np.diag(st.p.v)[0])
+            line["config"]["pooled_W_first"] = [float(x) for x in np.diag(st.p.w)[:3]]
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(mat, p, y_host)
+            line["cpu_baseline"] = cpu_baseline(cfg, mat, p, y[: min(N, 4096)].cpu().numpy())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -142,12 +142,13 @@ int dlm_device_mem_info(dlm_engine *e, uint64_t *free_bytes, uint64_t *total_byt
 
 /* ---- packed symmetric records (DLM_OPT_PACKED_SYM) --------------------------------------
  * A packed state record is [mean (d) | C(0,0) | C(1,0) C(1,1) | C(2,0) ... C(d-1,d-1)] -- the lower triangle by
- * rows -- padded with zeros to an even number of doubles: dlm_packed_record_doubles(d) = d + d (d + 1) / 2 rounded
- * up to even (104 at d = 13 against 182 dense).  With the flag, dlm_filter_batch (filt, prior), dlm_smooth_batch
- * (filt in, smooth out) and dlm_filter_smooth_batch (filt, smooth) read and write packed records; algorithmic
- * traffic of the fused pass drops from 8p + 24 (d + d^2) to 8p + 24 (d + d (d + 1) / 2) bytes per series-step
- * (2504 instead of 4376 at d = 13).  dlm_unpack_records expands [count] packed records into dense ones
- * (host or device memory according to opts->mem). */
+ * rows -- in a slot of dlm_packed_record_doubles(d) = d + d (d + 1) / 2 rounded up to even doubles (104 at d = 13
+ * against 182 dense; the padding double, when there is one, is never written).  With the flag dlm_filter_batch writes `filt` and
+ * dlm_filter_smooth_batch writes `filt` and `smooth` packed; algorithmic traffic of the fused pass drops from
+ * 8p + 24 (d + d^2) to 8p + 24 (d + d (d + 1) / 2) bytes per series-step (2504 instead of 4376 at d = 13).  Served by the
+ * structured d <= 15, p = 1 kernels (every model the reference can build at those sizes); other shapes, the Q1 literal
+ * mode, prior records and dlm_smooth_batch return DLM_ERR_UNSUPPORTED -- use dense records there.
+ * dlm_unpack_records expands [count] packed records into dense ones (host or device memory according to opts->mem). */
 int32_t dlm_packed_record_doubles(int32_t d);
 int dlm_unpack_records(dlm_engine *e, int32_t d, int64_t count, const double *packed, const dlm_options *opts,
                        double *dense);
@@ -230,8 +231,9 @@ int dlm_filter_smooth_batch(dlm_engine *e, const dlm_model_desc *model,
                             const dlm_options *opts, double *filt, double *smooth,
                             int32_t *status);
 
-/* Device time of the forward (ms[0]) and backward (ms[1]) kernel of the LAST
- * dlm_filter_smooth_batch call, from HIP events recorded on the engine's stream. */
+/* Device time of the forward (ms[0]) and backward (ms[1]) kernels of the LAST dlm_filter_smooth_batch, dlm_ffbs_batch,
+ * dlm_backward_sample_batch, dlm_svd_filter_batch or dlm_svd_ffbs_batch call, from HIP events recorded on the
+ * engine's stream around them (a part that did not run reads 0). */
 int dlm_last_timing(dlm_engine *e, double ms[2]);
 
 /* ---- FFBS + Gibbs sufficient statistics --------------------------------------------

@@ -1569,3 +1569,130 @@ def test_backward_sampling_from_existing_filter_records(eng, shape):
     np.testing.assert_allclose(again["theta"], full["theta"], rtol=1e-10, atol=1e-10)
     np.testing.assert_allclose(again["cond"], full["cond"], rtol=1e-10, atol=1e-10)
     np.testing.assert_allclose(again["stats"], full["stats"], rtol=1e-9, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------
+# round 2: packed symmetric records, engine-owned buffers, stream ordering, device-resident Gibbs
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["seasonal_d13", "seasonal_d13_missing_irregular", "poly2_d2", "poly3_plus_harmonic_d5"])
+def test_packed_symmetric_records_equal_dense(eng, case):
+    """DLM_OPT_PACKED_SYM: [mean | lower triangle by rows] records carry exactly the dense call's numbers."""
+    rng = np.random.default_rng(3)
+    if case.startswith("seasonal"):
+        mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+        times = np.cumsum(np.array([1, 1, 2, 1, 3] * 12, dtype=np.float64)) if "irregular" in case else np.arange(1, 61, dtype=np.float64)
+        p = DlmParameters([[1.0]], np.diag([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4]), np.zeros(13), np.eye(13))
+    elif case == "poly2_d2":
+        mod, times = Dlm.polynomial(2), np.arange(1, 41, dtype=np.float64)
+        p = DlmParameters([[2.0]], np.array([[0.5, 0.1], [0.1, 0.3]]), np.zeros(2), np.eye(2) * 5.0)
+    else:
+        mod, times = Dlm.polynomial(3) + Dlm.seasonal(12, 1), np.arange(1, 41, dtype=np.float64)
+        p = DlmParameters([[1.5]], np.eye(5) * 0.2, np.zeros(5), np.eye(5))
+    mat = materialise(mod, times)
+    d = mat.d
+    y = rng.standard_normal((5, mat.T, 1)).cumsum(axis=1)
+    if "missing" in case:
+        y[rng.random(y.shape) < 0.15] = np.nan
+    dense = eng.filter_smooth(mat, p, y, flags=_lib.OPT_NO_LANE)
+    packed = eng.filter_smooth(mat, p, y, flags=_lib.OPT_PACKED_SYM)
+    assert eng.last_variant == "sparse16" and np.all(packed["status"] == 0)
+    prec = d + d * (d + 1) // 2
+    assert packed["filt"].shape[-1] == prec + (prec & 1) == _lib.load().dlm_packed_record_doubles(d)
+    for name in ("filt", "smooth"):
+        un = eng.unpack_records(d, packed[name])
+        m, C = split(dense[name], d)
+        Cs = 0.5 * (C.reshape(C.shape[:-1] + (d, d)) + np.swapaxes(C.reshape(C.shape[:-1] + (d, d)), -1, -2))
+        # the dense record holds both triangles (equal to rounding); the packed one the lower triangle, mirrored on unpack --
+        # and the backward pass then reads a mirrored C_t where the dense call reads both triangles: rounding-level differences
+        np.testing.assert_allclose(un[..., :d], m, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(un[..., d:].reshape(Cs.shape), Cs, rtol=1e-11, atol=1e-12)
+    pf = eng.filter(mat, p, y, flags=_lib.OPT_PACKED_SYM)
+    np.testing.assert_array_equal(pf["filt"][..., :prec], packed["filt"][..., :prec])
+    with pytest.raises(EngineError):        # shapes outside the structured d <= 15, p = 1 path say so
+        eng.filter_smooth(mat, p, y, flags=_lib.OPT_PACKED_SYM | _lib.OPT_FORCE_GENERIC)
+
+
+def test_engine_owned_buffers_round_trip_and_device_mode(eng):
+    """dlm_buffer_alloc / upload / download: a caller without torch keeps a fused call device-resident."""
+    import ctypes
+    mod, mat, p = seasonal_model(T=40)
+    N, d = 6, 13
+    y = simulate(mat, p, N, seed=5, missing=0.05)
+    host = eng.filter_smooth(mat, p, y)
+    free0, total = eng.mem_info()
+    assert total > 100e9 and free0 <= total
+    rec = d + d * d
+    V, vs, W, ws, m0, m0s, C0, c0s, _, _ = __import__("bayesian_dlms_amd.engine", fromlist=["pack_params"]).pack_params(p, N)
+    arrays = {"y": y.reshape(-1), "F": mat.F, "G": mat.G, "V": V, "W": W, "m0": m0, "C0": C0}
+    ptrs = {}
+    for k, a in arrays.items():
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        ptrs[k] = eng.buffer_alloc(a.nbytes)
+        eng.buffer_upload(ptrs[k], a)
+    nrec = N * (mat.T + 1) * rec
+    for k in ("filt", "smooth"):
+        ptrs[k] = eng.buffer_alloc(nrec * 8)
+    ptrs["status"] = eng.buffer_alloc(N * 4)
+    md = _lib.ModelDesc(mat.d, mat.p, mat.T, N, ptrs["F"], 0, ptrs["G"], 1, None, None)
+    pd = _lib.ParamsDesc(ptrs["V"], 0, ptrs["W"], 0, ptrs["m0"], 0, ptrs["C0"], 0, 0, 0)
+    op = _lib.Options(0, _lib.DLM_MEM_DEVICE, 0, 0)
+    lib = _lib.load()
+    V_ = ctypes.c_void_p
+    rc = lib.dlm_filter_smooth_batch(eng.h, md, pd, V_(ptrs["y"]), op, V_(ptrs["filt"]), V_(ptrs["smooth"]), V_(ptrs["status"]))
+    assert rc == 0
+    for k in ("filt", "smooth"):
+        back = eng.buffer_download(ptrs[k], np.empty(nrec))
+        np.testing.assert_array_equal(back.reshape(N, mat.T + 1, rec), host[k])
+    one = eng.buffer_download(ptrs["smooth"], np.empty(rec), offset=(3 * (mat.T + 1) + 17) * rec * 8)    # a single record
+    np.testing.assert_array_equal(one, host["smooth"][3, 17])
+    for ptr in ptrs.values():
+        eng.buffer_free(ptr)
+    with pytest.raises(EngineError):
+        eng.buffer_free(12345)          # not a buffer of this engine
+
+
+def test_inputs_produced_on_the_torch_stream_are_ordered_before_the_engine(eng):
+    """The engine launches on its own stream: a tensor still being written by a long-running torch kernel must be
+    complete before the filter reads it (dlm_engine_wait_stream)."""
+    import torch
+    mod, mat, p = seasonal_model(T=64)
+    N = 2048
+    dev = torch.device("cuda", 0)
+    base = torch.as_tensor(simulate(mat, p, 4, seed=9), device=dev).repeat(N // 4, 1, 1).contiguous()
+    want = eng.filter_smooth(mat, p, base)["smooth"].clone()
+    big = torch.randn(6144, 6144, device=dev)
+    for _ in range(3):
+        torch.cuda.synchronize()
+        acc = big
+        for _ in range(12):
+            acc = (acc @ big).tanh()                 # a few tens of ms of queued work on torch's stream
+        y = base + 0.0 * acc[0, 0].double()          # the observations exist only when that chain has finished
+        got = eng.filter_smooth(mat, p, y)["smooth"]
+        assert torch.equal(got, want)
+
+
+def test_gibbs_sample_svd_and_device_resident_pooled_chain(eng):
+    """GibbsSampling.sampleSvd (Gibbs.scala:182-217) on the SVD sampler's statistics, and the pooled chain with the
+    observations as a device tensor (statistics pooled and reduced in HBM: the bench's C3 control flow, one rank)."""
+    import torch
+    from bayesian_dlms_amd.gibbs import GibbsSampling, InverseGamma
+    rng = np.random.default_rng(8)
+    mod = Dlm.polynomial(1)
+    T, N = 300, 12
+    times = np.arange(1, T + 1, dtype=np.float64)
+    x = np.cumsum(rng.standard_normal((N, T)) * np.sqrt(3.0), axis=1)
+    y = (x + rng.standard_normal((N, T)) * np.sqrt(2.0))[..., None]
+    init = DlmParameters([[1.0]], [[1.0]], [0.0], [[10.0]])
+    chain = list(GibbsSampling.sample_svd(mod, InverseGamma(4.0, 6.0), InverseGamma(4.0, 9.0), init, times, y, eng, n_iter=80, seed=2, pooled=True))
+    v = np.mean([s.p.v[0, 0] for s in chain[20:]]); w = np.mean([s.p.w[0, 0] for s in chain[20:]])
+    assert 1.4 < v < 2.8 and 2.0 < w < 4.2, (v, w)
+    uid = eng.comm_unique_id()
+    eng.comm_init_rank(1, 0, uid)
+    yd = torch.as_tensor(y, device="cuda:0")
+    host = list(GibbsSampling.sample(mod, InverseGamma(4.0, 6.0), InverseGamma(4.0, 9.0), init, times, y, eng, n_iter=4, seed=2, pooled=True))
+    devc = list(GibbsSampling.sample(mod, InverseGamma(4.0, 6.0), InverseGamma(4.0, 9.0), init, times, yd, eng, n_iter=4, seed=2, pooled=True,
+                                     allreduce=eng.allreduce_stats))
+    for a, b in zip(host, devc):   # same Philox draws, same pooled statistics, same numpy conjugate draws
+        np.testing.assert_allclose(a.p.v, b.p.v, rtol=1e-10)
+        np.testing.assert_allclose(a.p.w, b.p.w, rtol=1e-10)
+    assert hasattr(devc[-1].stats, "data_ptr")          # the per-series statistics stayed on the device
