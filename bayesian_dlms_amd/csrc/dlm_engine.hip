@@ -329,6 +329,13 @@ int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
   } else if (have_side && use_tiled(k) && !(k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1)) {
     e->variant = dlm::wave48_smoother_supported(k) ? "wave-mfma" : "tiled-mfma";   // fused call only: the information-form pass takes the innovations of the forward pass
     HIP_TRY(e, dlm::launch_tiled_smoother(k, e->ystar, e->stream));
+  } else if (fast_shape_ok(k) && e->sparse_k > 0 && !(k.packed & 1)) {
+    // RTS recursion on register tiles from the records alone: dlm_smooth_batch, and the literal Q1 covariance (Smoothing.scala:44)
+    e->variant = "sparse16-rts";
+    HIP_TRY(e, dlm::launch_sparse16_rts(k, e->sparse_k, e->sp_dev, e->stream));
+  } else if (!(k.flags & DLM_OPT_FORCE_GENERIC) && dlm::wave48_small_ok(k)) {
+    e->variant = "sparse16-rts";   // d <= 15 with several observation components: the same kernel on the multivariate tables
+    HIP_TRY(e, dlm::launch_small_mv_rts(k, e->stream));
   } else {
     e->variant = "generic";
     HIP_TRY(e, dlm::launch_generic_smoother(k, e->stream));
@@ -674,7 +681,10 @@ int dlm_smooth_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   st.out(&k.smooth, smooth, N * (T + 1) * rec);
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
+  if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;   // structure tables for the register-tile RTS kernel
+  if ((rc = mark(e, 0)) || (rc = mark(e, 1))) return rc;
   if ((rc = run_smoother(e, k, false))) return rc;
+  if ((rc = mark(e, 2))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
 

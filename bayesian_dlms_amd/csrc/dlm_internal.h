@@ -73,6 +73,9 @@ hipError_t launch_sparse16_simsmooth(const KArgs& a, int K, const SparseT* tabs_
 // the reference-form backward sampler (a.filt_in -> theta / cond / stats), dlm_sampler16.hip; tabs_dev as above
 hipError_t launch_sparse16_sampler(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s);
 hipError_t launch_small_mv_sampler(const KArgs& a, hipStream_t s);   // the same for d <= 15, p >= 2 (a.spb tables)
+// RTS smoother (Smoothing.smoothStep) from filter records alone on the same register tiles; textbook or literal Q1
+hipError_t launch_sparse16_rts(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s);
+hipError_t launch_small_mv_rts(const KArgs& a, hipStream_t s);
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s);
 
 // ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------

@@ -470,6 +470,203 @@ __global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const Tab* __restr
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The reference's RTS smoother on the same register tiles: Smoothing.smoothStep / backwardsSmoother (Smoothing.scala:31-64),
+// from filter records alone (no innovations from a forward pass needed: serves dlm_smooth_batch and the literal mode).
+//   a+ = G m, R+ = G C G^T + W dt (dt == 0: a+ = m, R+ = C);  J = C G^T R+^-1 (always the table entry g(dt), Smoothing.scala:41)
+//   s_t = m_t + J (s_{t+1} - a+)
+//   S_t = C_t - J (R+ - S_{t+1}) J^T          textbook
+//   S_t = C_t - J (R+ - S_{t+1}) J            DLM_OPT_SMOOTHER_COMPAT_Q1: Smoothing.scala:44 as written (no transpose)
+// With mm(A, B) = A^T B on the tiles:  J^T = mm(Rinv, G C),  Y = mm(X, J^T) = (J X)^T,  J X J^T = mm(J^T, Y),  J X J = mm(Y, J)
+// with J = mm(G C, Rinv).  Rinv is the warm-started Newton-Schulz inverse of the sampler above; once the filtered
+// covariance has stopped moving, J and R+ are those of the step before and a step is two products.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K, class Tab>
+__global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __restrict__ sp) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 4 * 16];
+  double* img = lds;       double* inv = lds + IMG;
+  double* mv = inv + IMG;  double* sv = mv + 16;   double* uv = sv + 16;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int d = a.d, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  const bool vc = c < d;
+  const bool compat = (a.flags & DLM_OPT_SMOOTHER_COMPAT_Q1) != 0;
+  for (int i = lane; i < 4 * 16; i += 64) mv[i] = 0.0;
+
+  int ridx[K];                   // nonzeros of row c of G
+  double rval[K];
+  int gcur = -1;
+  auto load_tables = [&](int gi) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) { ridx[s] = sp[2 * gi].idx[c][s]; rval[s] = vc ? sp[2 * gi].val[c][s] : 0.0; }
+    gcur = gi;
+  };
+  const double* W0 = a.W + (size_t)n * a.w_stride;
+  d4 Wt;
+  bool va[4];
+  int offC[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    va[r] = i < d && vc;
+    offC[r] = va[r] ? (d + i + c * d) * 8 : OOB;      // element (i, c) of a record's covariance, column-major
+    Wt[r] = va[r] ? W0[i + c * d] : 0.0;
+  }
+  const int offM = (vc && g == 0) ? c * 8 : OOB;
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const __amdgpu_buffer_rsrc_t rout = mk_rsrc(a.smooth + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  int st = 0;
+  d4 S, Rinv = {0.0, 0.0, 0.0, 0.0};
+  bool warm = false;
+  {   // init = last filter state (Smoothing.scala:59-61)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { S[r] = bld(rin, offC[r], T * recb); bst(rout, offC[r], T * recb, S[r]); }
+    const double mc = bld(rin, vc ? c * 8 : OOB, T * recb);
+    bst(rout, offM, T * recb, mc);
+    if (g == 0) sv[c] = mc;
+    wave_sync();
+  }
+  d4 Cp = {0.0, 0.0, 0.0, 0.0}, JTs = Cp, Js = Cp, Rs = Cp;   // steady-state reuse (see k_sampler_sp16)
+  bool have = false;
+  int gprev = -1;
+  double dtprev = 0.0, cmaxp = 0.0;
+  d4 nC;
+  double nm;
+  {
+    const int tp = T > 0 ? T - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
+    nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
+  }
+  double scol = 0.0;
+  for (int t = T - 1; t >= 0; --t) {
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    const int gi = a.g_index ? a.g_index[t] : 0;
+    if (gi != gcur) load_tables(gi);
+    const d4 C = nC;
+    const double mc = nm;
+    {
+      const int tp = t > 0 ? t - 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
+      nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
+    }
+    if (a.w_tstride) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wt[r] = va[r] ? (W0 + (size_t)t * a.w_tstride)[4 * r + g + c * d] : 0.0;
+    }
+    if (g == 0) mv[c] = mc;
+    bool reuse = false;
+    if (have && gi == gprev && dt == dtprev && !a.w_tstride) {
+      bool moved = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) moved |= !(fabs(C[r] - Cp[r]) <= 1e-13 * cmaxp);
+      reuse = __ballot(moved) == 0ull;
+    }
+    d4 JT, J, R;
+    double a1 = mc;
+    if (reuse) {
+      wave_sync();
+      if (dt != 0.0) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) s_ = fma(mv[ridx[s]], rval[s], s_);
+        a1 = s_;
+      }
+      JT = JTs; J = Js; R = Rs;
+    } else {
+      to_img(C, img, g, c);
+      wave_sync();
+      d4 T1;                                           // C G^T (pass 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* row = img + (4 * r + g) * IL;
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) s_ = fma(row[ridx[s]], rval[s], s_);
+        T1[r] = s_;
+      }
+      if (dt != 0.0) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < K; ++s) s_ = fma(mv[ridx[s]], rval[s], s_);
+        a1 = s_;
+      }
+      wave_sync();
+      const d4 GC = transposed(T1, img, g, c);         // (C G^T)^T = G C
+      if (dt != 0.0) {
+        to_img(T1, img, g, c);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * r + g;
+          double s_ = Wt[r] * dt;
+#pragma unroll
+          for (int s = 0; s < K; ++s) s_ = fma(img[ridx[s] * IL + i], rval[s], s_);
+          R[r] = s_;
+        }
+        wave_sync();
+        const d4 Rt = transposed(R, img, g, c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[r] = 0.5 * (R[r] + Rt[r]);
+      } else R = C;
+      {
+        bool done = false;
+        if (warm) {
+          for (int it = 0; it < 6 && !done; ++it) {
+            d4 E = mm(R, Rinv, d);
+            bool big = false, far = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 4 * r + g;
+              const double e = ((i == c) ? 1.0 : 0.0) - E[r];
+              E[r] = e;
+              if (i < d && vc) { big |= !(fabs(e) <= 2e-10); far |= !(fabs(e) * d < 0.5); }
+            }
+            const bool any_big = __ballot(big) != 0ull, any_far = __ballot(far) != 0ull;
+            if (any_far && any_big) break;
+            if (!any_big) done = true;
+            const d4 D = mm(Rinv, E, d);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Rinv[r] += D[r];
+            const d4 Xt = transposed(Rinv, img, g, c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Rinv[r] = 0.5 * (Rinv[r] + Xt[r]);
+          }
+        }
+        if (!done && direct_inverse(R, Rinv, d, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
+        warm = true;
+      }
+      JT = mm(Rinv, GC, d);                             // J^T = R+^-1 G C
+      J = mm(GC, Rinv, d);                              // J   = C G^T R+^-1
+      Cp = C; JTs = JT; Js = J; Rs = R; have = true; gprev = gi; dtprev = dt;
+      {
+        double mx = fmax(fmax(fabs(C[0]), fabs(C[1])), fmax(fabs(C[2]), fabs(C[3])));
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mx = fmax(mx, __shfl_xor(mx, o_));
+        cmaxp = mx;
+      }
+    }
+    if (g == 0) uv[c] = vc ? sv[c] - a1 : 0.0;
+    wave_sync();
+    scol = mc + matTvec(JT, uv, g);                     // s = m + J (s+ - a+)
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] = R[r] - S[r];     // R+ - S+
+    const d4 Y = mm(X, JT, d);                          // X^T J^T = (J X)^T
+    const d4 JXJ = compat ? mm(Y, J, d) : mm(JT, Y, d); // J X J (Smoothing.scala:44)  |  J X J^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { S[r] = va[r] ? C[r] - JXJ[r] : 0.0; bst(rout, offC[r], t * recb, S[r]); }
+    bst(rout, offM, t * recb, scol);
+    wave_sync();
+    if (g == 0) sv[c] = vc ? scol : 0.0;
+    wave_sync();
+  }
+  bool bad = vc && g == 0 && !isfinite(scol);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(S[r]);
+  if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
 }  // namespace s16
 
 template <class Tab>
@@ -484,6 +681,21 @@ static hipError_t launch_sampler_t(const KArgs& a, int K, const Tab* tabs_dev, h
   return hipGetLastError();
 }
 hipError_t launch_sparse16_sampler(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s) { return launch_sampler_t(a, K, tabs_dev, s); }
+
+template <class Tab>
+static hipError_t launch_rts_t(const KArgs& a, int K, const Tab* tabs_dev, hipStream_t s) {
+  switch (K) {
+    case 1: hipLaunchKernelGGL((s16::k_smoother_rts16<1, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 2: hipLaunchKernelGGL((s16::k_smoother_rts16<2, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 3: hipLaunchKernelGGL((s16::k_smoother_rts16<3, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 4: hipLaunchKernelGGL((s16::k_smoother_rts16<4, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+// RTS smoother from filter records alone (a.filt_in -> a.smooth), textbook or literal Q1: structured d <= 15
+hipError_t launch_sparse16_rts(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s) { return launch_rts_t(a, K, tabs_dev, s); }
+hipError_t launch_small_mv_rts(const KArgs& a, hipStream_t s) { return launch_rts_t(a, a.spb_k, a.spb, s); }
 // d <= 15 with several observation components: the tables of the multivariate paths (a.spb, [2 gi] rows / [2 gi + 1] columns)
 hipError_t launch_small_mv_sampler(const KArgs& a, hipStream_t s) { return launch_sampler_t(a, a.spb_k, a.spb, s); }
 

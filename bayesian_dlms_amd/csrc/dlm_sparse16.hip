@@ -111,6 +111,13 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, char*, int v
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
+// the forward pass's (e / Q, 1 / Q) pair for the backward pass: one 16-byte store from lane 0 (the others carry OOB)
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void side_store(__amdgpu_buffer_rsrc_t r, int voff, int soff, double a, double b) {
+  const u4 v = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
 // ---- record prefetch by LDS DMA (backward pass) ---------------------------------------------------
 // `buffer_load_dwordx4 ... lds` copies 16 B per lane straight from HBM into LDS: no VGPRs are held while
 // the load is in flight, so the backward pass can keep TWO records in flight per wave (the loaded HBM
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS + (SIM ? 4 * IMG : 0)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
-  const int n = blockIdx.x * 4 + wave;
+  const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
   if (n >= a.N) return;
   double* imgA = lds + wave * WAVE_LDS;
   double* imgB = imgA + IMG;
@@ -321,6 +328,8 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   double ll = 0.0;   // sum_t log N(y_t; f_t, Q_t) (KalmanFilter.conditionalLikelihood, KalmanFilter.scala:138-153)
   double* fq = a.fq ? a.fq + (size_t)n * (T + 1) * 2 : nullptr;
   double* sd = side ? side + (size_t)n * (T + 1) * 2 : nullptr;
+  const __amdgpu_buffer_rsrc_t rside = make_rsrc(sd, sd ? (size_t)(T + 1) * 16 : 0);   // zero-sized without a side buffer: stores dropped
+  const int offS = lane == 0 ? 0 : OOB;
   char* bpri = a.prior ? (char*)(a.prior + (size_t)n * (T + 1) * rec) : nullptr;   // optional (a_t, R_t) records
   const __amdgpu_buffer_rsrc_t rpri = make_rsrc(bpri ? bpri : bout, (size_t)(T + 1) * rec * 8);
 
@@ -499,10 +508,10 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
       for (int r = 0; r < 3; ++r) cc[r] = fma(rfr[r], ngam, R[r]);
       cc[3] = (g == 3) ? fma(Kc, e, R[3]) : fma(rfr[3], ngam, R[3]);
       if (LL) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * erq);   // -log N(y; f, Q); log(2 pi) = 1.83787...
-      if (sd && lane == 0) { sd[2 * (t + 1)] = erq; sd[2 * (t + 1) + 1] = rq; }
+      side_store(rside, offS, (t + 1) * 16, erq, rq);
     } else {
       cc = R;
-      if (sd && lane == 0) { sd[2 * (t + 1)] = __builtin_nan(""); sd[2 * (t + 1) + 1] = __builtin_nan(""); }
+      side_store(rside, offS, (t + 1) * 16, __builtin_nan(""), __builtin_nan(""));
     }
     if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
     const int so = (t + 1) * recb;
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const 
   extern __shared__ __attribute__((aligned(16))) char ring_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
-  const int n = blockIdx.x * 4 + wave;
+  const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
   if (n >= a.N) return;
   double* imgA = lds + wave * SM_LDS;
   double* imgB = imgA + IMG;
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
   __shared__ __attribute__((aligned(16))) double lds[4 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = blockIdx.x * 4 + wave;
+  const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
   if (n >= a.N) return;
   double* vQ = lds + wave * 64;   // q_t
   double* vR = vQ + 16;           // r
@@ -941,10 +950,15 @@ int sparse16_analyse(const double* G /* d x d column-major, host */, int d, Spar
   return kmax;
 }
 
+// Batches that cannot fill the chip's SIMDs twice over go out as one-wave workgroups: the dispatcher then spreads the waves
+// over all CUs one by one instead of four at a time (at 1250 series: 5 waves on almost every CU instead of 8 on 57 of them).
+static int waves_per_block(const KArgs& a) { return (a.N < 2048 && !(a.flags & DLM_OPT_NO_SMALL_BATCH)) ? 1 : 4; }
+
 template <int K>
 static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, double* xplus, hipStream_t s) {
   const bool irr = a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride;
-  const dim3 grid((a.N + 3) / 4), blk(256);
+  const int wpb = waves_per_block(a);
+  const dim3 grid((a.N + wpb - 1) / wpb), blk(64 * wpb);
   if (a.loglik && !xplus) {
     if (irr) hipLaunchKernelGGL((k_filter_sp16<K, false, true, true>), grid, blk, 0, s, a, sp, side, xplus);
     else hipLaunchKernelGGL((k_filter_sp16<K, false, false, true>), grid, blk, 0, s, a, sp, side, xplus);
@@ -956,15 +970,19 @@ static hipError_t launch_f(const KArgs& a, const SparseT* sp, double* side, doub
 }
 template <int K>
 static hipError_t launch_ss(const KArgs& a, const SparseT* sp, const double* side, const double* xplus, hipStream_t s) {
-  if (a.g_index || a.dt || a.f_stride || a.v_tstride) hipLaunchKernelGGL((k_simsmooth_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
-  else hipLaunchKernelGGL((k_simsmooth_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), 0, s, a, sp, side, xplus);
+  const int wpb = waves_per_block(a);
+  const dim3 grid((a.N + wpb - 1) / wpb), blk(64 * wpb);
+  if (a.g_index || a.dt || a.f_stride || a.v_tstride) hipLaunchKernelGGL((k_simsmooth_sp16<K, true>), grid, blk, 0, s, a, sp, side, xplus);
+  else hipLaunchKernelGGL((k_simsmooth_sp16<K, false>), grid, blk, 0, s, a, sp, side, xplus);
   return hipGetLastError();
 }
 template <int K>
 static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side, hipStream_t s) {
-  const size_t ring = (size_t)4 * 2 * (((a.packed & 1) ? packed_rec_bytes(a.d) : (a.d + a.d * a.d) * 8) + 16);   // dynamic LDS: DMA ring, 2 slots per wave
-  if (a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
-  else hipLaunchKernelGGL((k_smoother_sp16<K, false>), dim3((a.N + 3) / 4), dim3(256), ring, s, a, sp, side);
+  const int wpb = waves_per_block(a);
+  const size_t ring = (size_t)wpb * 2 * (((a.packed & 1) ? packed_rec_bytes(a.d) : (a.d + a.d * a.d) * 8) + 16);   // dynamic LDS: DMA ring, 2 slots per wave
+  const dim3 grid((a.N + wpb - 1) / wpb), blk(64 * wpb);
+  if (a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), grid, blk, ring, s, a, sp, side);
+  else hipLaunchKernelGGL((k_smoother_sp16<K, false>), grid, blk, ring, s, a, sp, side);
   return hipGetLastError();
 }
 

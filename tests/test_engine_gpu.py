@@ -202,17 +202,61 @@ def test_fast_path_variants_by_g_structure(eng, kind, expect):
     np.testing.assert_allclose(fq[0, 1:, 1], f0["Q"][1:, 0], rtol=1e-9, atol=1e-10)
 
 
-def test_smoother_q1_compat_switch(eng):
-    """DLM_OPT_SMOOTHER_COMPAT_Q1 reproduces the literal Smoothing.scala:44 form."""
-    mod, mat, p = seasonal_model(T=60)
-    y = simulate(mat, p, 2, seed=1)
+@pytest.mark.parametrize("case", ["seasonal_d13", "seasonal_d13_missing_irregular", "poly2_d2_dt0", "d8_p4_multivariate", "dense_g_d6"])
+def test_smoother_q1_compat_switch(eng, case):
+    """DLM_OPT_SMOOTHER_COMPAT_Q1 reproduces the literal Smoothing.scala:44 form (J X J, no transpose) -- on the register-tile
+    RTS kernel (dlm_sampler16.hip: k_smoother_rts16) wherever G is structured and d <= 15, on the generic kernel elsewhere --
+    and dlm_smooth_batch on bare filter records runs the same kernel in its textbook form."""
+    rng = np.random.default_rng(4)
+    expect = "sparse16-rts"
+    if case.startswith("seasonal"):
+        mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+        times = np.cumsum(np.array([1, 1, 2, 1, 3, 0.5] * 10, dtype=np.float64)) if "irregular" in case else np.arange(1, 121, dtype=np.float64)
+        p = DlmParameters([[1.0]], np.diag([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4]), np.zeros(13), np.eye(13))
+    elif case == "poly2_d2_dt0":
+        mod, times = Dlm.polynomial(2), np.array([1, 2, 2, 3, 4, 4, 5, 7, 8, 9, 10, 10, 11], dtype=np.float64)   # repeated times: dt = 0
+        p = DlmParameters([[2.0]], np.array([[0.5, 0.1], [0.1, 0.3]]), np.zeros(2), np.eye(2) * 5.0)
+    elif case == "d8_p4_multivariate":
+        mod = Dlm.polynomial(2)
+        for _ in range(3):
+            mod = mod * Dlm.polynomial(2)
+        times = np.arange(1, 41, dtype=np.float64)
+        A = rng.standard_normal((8, 8))
+        p = DlmParameters(np.diag([1.0, 2.0, 0.5, 1.5]), A @ A.T / 8 + 0.1 * np.eye(8), rng.standard_normal(8), np.eye(8) * 2)
+    else:
+        Gd = 0.9 * np.eye(6) + 0.05 * rng.standard_normal((6, 6))
+        mod, times = Dlm(lambda t: np.ones((6, 1)), lambda dt: Gd), np.arange(1, 41, dtype=np.float64)
+        p = DlmParameters([[1.0]], np.eye(6) * 0.3, np.zeros(6), np.eye(6))
+        expect = "generic"
+    mat = materialise(mod, times)
+    d = mat.d
+    y = rng.standard_normal((3, mat.T, mat.p)).cumsum(axis=1)
+    if "missing" in case:
+        y[rng.random(y.shape) < 0.15] = np.nan
     out = eng.filter_smooth(mat, p, y, flags=_lib.OPT_SMOOTHER_COMPAT_Q1)
-    assert eng.last_variant == "generic"
-    for n in range(2):
+    assert eng.last_variant == expect and np.all(out["status"] == 0)
+    tb = eng.smooth(mat, p, out["filt"])                       # textbook RTS from the records alone
+    assert eng.last_variant == (expect if d > 5 or mat.p > 1 else "lane")
+    for n in range(3):
         f, s = oracle_filter_smooth(mat, p, y[n], compat=True)
-        sm, S = split(out["smooth"][n], 13)
+        sm, S = split(out["smooth"][n], d)
         np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+        s2 = oracle.smoother(omodel(mat), f, compat_q1=False)
+        sm2, S2 = split(tb["smooth"][n], d)
+        np.testing.assert_allclose(sm2, s2["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S2, s2["S"], rtol=1e-8, atol=1e-9)
+    if d == 13:   # the literal covariance really is another matrix (SURVEY Q1), the means are not
+        assert np.abs(out["smooth"][..., 13:] - tb["smooth"][..., 13:]).max() > 1e-3
+        np.testing.assert_allclose(out["smooth"][..., :13], tb["smooth"][..., :13], rtol=1e-8, atol=1e-9)
+    # a long stationary stretch: the steady-state reuse of J must not change a digit that matters
+    if case == "seasonal_d13":
+        mat2 = materialise(mod, np.arange(1, 601, dtype=np.float64))
+        y2 = rng.standard_normal((2, 600, 1)).cumsum(axis=1)
+        o2 = eng.filter_smooth(mat2, p, y2, flags=_lib.OPT_SMOOTHER_COMPAT_Q1)
+        g2 = eng.filter_smooth(mat2, p, y2, flags=_lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_FORCE_GENERIC)
+        assert eng.last_variant == "generic"
+        np.testing.assert_allclose(o2["smooth"], g2["smooth"], rtol=1e-8, atol=1e-9)
 
 
 def test_multivariate_d8_p4_missing_irregular(eng):
