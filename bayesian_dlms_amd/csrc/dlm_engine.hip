@@ -828,7 +828,6 @@ int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
                          const dlm_options* opts, double* svd_rec, int32_t* status) {
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
-  if (params->v_tstride || params->w_tstride) return fail(e, DLM_ERR_UNSUPPORTED, "the SVD filter takes time-invariant V and W");
   if (!y || !svd_rec) return fail(e, DLM_ERR_ARG, "y and svd_rec are required");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
   KArgs k{};
@@ -851,7 +850,6 @@ int dlm_svd_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_par
                        double* svd_ws, double* theta, double* stats, int32_t* status) {
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
-  if (params->v_tstride || params->w_tstride) return fail(e, DLM_ERR_UNSUPPORTED, "the SVD filter takes time-invariant V and W");
   if (!y || !svd_ws) return fail(e, DLM_ERR_ARG, "y and svd_ws are required");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
   KArgs k{};

@@ -22,9 +22,9 @@
 namespace dlm {
 
 constexpr int SL = 17;   // leading dimension of the d x d LDS matrices
-constexpr int STL = 33;  // leading dimension of the stacked matrix (<= 32 rows)
+constexpr int STL = 33;  // largest leading dimension of the stacked matrix (<= 32 rows); kernels use `stl` (odd, sized by the shape)
 #define M17(buf, i, j) (buf)[(i) + (j) * SL]
-#define STK(i, j) stack[(i) + (j) * STL]
+#define STK(i, j) stack[(i) + (j) * stl]
 
 // A block is ONE wavefront: LDS hand-offs need only keep the compiler (and the in-order LDS queue) in order --
 // no s_barrier, and none of the vmcnt(0) a __syncthreads() fence would add after the record stores.
@@ -170,12 +170,134 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
 #endif
 }
 
+
+// Eigen-decomposition of diag(delta) + w w^T (delta > 0) by the secular equation -- the measurement update of the SVD filter
+// when ONE observation component is present:  the stacked matrix [w^T ; diag(1 / dr)] of SvdFilter.updateState
+// (SvdFilter.scala:56) has A^T A = diag(1 / dr^2) + w w^T, so its right singular vectors and squared singular values are
+// the eigen-pairs of a diagonal plus a rank-one matrix.  No sweeps: lane i finds eigenvalue i as the root of
+//   1 + sum_j w_j^2 / (delta_j - lambda) = 0   in (delta_i, delta_{i+1})        (poles sorted ascending)
+// by a safeguarded Newton iteration on F(tau) = tau (1 + r(tau)) - w_o^2 with the origin o at the nearer pole (lambda =
+// delta_o + tau, so that delta_j - lambda is computed without cancellation), then the Gu-Eisenstat weights
+//   zhat_j^2 = prod_i (lambda_i - delta_j) / prod_{i != j} (delta_i - delta_j)
+// make the vectors  v_i ~ zhat_j / (delta_j - lambda_i)  the EXACT eigenvectors of a matrix within rounding of the given
+// one -- orthogonal to working precision without any deflation logic.  Equal poles are separated by 16 eps scale and
+// vanishing weights floored at 1e-13 sqrt(scale) first (a 1e-13 relative perturbation of the matrix, below the
+// steady-state tolerance of this file).  Prototype and stress test: 3000 adversarial cases, |V^T V - I| <= 8e-16.
+// In: lane j < d holds delta_j and w_j.  Out: V (d x d, ld SL, columns = eigenvectors in the caller's coordinates),
+// sig[i] = sqrt(lambda_i).  scr: 6 x 16 doubles of LDS scratch.
+__device__ void secular_update(int lane, int d, double delta, double w, double* V, double* sig, double* scr) {
+  // LDS scratch (6 x 16 doubles): sorted poles, squared weights, roots' offsets and origins, Gu-Eisenstat weights, permutation.
+  // All loops over j read sds[j] / sw2[j] at a wave-uniform address (LDS broadcast): no per-lane register arrays.
+  double* sds = scr; double* sw2 = scr + 16; double* stau = scr + 32; double* sdso = scr + 48; double* szh = scr + 64;
+  int* sperm = (int*)(scr + 80);
+  const double EPS = 2.220446049250313e-16;
+  const bool act = lane < d;
+  if (act) stau[lane] = delta;
+  ssync();
+  int rank = 0;
+  if (act)
+    for (int k = 0; k < d; ++k) { const double dk = stau[k]; rank += (dk < delta) || (dk == delta && k < lane); }
+  ssync();
+  if (act) { sds[rank] = delta; sw2[rank] = w; sperm[rank] = lane; }
+  ssync();
+  // regularise (every lane the same scalar recurrences, values broadcast from LDS): strictly increasing poles, no vanishing weights
+  double wn2 = 0.0, scale = 0.0;
+  for (int j = 0; j < d; ++j) { const double wj = sw2[j]; wn2 = fma(wj, wj, wn2); scale = fmax(scale, sds[j]); }
+  scale = fmax(scale, wn2);
+  const double sep = 16.0 * EPS * scale, floorw = 1e-13 * sqrt(scale);
+  double mine = 0.0, prev = 0.0, wmine = 0.0;
+  wn2 = 0.0;
+  for (int j = 0; j < d; ++j) {
+    double dj = sds[j];
+    if (j > 0) dj = fmax(dj, prev + sep);
+    prev = dj;
+    double wj = sw2[j];
+    if (fabs(wj) < floorw) wj = wj < 0.0 ? -floorw : floorw;
+    wn2 = fma(wj, wj, wn2);
+    if (j == lane) { mine = dj; wmine = wj; }
+  }
+  ssync();
+  if (act) { sds[lane] = mine; sw2[lane] = wmine * wmine; }
+  const double wsgn = wmine < 0.0 ? -1.0 : 1.0;
+  ssync();
+  // ---- roots: lane i, eigenvalue i in (delta_i, delta_{i+1}) ----------------------------------------------------------
+  const int i = act ? lane : 0;
+  const bool last = i == d - 1;
+  const double di = sds[i], dip = last ? di : sds[i + 1];
+  double lo, hi, dso, w2o, t;
+  int o;
+  {
+    const double mid = 0.5 * (dip - di);
+    double hm = 1.0;
+    for (int j = 0; j < d; ++j) hm = fma(sw2[j], fast_rcp((sds[j] - di) - mid), hm);
+    const bool lower = last || hm >= 0.0;
+    o = lower ? i : i + 1;
+    dso = lower ? di : dip;
+    lo = lower ? 0.0 : -mid;
+    hi = last ? wn2 * (1.0 + 1e-12) : (lower ? mid : 0.0);
+    w2o = sw2[o];
+    double r0 = 0.0;
+    for (int j = 0; j < d; ++j) { const double dj = sds[j] - dso; r0 += (j == o) ? 0.0 : sw2[j] * fast_rcp(dj); }
+    t = w2o * fast_rcp(1.0 + r0);
+    if (!(lo < t && t < hi)) t = 0.5 * (lo + hi);
+  }
+  bool done = !act;
+  for (int it = 0; it < 48; ++it) {
+    if (__ballot(!done) == 0ull) break;
+    double r = 0.0, rp = 0.0;
+    for (int j = 0; j < d; ++j) {
+      const double inv = fast_rcp((sds[j] - dso) - t);
+      const double tt = (j == o) ? 0.0 : sw2[j] * inv;
+      r += tt; rp = fma(tt, inv, rp);
+    }
+    const double f = fma(t, 1.0 + r, -w2o), fp = (1.0 + r) + t * rp;
+    const double step = fp != 0.0 ? f * fast_rcp(fp) : 0.0;
+    if (!done) {
+      if (fp != 0.0 && fabs(step) <= 4.0 * EPS * fabs(t)) done = true;
+      else {
+        if ((f > 0.0) == (t > 0.0)) hi = t; else lo = t;
+        double tn = fp != 0.0 ? t - step : 0.5 * (lo + hi);
+        if (!(lo < tn && tn < hi)) {
+          const double a_ = lo >= 0.0 ? lo : -hi, b_ = lo >= 0.0 ? hi : -lo;
+          const double m_ = a_ == 0.0 ? 0.125 * fabs(t) : (b_ > 4.0 * a_ ? sqrt(a_ * b_) : 0.5 * (a_ + b_));
+          tn = lo >= 0.0 ? m_ : -m_;
+        }
+        t = tn;
+      }
+    }
+  }
+  if (act) { stau[lane] = t; sdso[lane] = dso; }
+  ssync();
+  // ---- Gu-Eisenstat weights (lane j = i) -------------------------------------------------------------------------------
+  {
+    double prod = 1.0;
+    for (int k = 0; k < d; ++k) {
+      const double num = (sdso[k] - di) + stau[k];                          // lambda_k - delta_j
+      const double den = (k < i) ? sds[k] - di : (k < d - 1 ? sds[k + 1] - di : 1.0);
+      prod *= num * fast_rcp(den);
+    }
+    if (act) szh[lane] = sqrt(fabs(prod)) * wsgn;
+  }
+  ssync();
+  // ---- eigenvectors: lane i builds column i, rows back in the caller's order ----------------------------------------------
+  {
+    double nrm = 0.0;
+    for (int j = 0; j < d; ++j) { const double x = szh[j] * fast_rcp((sds[j] - dso) - t); nrm = fma(x, x, nrm); }
+    const double inv = fast_rsqrt(nrm);
+    if (act) {
+      for (int j = 0; j < d; ++j) M17(V, sperm[j], lane) = szh[j] * fast_rcp((sds[j] - dso) - t) * inv;
+      sig[lane] = sqrt(dso + t);
+    }
+  }
+  ssync();
+}
+
 // sqrtSvd / sqrtInvSvd (SvdFilter.scala:210-227): out = diag(sig^{+-1/2}) V^T for the SPD n x n Mx.
 __device__ int sqrt_svd(int lane, int n, const double* Mx /* global, col-major n x n */, bool inverse,
-                        double* out, double* stack, double* Vacc, double* sig) {
+                        double* out, double* stack, int stl, double* Vacc, double* sig) {
   for (int k = lane; k < n * n; k += 64) STK(k % n, k / n) = Mx[k];
   ssync();
-  const int rc = jacobi_svd(lane, n, n, stack, STL, Vacc, sig);
+  const int rc = jacobi_svd(lane, n, n, stack, stl, Vacc, sig);
   for (int k = lane; k < n * n; k += 64) {
     const int i = k % n, j = k / n;
     const double s = inverse ? 1.0 / sqrt(sig[i]) : sqrt(sig[i]);
@@ -205,7 +327,26 @@ __device__ __forceinline__ SvdLds carve(double* sm) {
   L.tmp = L.gs + 16 * SL; L.sWb = L.tmp + 16 * SL;
   return L;
 }
-size_t svd_filter_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 5 * 16 * SL + 16 * STL + 8 + 16) + 16; }
+// The filter's LDS, sized by the shape: the decompositions are latency-bound (a Jacobi round is a dependent chain of ~2400
+// cycles), so waves per SIMD is throughput -- 11 KB per one-wave workgroup at d = 13, p = 1 (14 per CU) instead of 18.6.
+__device__ __host__ inline int svd_filter_stl(int d, int p) { int r = 2 * d; if (16 + p > r) r = 16 + p; if (p + d > r) r = p + d; return r | 1; }
+__device__ __forceinline__ SvdLds carve_filter(double* sm, int d, int p) {
+  const int n = d > p ? d : p;
+  SvdLds L;
+  L.m = sm; L.a = L.m + 16; L.dc = L.a + 16; L.dr = L.dc + 16; L.sig = L.dr + 16; L.e = L.sig + 16;
+  L.yv = L.e + 16; L.tv = L.yv + 16;
+  L.uc = L.tv + 16; L.ur = L.uc + n * SL; L.V = L.ur + n * SL; L.Wadv = L.V + n * SL;
+  L.sVinv = L.Wadv + d * SL;
+  L.stack = L.sVinv + p * SL;
+  L.idx = (int*)(L.stack + n * svd_filter_stl(d, p));
+  L.gs = L.stack + n * svd_filter_stl(d, p) + 8;
+  L.tmp = nullptr; L.sWb = nullptr;
+  return L;
+}
+size_t svd_filter_lds_bytes(int d, int p) {
+  const int n = d > p ? d : p;
+  return sizeof(double) * (size_t)(8 * 16 + 3 * n * SL + d * SL + p * SL + n * svd_filter_stl(d, p) + 8 + 16) + 16;
+}
 size_t svd_sampler_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 16 * SL + 16 * STL + 8) + 16; }
 
 // ---------------------------------------------------------------------------------------
@@ -215,8 +356,9 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = 2 * d + dd;
-  SvdLds L = carve(sm);
+  SvdLds L = carve_filter(sm, d, p);
   double* stack = L.stack;
+  const int stl = svd_filter_stl(d, p);
   const double* V = a.V + (size_t)n * a.v_stride;
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
@@ -229,12 +371,12 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
   if (a.flags & DLM_OPT_SVD_RAW_W_Q2) {
     for (int k = lane; k < dd; k += 64) M17(L.Wadv, k % d, k / d) = W[k];
     ssync();
-  } else if (sqrt_svd(lane, d, W, false, L.Wadv, stack, L.V, L.sig)) st |= DLM_ST_NOCONV;
-  if (sqrt_svd(lane, p, V, true, L.sVinv, stack, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  } else if (sqrt_svd(lane, d, W, false, L.Wadv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (sqrt_svd(lane, p, V, true, L.sVinv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
   // initialiseState (SvdFilter.scala:83-95): svd(C0) -> dc0 = sqrt(sigma), uc0 = V
   for (int k = lane; k < dd; k += 64) STK(k % d, k / d) = C0[k];
   ssync();
-  if (jacobi_svd(lane, d, d, stack, STL, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (jacobi_svd(lane, d, d, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
   for (int i = lane; i < d; i += 64) { L.m[i] = m0[i]; L.dc[i] = sqrt(L.sig[i]); out[i] = m0[i]; out[d + i] = sqrt(L.sig[i]); }
   for (int k = lane; k < dd; k += 64) { M17(L.uc, k % d, k / d) = M17(L.V, k % d, k / d); out[2 * d + k] = M17(L.V, k % d, k / d); }
   ssync();
@@ -243,6 +385,16 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
   // dropped every 64th step (a rotation product drifts from orthogonality by ~1e-16 per step) and whenever the
   // buffers were used for something else.
   bool warm_r = false, warm_c = false;
+  // Steady state.  On a regular stretch without missing observations the Riccati recursion converges: the posterior
+  // factors a measurement update writes equal the ones it overwrites.  `settled` records that for the last update actually
+  // computed (largest change <= 1e-13 of the largest entry, for uc and for dc); while it holds and the transition is the
+  // same, (ur, dr) ARE the answer, and with the same observation pattern so are (uc, dc): both decompositions are skipped
+  // and only the mean moves.  Anything that disturbs the covariance (a missing observation, another dt, a variance
+  // stream) clears it and the full path resumes.
+  bool have_r = false, have_c = false, reuse_r = false, settled = false;
+  int gprev = -1;
+  double dtprev = 0.0;
+  unsigned long long mask_prev = 0ull;
   int dbg_sw1 = 0, dbg_sw2 = 0;   // sweep counts (reported by the diagnostic build only)
 #ifdef DLM_STAMP
   unsigned long long tj = 0, t0_ = 0, tstart;
@@ -258,19 +410,45 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
     const double* Ft = a.F + (size_t)t * a.f_stride;
     const double dt = a.dt ? a.dt[t] : 1.0;
     if ((t & 63) == 0) { warm_r = false; warm_c = false; }
+    // V_t / W_t streams: step t runs with transformParams(p.copy(v = V_t)) / transformParams(p.copy(w = W_t))
+    // (DlmFsv.ffbsSvd, DlmFsv.scala:208-228; DlmFsvSystem.ffbsSvd, DlmFsvSystem.scala:176-208).  The square roots use
+    // the stack and L.V as scratch: the update step's warm start is gone.
+    if (a.w_tstride) {
+      const double* Wt = W + (size_t)t * a.w_tstride;
+      if (a.flags & DLM_OPT_SVD_RAW_W_Q2) {
+        ssync();
+        for (int k = lane; k < dd; k += 64) M17(L.Wadv, k % d, k / d) = Wt[k];
+        ssync();
+      } else {
+        ssync();
+        if (sqrt_svd(lane, d, Wt, false, L.Wadv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+        warm_c = false;
+      }
+    }
+    if (a.v_tstride) {
+      ssync();
+      if (sqrt_svd(lane, p, V + (size_t)t * a.v_tstride, true, L.sVinv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+      warm_c = false;
+    }
     // advState (SvdFilter.scala:183-202)
     if (dt == 0.0) {
       for (int i = lane; i < d; i += 64) { L.a[i] = L.m[i]; L.dr[i] = L.dc[i]; }
       for (int k = lane; k < dd; k += 64) M17(L.ur, k % d, k / d) = M17(L.uc, k % d, k / d);
       warm_r = false;
       ssync();
+      have_r = false;
+      reuse_r = false;
     } else {
       const double sdt = sqrt(dt);
+      const int gi = a.g_index ? a.g_index[t] : 0;
       for (int i = lane; i < d; i += 64) {
         double s = 0.0;
         for (int k = 0; k < d; ++k) s = fma(Gt[i + k * d], L.m[k], s);
         L.a[i] = s;
       }
+      reuse_r = settled && have_r && gi == gprev && dt == dtprev && !a.w_tstride && !(a.flags & DLM_OPT_FORCE_GENERIC);
+      if (reuse_r) { ssync(); } else {
+      have_r = true; have_c = false; gprev = gi; dtprev = dt;
       for (int k = lane; k < dd; k += 64) {   // stack = [diag(dc) uc^T G^T ; Wadv sqrt(dt)]
         const int i = k % d, j = k / d;
         double s = 0.0;
@@ -280,9 +458,10 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
       }
       ssync();
       SVD_T0
-      { const int rc = jacobi_svd(lane, 2 * d, d, stack, STL, L.ur, L.dr, warm_r); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw1 += rc >> 8; }   // dr = sigma, ur = V
+      { const int rc = jacobi_svd(lane, 2 * d, d, stack, stl, L.ur, L.dr, warm_r); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw1 += rc >> 8; }   // dr = sigma, ur = V
       SVD_T1
       warm_r = true;
+      }
     }
     // updateState (SvdFilter.scala:38-68)
     const double yl = (lane < p) ? y[(size_t)t * p + lane] : __builtin_nan("");
@@ -290,9 +469,12 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
     const int pm = __popcll(mask);
     if (yl == yl) { const int pos = __popcll(mask & ((1ull << lane) - 1ull)); L.idx[pos] = lane; L.yv[pos] = yl; }
     ssync();
+    // same prior factors, same observation pattern, same F and V: (uc, dc) of the step before are the posterior factors
+    const bool reuse_c = reuse_r && have_c && mask == mask_prev && pm > 0 && !a.f_stride && !a.v_tstride;
     if (pm == 0) {
       for (int i = lane; i < d; i += 64) { L.m[i] = L.a[i]; L.dc[i] = L.dr[i]; }
       for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = M17(L.ur, k % d, k / d);
+      have_c = false; settled = false;
     } else {
       // e = y - fm^T a ; tmp(pm x d) = vm fm^T   (vm = sqrtVinv[idx, idx], fm = F[:, idx])
       for (int j = lane; j < pm; j += 64) {
@@ -307,6 +489,7 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
         STK(16 + i, j) = s;                    // vm fm^T, parked in rows 16.. of the stack
       }
       ssync();
+      if (!reuse_c) {
       // stack ((pm + d) x d) = [vm fm^T ur ; diag(1/dr)]
       for (int k = lane; k < pm * d; k += 64) {
         const int i = k % pm, j = k / pm;
@@ -315,20 +498,37 @@ __global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__
         STK(i, j) = s;
       }
       ssync();                                 // rows 16.. are overwritten next
+      if (pm == 1 && !(a.flags & DLM_OPT_FORCE_GENERIC)) {
+        // one observed component: [w^T ; diag(1 / dr)] has A^T A = diag(1 / dr^2) + w w^T -- no Jacobi sweeps (secular_update)
+        const double wj = lane < d ? STK(0, lane) : 0.0;
+        const double rj = lane < d ? 1.0 / L.dr[lane] : 0.0;
+        ssync();
+        SVD_T0
+        secular_update(lane, d, rj * rj, wj, L.V, L.sig, stack);
+        SVD_T1
+        warm_c = false;
+      } else {
       for (int k = lane; k < dd; k += 64) { const int i = k % d, j = k / d; STK(pm + i, j) = (i == j) ? 1.0 / L.dr[i] : 0.0; }
       ssync();
       SVD_T0
-      { const int rc = jacobi_svd(lane, pm + d, d, stack, STL, L.V, L.sig, warm_c); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw2 += rc >> 8; }
+      { const int rc = jacobi_svd(lane, pm + d, d, stack, stl, L.V, L.sig, warm_c); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw2 += rc >> 8; }
       SVD_T1
       warm_c = true;
-      // uc = ur V ; dc = 1 / sigma
+      }
+      // uc = ur V ; dc = 1 / sigma -- and how far they moved (steady-state test)
+      double mxu = 0.0, dfu = 0.0, mxd = 0.0, dfd = 0.0;
       for (int k = lane; k < dd; k += 64) {
         const int i = k % d, j = k / d;
         double s = 0.0;
         for (int l = 0; l < d; ++l) s = fma(M17(L.ur, i, l), M17(L.V, l, j), s);
+        mxu = fmax(mxu, fabs(s)); dfu = fmax(dfu, fabs(s - M17(L.uc, i, j)));
         M17(L.uc, i, j) = s;
       }
-      for (int i = lane; i < d; i += 64) L.dc[i] = 1.0 / L.sig[i];
+      for (int i = lane; i < d; i += 64) { const double v = 1.0 / L.sig[i]; mxd = fmax(mxd, fabs(v)); dfd = fmax(dfd, fabs(v - L.dc[i])); L.dc[i] = v; }
+      for (int o_ = 32; o_ > 0; o_ >>= 1) { mxu = fmax(mxu, __shfl_xor(mxu, o_)); dfu = fmax(dfu, __shfl_xor(dfu, o_)); mxd = fmax(mxd, __shfl_xor(mxd, o_)); dfd = fmax(dfd, __shfl_xor(dfd, o_)); }
+      settled = dfu <= 1e-13 * mxu && dfd <= 1e-13 * mxd;
+      have_c = true; mask_prev = mask;
+      }
       // tv (pm) = vm^T vm e ; gs (d) = fm tv ; gain e = uc dc^2 uc^T gs
       for (int j = lane; j < pm; j += 64) {
         double s = 0.0;
@@ -402,6 +602,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
   const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = 2 * d + dd;
   SvdLds L = carve(sm);
   double* stack = L.stack;
+  constexpr int stl = STL;
   double* th = L.e;      // theta_{t+1}
   double* zv = L.yv;     // normals
   double* ssv = L.dr;    // per-state sum of squares (diag statistics)
@@ -417,7 +618,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
   int st = 0;
 
   // ps.w of SvdSampler.ffbs: sqrtSvd(W) literally (Q9), sqrtInvSvd(W) for the consistent form
-  if (sqrt_svd(lane, d, W, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (sqrt_svd(lane, d, W, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
   for (int i = lane; i < d; i += 64) ssv[i] = 0.0;
   for (int k = lane; k < dd; k += 64) M17(outer, k % d, k / d) = 0.0;
   for (int i = lane; i < 32; i += 64) ssy[i] = 0.0;
@@ -462,6 +663,9 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
     }
     for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = r[2 * d + k];
     ssync();
+    if (a.w_tstride) {   // the step from record t uses W_t, the transition into observation t (DlmFsvSystem.scala:196-205)
+      if (sqrt_svd(lane, d, W + (size_t)t * a.w_tstride, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+    }
     // a_{t+1} = G m_t ; tmp = sqrtWb G
     for (int i = lane; i < d; i += 64) {
       double s = 0.0;
@@ -484,7 +688,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
       STK(d + i, j) = (i == j) ? 1.0 / L.dc[i] : 0.0;
     }
     ssync();
-    if (jacobi_svd(lane, 2 * d, d, stack, STL, L.V, L.sig)) st |= DLM_ST_NOCONV;
+    if (jacobi_svd(lane, 2 * d, d, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
     // uh = uc V -> Wadv buffer ; dh = 1/sigma -> tv
     for (int k = lane; k < dd; k += 64) {
       const int i = k % d, j = k / d;

@@ -88,7 +88,8 @@ typedef struct {
  * Time-varying variances (the per-step V_t / W_t streams of StudentT.filter, StudentTGibbs.scala:100-136,
  * and of DlmFsvSystem.ffbs, DlmFsvSystem.scala:137-208): with v_tstride / w_tstride != 0 observation t (0-based) uses
  * V + n * v_stride + t * v_tstride and the transition INTO observation t uses W + n * w_stride + t * w_tstride
- * (T matrices each).  0 = time-invariant.  Not available on the SVD entry points (DLM_ERR_UNSUPPORTED). */
+ * (T matrices each).  0 = time-invariant.  The SVD entry points take them too: step t then runs with the square roots
+ * of V_t / W_t (DlmFsv.ffbsSvd, DlmFsv.scala:208-228; DlmFsvSystem.ffbsSvd, DlmFsvSystem.scala:176-208). */
 typedef struct {
   const double *V;  int64_t v_stride;   /* p x p */
   const double *W;  int64_t w_stride;   /* d x d */

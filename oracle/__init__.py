@@ -201,26 +201,29 @@ def sqrt_svd(Mx, inverse=False):
 
 
 def svd_filter(M, V, W, m0, C0, y, raw_w_q2=False):
+    """SvdFilter (SvdFilter.scala:38-95, :183-236).  V / W may be [T] streams of matrices (DlmFsv.ffbsSvd, DlmFsvSystem.ffbsSvd)."""
     d, p, T = M.d, M.p, M.T
     y = np.ascontiguousarray(y, dtype=np.float64).reshape(T, p)
     out = {"m": np.empty((T + 1, d)), "dc": np.empty((T + 1, d)), "uc": np.empty((T + 1, d * d)),
            "a": np.empty((T + 1, d)), "dr": np.empty((T + 1, d)), "ur": np.empty((T + 1, d * d))}
-    V, W, m0, C0 = cm(V), cm(W), cm(m0), cm(C0)
-    lib().oracle_svd_filter(d, p, T, _p(M.F), ctypes.c_long(M.f_stride), _p(M.G), _pi(M.g_index),
-                            _p(M.dt), _p(V), _p(W), _p(m0), _p(C0), _p(y), int(bool(raw_w_q2)),
-                            _p(out["m"]), _p(out["dc"]), _p(out["uc"]), _p(out["a"]),
-                            _p(out["dr"]), _p(out["ur"]))
+    (Vf, vts), (Wf, wts) = _tv(V, p), _tv(W, d)
+    m0, C0 = cm(m0), cm(C0)
+    lib().oracle_svd_filter_tv(d, p, T, _p(M.F), ctypes.c_long(M.f_stride), _p(M.G), _pi(M.g_index),
+                               _p(M.dt), _p(Vf), ctypes.c_long(vts), _p(Wf), ctypes.c_long(wts), _p(m0), _p(C0), _p(y), int(bool(raw_w_q2)),
+                               _p(out["m"]), _p(out["dc"]), _p(out["uc"]), _p(out["a"]),
+                               _p(out["dr"]), _p(out["ur"]))
     return out
 
 
 def svd_backward_sample(M, W, sf, z, literal_q9=True):
+    """SvdSampler (SvdSampler.scala:15-60).  W may be a [T] stream (the step from record t uses W_t)."""
     d, T = M.d, M.T
     z = np.ascontiguousarray(z, dtype=np.float64).reshape(T + 1, d)
     theta = np.empty((T + 1, d)); h = np.empty((T + 1, d))
     dh = np.empty((T + 1, d)); uh = np.empty((T + 1, d * d))
-    W = cm(W)
-    lib().oracle_svd_backward_sample(d, T, _p(M.G), _pi(M.g_index), _p(W), _p(sf["m"]), _p(sf["dc"]),
-                                     _p(sf["uc"]), _p(sf["a"]), _p(z), int(bool(literal_q9)), _p(theta), _p(h), _p(dh), _p(uh))
+    Wf, wts = _tv(W, d)
+    lib().oracle_svd_backward_sample_tv(d, T, _p(M.G), _pi(M.g_index), _p(Wf), ctypes.c_long(wts), _p(sf["m"]), _p(sf["dc"]),
+                                        _p(sf["uc"]), _p(sf["a"]), _p(z), int(bool(literal_q9)), _p(theta), _p(h), _p(dh), _p(uh))
     return {"theta": theta, "h": h, "dh": dh, "uh": uh}
 
 

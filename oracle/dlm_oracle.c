@@ -691,11 +691,14 @@ void oracle_sqrt_svd(int n, const double *Mx, int inverse, double *out) {
   free(A); free(sig); free(Vt);
 }
 
-void oracle_svd_filter(int d, int p, int T, const double *F, long f_stride, const double *G,
-                       const int *g_index, const double *dts, const double *V, const double *W,
-                       const double *m0, const double *C0, const double *y, int raw_w_q2,
-                       double *m_out, double *dc_out, double *uc_out, double *a_out,
-                       double *dr_out, double *ur_out) {
+/* V_t / W_t streams (v_tstride / w_tstride != 0): step t runs with transformParams(p.copy(v = V_t)) or
+ * transformParams(p.copy(w = W_t)) -- DlmFsv.ffbsSvd (DlmFsv.scala:208-228), DlmFsvSystem.ffbsSvd
+ * (DlmFsvSystem.scala:176-208): observation t uses V + t v_tstride, the transition into it W + t w_tstride. */
+void oracle_svd_filter_tv(int d, int p, int T, const double *F, long f_stride, const double *G,
+                          const int *g_index, const double *dts, const double *V, long v_tstride, const double *W,
+                          long w_tstride, const double *m0, const double *C0, const double *y, int raw_w_q2,
+                          double *m_out, double *dc_out, double *uc_out, double *a_out,
+                          double *dr_out, double *ur_out) {
   model_t M = {d, p, T, F, f_stride, G, g_index, dts};
   const int dd = d * d;
   double *sqrtVinv = malloc(sizeof(double) * p * p), *sqrtW = malloc(sizeof(double) * dd);
@@ -731,6 +734,12 @@ void oracle_svd_filter(int d, int p, int T, const double *F, long f_stride, cons
     double *ucn = uc_out + (size_t)(t + 1) * dd;
     const double *Ft = F_at(&M, t), *Gt = G_at(&M, t);
     const double dt = dt_at(&M, t);
+    if (w_tstride) {
+      const double *Wt = W + (size_t)t * w_tstride;
+      oracle_sqrt_svd(d, Wt, 0, sqrtW);
+      Wadv = raw_w_q2 ? Wt : sqrtW;
+    }
+    if (v_tstride) oracle_sqrt_svd(p, V + (size_t)t * v_tstride, 1, sqrtVinv);
     /* advState: SvdFilter.scala:183-202 */
     if (dt == 0.0) {
       memcpy(a, m, sizeof(double) * d); memcpy(dr, dc, sizeof(double) * d);
@@ -794,6 +803,14 @@ void oracle_svd_filter(int d, int p, int T, const double *F, long f_stride, cons
   free(gain); free(VtV); free(idx);
 }
 
+void oracle_svd_filter(int d, int p, int T, const double *F, long f_stride, const double *G,
+                       const int *g_index, const double *dts, const double *V, const double *W,
+                       const double *m0, const double *C0, const double *y, int raw_w_q2,
+                       double *m_out, double *dc_out, double *uc_out, double *a_out,
+                       double *dr_out, double *ur_out) {
+  oracle_svd_filter_tv(d, p, T, F, f_stride, G, g_index, dts, V, 0, W, 0, m0, C0, y, raw_w_q2, m_out, dc_out, uc_out, a_out, dr_out, ur_out);
+}
+
 /* ------------------------------------------------------------------ */
 /* SVD backward sampler: SvdSampler.scala:15-60, rnorm :94-102.          */
 /* Inputs: SVD filter records (m, dc, uc, a); sqrtW = sqrtSvd(W).         */
@@ -807,11 +824,13 @@ void oracle_svd_filter(int d, int p, int T, const double *F, long f_stride, cons
 /* the two coincide.  literal_q9 != 0 restates the reference; 0 uses       */
 /* sqrtInvSvd(W), the form that agrees with Smoothing.step.                */
 /* ------------------------------------------------------------------ */
-void oracle_svd_backward_sample(int d, int T, const double *G, const int *g_index,
-                                const double *W, const double *m, const double *dc,
-                                const double *uc, const double *a, const double *z,
-                                int literal_q9, double *theta, double *h_out, double *dh_out,
-                                double *uh_out) {
+/* w_tstride != 0: the backward step from record t uses W + t w_tstride (the transition into observation t),
+ * as DlmFsvSystem.ffbsSvd zips ps with filtered.init (DlmFsvSystem.scala:196-205). */
+void oracle_svd_backward_sample_tv(int d, int T, const double *G, const int *g_index,
+                                   const double *W, long w_tstride, const double *m, const double *dc,
+                                   const double *uc, const double *a, const double *z,
+                                   int literal_q9, double *theta, double *h_out, double *dh_out,
+                                   double *uh_out) {
   const int dd = d * d;
   double *sqrtW = malloc(sizeof(double) * dd);
   oracle_sqrt_svd(d, W, literal_q9 ? 0 : 1, sqrtW);
@@ -839,6 +858,7 @@ void oracle_svd_backward_sample(int d, int T, const double *G, const int *g_inde
     const double *Gn = G + (size_t)(g_index ? g_index[t] : 0) * dd;
     const double *mt = m + (size_t)t * d, *dct = dc + (size_t)t * d, *uct = uc + (size_t)t * dd;
     const double *a1 = a + (size_t)(t + 1) * d, *thn = theta + (size_t)(t + 1) * d;
+    if (w_tstride) oracle_sqrt_svd(d, W + (size_t)t * w_tstride, literal_q9 ? 0 : 1, sqrtW);
     /* root = svd([sqrtW * g * uc ; diag(1/dc)]) : SvdSampler.scala:19-21 */
     mm(d, d, d, sqrtW, d, 0, Gn, d, 0, t1, d);
     mm(d, d, d, t1, d, 0, uct, d, 0, t2, d);
@@ -871,6 +891,14 @@ void oracle_svd_backward_sample(int d, int T, const double *G, const int *g_inde
   }
   free(sqrtW); free(stack); free(sig); free(Vt); free(t1); free(t2); free(uh); free(dh);
   free(u); free(v1); free(v2);
+}
+
+void oracle_svd_backward_sample(int d, int T, const double *G, const int *g_index,
+                                const double *W, const double *m, const double *dc,
+                                const double *uc, const double *a, const double *z,
+                                int literal_q9, double *theta, double *h_out, double *dh_out,
+                                double *uh_out) {
+  oracle_svd_backward_sample_tv(d, T, G, g_index, W, 0, m, dc, uc, a, z, literal_q9, theta, h_out, dh_out, uh_out);
 }
 
 /* ------------------------------------------------------------------ */

@@ -1740,3 +1740,45 @@ def test_gibbs_sample_svd_and_device_resident_pooled_chain(eng):
         np.testing.assert_allclose(a.p.v, b.p.v, rtol=1e-10)
         np.testing.assert_allclose(a.p.w, b.p.w, rtol=1e-10)
     assert hasattr(devc[-1].stats, "data_ptr")          # the per-series statistics stayed on the device
+
+
+@pytest.mark.parametrize("stream", ["w", "v", "w_literal"])
+def test_svd_filter_and_sampler_with_variance_streams(eng, stream):
+    """V_t / W_t streams on the SVD path (second half): DlmFsvSystem.ffbsSvd feeds
+    transformParams(p.copy(w = W_t)) to SvdFilter.step / SvdSampler.step (DlmFsvSystem.scala:176-208), DlmFsv.ffbsSvd
+    the same with V_t (DlmFsv.scala:208-228).  Against the oracle with per-step parameters, and -- the consistent form --
+    against the standard Kalman filter with the same streams."""
+    rng = np.random.default_rng(12)
+    mod = Dlm.polynomial(1) + Dlm.seasonal(12, 2)
+    T, d, N = 30, 5, 2
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    base_w = np.diag([0.05, 0.3, 0.2, 0.4, 0.1])
+    if stream.startswith("w"):
+        A = rng.standard_normal((T, d, d)) * 0.15
+        W = base_w[None] * (1.0 + 0.5 * rng.random((T, 1, 1))) + A @ A.transpose(0, 2, 1)      # dense SPD, different every step
+        V = np.array([[1.2]])
+    else:
+        W = base_w
+        V = (0.5 + rng.random((T, 1, 1)) * 2.0)
+    literal = stream == "w_literal"
+    p = DlmParameters(V, W, np.zeros(d), np.diag(np.linspace(0.5, 2.0, d)))
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1)
+    y[rng.random(y.shape) < 0.1] = np.nan
+    flags = (_lib.OPT_SVD_RAW_W_Q2 | _lib.OPT_SVD_SAMPLER_Q9) if literal else 0
+    out = eng.svd_filter(mat, p, y, flags=flags)
+    assert eng.last_variant == "svd-jacobi" and np.all(out["status"] == 0)
+    z = rng.standard_normal((N, T + 1, d))
+    draw = eng.svd_ffbs(mat, p, y, z=z, flags=flags)
+    om = omodel(mat)
+    for n in range(N):
+        o = oracle.svd_filter(om, V, W, p.m0, p.c0, y[n], raw_w_q2=literal)
+        m, C = _svd_cov(out["svd"][n], d)
+        om_, oC = _svd_cov(np.concatenate([o["m"], o["dc"], o["uc"]], axis=1), d)
+        np.testing.assert_allclose(m, om_, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(C, oC, rtol=1e-7, atol=1e-8)
+        ob = oracle.svd_backward_sample(om, W, o, z[n], literal_q9=literal)
+        np.testing.assert_allclose(draw["theta"][n], ob["theta"], rtol=1e-6, atol=1e-7)
+        if not literal:
+            kf = oracle.kf_filter(om, V, W, p.m0, p.c0, y[n])
+            np.testing.assert_allclose(m, kf["m"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(C.transpose(0, 2, 1).reshape(T + 1, d * d), kf["C"], rtol=1e-6, atol=1e-7)

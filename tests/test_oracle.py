@@ -418,3 +418,31 @@ def test_simulate_moments_and_consistency():
     ll = materialise(Dlm.polynomial(1), np.arange(1, 3, dtype=np.float64))
     ys = np.array([oracle.simulate(_omodel(ll), [[2.0]], [[0.5]], [1.0], [[3.0]], 1, n)[1][0, 0] for n in range(4000)])
     assert abs(ys.mean() - 1.0) < 0.15 and abs(ys.var() - 5.5) < 0.5
+
+
+def test_svd_filter_with_variance_streams_is_the_kalman_filter():
+    """V_t / W_t streams on the oracle's SVD path (DlmFsvSystem.ffbsSvd, DlmFsv.ffbsSvd): with the square roots taken per
+    step the SVD filter's U D^2 U^T must equal the standard filter's C under the same streams (the identity the
+    reference's SvdFilterTest checks for constant parameters, core/src/test/scala/SvdFilter.scala:145-157)."""
+    from bayesian_dlms_amd.dlm import Dlm, materialise
+    rng = np.random.default_rng(5)
+    mod = Dlm.polynomial(2) + Dlm.seasonal(12, 1)
+    T, d = 25, 4
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    M = oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+    A = rng.standard_normal((T, d, d)) * 0.2
+    W = np.eye(d)[None] * 0.3 + A @ A.transpose(0, 2, 1)
+    V = 0.5 + rng.random((T, 1, 1))
+    y = rng.standard_normal((T, 1)).cumsum(axis=0)
+    y[[4, 11]] = np.nan
+    sf = oracle.svd_filter(M, V, W, np.zeros(d), np.eye(d) * 2.0, y)
+    kf = oracle.kf_filter(M, V, W, np.zeros(d), np.eye(d) * 2.0, y)
+    np.testing.assert_allclose(sf["m"], kf["m"], rtol=1e-8, atol=1e-9)
+    for t in range(T + 1):
+        U = oracle.from_cm(sf["uc"][t], d, d)
+        np.testing.assert_allclose(U @ np.diag(sf["dc"][t] ** 2) @ U.T, oracle.from_cm(kf["C"][t], d, d), rtol=1e-8, atol=1e-9)
+    # the sampler with zero noise and per-step W reproduces the RTS mean of the same model
+    z = np.zeros((T + 1, d))
+    th = oracle.svd_backward_sample(M, W, sf, z, literal_q9=False)["theta"]
+    np.testing.assert_allclose(th[T], kf["m"][T], rtol=1e-8, atol=1e-9)
+    assert np.all(np.isfinite(th))
