@@ -804,6 +804,11 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     HIP_TRY(e, dlm::launch_small_mv_sampler(k, e->stream));
     return done();
   }
+  if (!(k.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16)) && dlm::wave48_sampler_supported(k)) {
+    e->variant = "wave-sampler";
+    HIP_TRY(e, dlm::launch_wave48_sampler(k, e->stream));
+    return done();
+  }
   e->variant = "generic";
   HIP_TRY(e, dlm::launch_generic_sampler(k, e->stream));
   return done();

@@ -102,6 +102,8 @@ bool wave48_smoother_supported(const KArgs& a);
 hipError_t launch_wave48_smoother(const KArgs& a, int K, const double* innov, hipStream_t s);
 bool wave48_simsmooth_supported(const KArgs& a);
 hipError_t launch_wave48_simsmooth(const KArgs& a, int K, double* xplus, double* ystar, hipStream_t s);
+bool wave48_sampler_supported(const KArgs& a);   // the reference-form backward sampler on register tiles (16 <= d <= 48, structured G)
+hipError_t launch_wave48_sampler(const KArgs& a, hipStream_t s);
 // simulation-smoother FFBS (forward SIM pass + mean-only backward pass); xplus [N][T+1][d], ystar [N][T][p]
 hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s);
 

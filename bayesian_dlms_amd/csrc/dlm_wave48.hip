@@ -1481,7 +1481,445 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
+// ---------------------------------------------------------------------------------------
+// The reference's backward sampler (Smoothing.sampleDlm / Smoothing.step, Smoothing.scala:74-122) for 16 <= d <= 48 on
+// register tiles: dlm_sampler16.hip's kernel with DT x DT tiles per matrix.  Per step t = T-1 .. 0, given theta_{t+1}:
+//   a+ = G m, R+ = G C G^T + W dt (dt == 0: a+ = m, R+ = C);  J = C G^T R+^-1 (always the table entry g(dt));
+//   h = m + J (theta_{t+1} - a+);  H = (I - J G) C (I - J G)^T + dt J W J^T, symmetrised;  theta_t = h + chol(H) z_t
+// with the conditional-moment records and the Gibbs statistics (diagonal or outer product) of k_sampler_generic, whose
+// draws it reproduces.  Products are MFMA chains on the tiles (X^T Y, as everywhere in this file), the three products
+// with G gathers through the image, R+^-1 the warm-started Newton-Schulz refinement, the factor of H is taken with lane i
+// holding row i in registers (pivots and multipliers by v_readlane: no LDS round trip on the d dependent pivots).
+// Once the filtered covariance has stopped moving (|C_t - C| <= 1e-13 max|C| against the last step computed in full), J, H
+// and the factor are reused and a step is a gather, two matrix-vector products and the draw.
+// LDS per wave: two images (scratch; the second also keeps the factor L in its lower triangle and the comparison copy of
+// C in its strict upper triangle) and six vectors -- 39 KB at DT = 3: four series per CU.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane((int)__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane((int)__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+template <int DT, int K, bool OUTER>
+__global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int IL = 16 * DT + 1, IMG = 16 * DT * IL, VL = 16 * DT, ND = 16 * DT;
+  double* img = sm;       double* keep = sm + IMG;      // keep: direct-inverse scratch; afterwards L (lower + diagonal) and C (strict upper)
+  double* mv = keep + IMG; double* thv = mv + VL; double* uv = thv + VL; double* hv = uv + VL; double* zv = hv + VL; double* cdv = zv + VL;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  for (int i = lane; i < 6 * VL; i += 64) mv[i] = 0.0;
+
+  bool jd[DT];
+  int cpart[DT], moff[DT];
+#pragma unroll
+  for (int b = 0; b < DT; ++b) { jd[b] = 16 * b + c < d; cpart[b] = (d + (16 * b + c) * d) * 8; moff[b] = (jd[b] && g == 0) ? (16 * b + c) * 8 : OOB; }
+  int rix[DT][K], cix[DT][K];       // nonzeros of the lanes' ROWS / COLUMNS of G
+  double rvl[DT][K], cvl[DT][K];
+  int gcur = -1;
+  auto load_tables = [&](int gi) {
+    const SparseBig* tr = a.spb + 2 * gi;
+    const SparseBig* tc = a.spb + 2 * gi + 1;
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        rix[b][s] = tr->idx[16 * b + c][s]; rvl[b][s] = jd[b] ? tr->val[16 * b + c][s] : 0.0;
+        cix[b][s] = tc->idx[16 * b + c][s]; cvl[b][s] = jd[b] ? tc->val[16 * b + c][s] : 0.0;
+      }
+    gcur = gi;
+  };
+  const double* W0 = a.W + (size_t)n * a.w_stride;
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  double* cond = a.cond ? a.cond + (size_t)n * (T + 1) * rec : nullptr;
+  const __amdgpu_buffer_rsrc_t rco = mk_rsrc(cond, cond ? (size_t)(T + 1) * recb : 0);
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  const double* y = a.y ? a.y + (size_t)n * T * p : nullptr;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * d : nullptr;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  int st = 0;
+
+  auto load_record = [&](d4 (&C)[DT][DT], int t, int g, int c) {
+    const int so = t * recb;
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g;
+          C[aa][b][r] = bld(rin, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so);
+        }
+    if (lane < ND) mv[lane] = bld(rin, lane < d ? lane * 8 : OOB, so);
+  };
+  auto load_W = [&](d4 (&Wt)[DT][DT], const double* Wp, int g, int c) {
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+          Wt[aa][b][r] = (i < d && jd[b]) ? Wp[i + j * d] : 0.0;
+        }
+  };
+  // lower Cholesky factor of the symmetric matrix in `img` (rows by lanes, in registers), written to the lower triangle of `keep`
+  auto factor_to_keep = [&]() {
+    double row[ND];
+    const double* src = img + (lane < ND ? lane : 0) * IL;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) row[j] = src[j];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      if (k < d) {
+        const double akk = readlane_d(row[k], k);
+        const bool np = !(akk > 0.0);
+        bad |= np;
+        double inv = __builtin_amdgcn_rsq(np ? 1.0 : akk);
+        inv = inv * fma(-0.5 * akk * inv, inv, 1.5);
+        inv = inv * fma(-0.5 * akk * inv, inv, 1.5);
+        inv = np ? 0.0 : inv;
+        const double lik = row[k] * inv;
+        row[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < ND; ++j)
+          if (j < d) row[j] = fma(-lik, readlane_d(lik, j), row[j]);
+      }
+    if (bad) st |= DLM_ST_NOT_PD;
+    wave_sync();
+    if (lane < d) {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) if (j <= lane) keep[lane * IL + j] = row[j];
+    }
+    wave_sync();
+  };
+  // theta = h + L z from the factor in `keep`; hv holds h, zv the normals; returns this lane's component (lane < d)
+  auto draw = [&]() {
+    double th = 0.0;
+    if (lane < d) {
+      th = hv[lane];
+      const double* Lr = keep + lane * IL;
+      for (int k = 0; k <= lane; ++k) th = fma(Lr[k], zv[k], th);
+    }
+    return th;
+  };
+  auto store_cond = [&](const d4 (&H)[DT][DT], int t, int g, int c) {
+    const int so = t * recb;
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * aa + 4 * r + g;
+          bst(rco, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so, H[aa][b][r]);
+        }
+    if (lane < ND) bst(rco, lane < d ? lane * 8 : OOB, so, hv[lane]);
+  };
+
+  // Persistent tiles: the Newton-Schulz warm start and (GibbsWishart) the outer-product statistics.  J^T of the last full
+  // step lives in `img` (the steady-state path uses the image for nothing else) -- a step that recomputes it may use the
+  // image as scratch again.
+  d4 Rinv[DT][DT], OUT[OUTER ? DT : 1][OUTER ? DT : 1];
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b) Rinv[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int aa = 0; aa < (OUTER ? DT : 1); ++aa)
+#pragma unroll
+    for (int b = 0; b < (OUTER ? DT : 1); ++b) OUT[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+  double ssd[DT];
+#pragma unroll
+  for (int b = 0; b < DT; ++b) ssd[b] = 0.0;
+  double ssy = 0.0, nob = 0.0;
+  bool warm = false, have = false;
+  int gprev = -1;
+  double dtprev = 0.0, cmaxp = 0.0;
+#ifdef DLM_STAMP
+  int n_reuse = 0;      // diagnostic build: steps that took the steady-state path, reported in status[n] >> 8
+#endif
+
+  {   // theta_T ~ N(m_T, C_T)
+    d4 C[DT][DT];
+    load_record(C, T, g, c);
+    to_image<IL, DT, DT>(C, keep, g, c);
+    if (lane < ND) { zv[lane] = lane < d ? (zin ? zin[(size_t)T * d + lane] : philox_normal(a.seed, series, (unsigned)T, (unsigned)lane)) : 0.0; }
+    wave_sync();
+    if (lane < ND) hv[lane] = mv[lane];
+    if (chol_rows(keep, d, IL, lane)) st |= DLM_ST_NOT_PD;   // once per series: the in-LDS factorisation (psd pivots: see below)
+    wave_sync();
+    if (cond) store_cond(C, T, g, c);
+    const double th = draw();
+    wave_sync();
+    if (lane < ND) thv[lane] = lane < d ? th : 0.0;
+    if (thout && lane < d) thout[(size_t)T * d + lane] = th;
+    wave_sync();
+  }
+
+  for (int t = T - 1; t >= 0; --t) {
+    int g_ = g, c_ = c;
+    asm volatile("" : "+v"(g_), "+v"(c_));
+    {
+    const int g = g_, c = c_;
+    const double dt = a.dt ? a.dt[t] : 1.0;
+    const int gi = a.g_index ? a.g_index[t] : 0;
+    if (gi != gcur) load_tables(gi);
+    if (a.stats && y && lane < p) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
+      const double yv = y[(size_t)t * p + lane];
+      if (yv == yv) {
+        const double* Fj = a.F + (size_t)t * a.f_stride + (size_t)lane * d;
+        double f = 0.0;
+        for (int k = 0; k < d; ++k) f = fma(Fj[k], thv[k], f);
+        ssy += (yv - f) * (yv - f); nob += 1.0;
+      }
+    }
+    if (lane < ND) zv[lane] = lane < d ? (zin ? zin[(size_t)t * d + lane] : philox_normal(a.seed, series, (unsigned)t, (unsigned)lane)) : 0.0;
+    // steady state: C against the copy kept from the last full step (strict upper triangle of `keep`, diagonal in cdv)
+    bool reuse = false;
+    {
+      d4 C[DT][DT];
+      load_record(C, t, g, c);
+      wave_sync();
+    if (have && gi == gprev && dt == dtprev && !a.w_tstride) {
+      bool moved = false;
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+            if (i < d && j < d) {
+              const double old = (i == j) ? cdv[i] : (i < j ? keep[i * IL + j] : keep[j * IL + i]);
+              moved |= !(fabs(C[aa][b][r] - old) <= 1e-13 * cmaxp);
+            }
+          }
+      reuse = __ballot(moved) == 0ull;
+    }
+    }
+    double a1[DT];
+    if (dt != 0.0) gather_vec<DT, K>(mv, rix, rvl, a1);
+    else {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) a1[b] = mv[16 * b + c];
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) uv[16 * b + c] = jd[b] ? thv[16 * b + c] - a1[b] : 0.0;
+    }
+    wave_sync();
+    double hc[DT];
+    if (reuse) {
+#ifdef DLM_STAMP
+      ++n_reuse;
+#endif
+      d4 JTl[DT][DT];
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) JTl[aa][b][r] = img[(16 * aa + 4 * r + g) * IL + 16 * b + c];
+      matTvec<DT, DT>(JTl, uv, g, hc);
+    } else {
+      // R+ = G C G^T + W dt on a copy of C (the congruence works in place), exactly symmetric.  C itself is fetched again
+      // when it is next needed (the record is in L2): holding it across the inverse costs 24 registers per tile.
+      d4 R[DT][DT];
+      load_record(R, t, g, c);
+      if (dt != 0.0) {
+        d4 Wt[DT][DT];
+        load_W(Wt, W0 + (size_t)t * a.w_tstride, g, c);
+        congruence<IL, DT, K, true>(R, Wt, dt, rix, rvl, img, g, c);
+      }
+      if (spd_inverse_warm<IL, DT>(R, Rinv, d, warm, img, keep, lane, g, c)) st |= DLM_ST_NOT_PD;
+      warm = true;
+      // G C = (C G^T)^T: pass 1 of the congruence on the image of C, read back transposed
+      d4 C[DT][DT], GC[DT][DT];
+      load_record(C, t, g, c);
+      {   // remember C (strict upper triangle of `keep` -- the inverse is done with it --, diagonal in cdv) and its scale
+        double mx = 0.0;
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+              if (i < d && j < d) {
+                mx = fmax(mx, fabs(C[aa][b][r]));
+                if (i < j) keep[i * IL + j] = C[aa][b][r];
+                if (i == j) cdv[i] = C[aa][b][r];
+              }
+            }
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mx = fmax(mx, __shfl_xor(mx, o_));
+        cmaxp = mx;
+      }
+      to_image<IL, DT, DT>(C, img, g, c);
+      wave_sync();
+      {
+        d4 T1[DT][DT];
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double* row = img + (16 * aa + 4 * r + g) * IL;
+              double s_ = 0.0;
+#pragma unroll
+              for (int s = 0; s < K; ++s) s_ = fma(row[rix[b][s]], rvl[b][s], s_);
+              T1[aa][b][r] = s_;
+            }
+        wave_sync();
+        transpose<IL, DT, DT>(T1, GC, img, g, c);
+      }
+      d4 JT[DT][DT];
+      mmT<DT, DT, DT, false>(Rinv, GC, JT, d);            // J^T = R+^-1 G C
+      matTvec<DT, DT>(JT, uv, g, hc);
+      // Dm = I - J G: J (= J^T transposed into the image), gathered with the COLUMN tables of G
+      d4 DmT[DT][DT];
+      {
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[(16 * b + c) * IL + 16 * aa + 4 * r + g] = JT[aa][b][r];
+        wave_sync();
+        d4 Dm[DT][DT];
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+              const double* row = img + i * IL;
+              double s_ = 0.0;
+#pragma unroll
+              for (int s = 0; s < K; ++s) s_ = fma(row[cix[b][s]], cvl[b][s], s_);
+              Dm[aa][b][r] = ((i == j && j < d) ? 1.0 : 0.0) - s_;
+            }
+        wave_sync();
+        transpose<IL, DT, DT>(Dm, DmT, img, g, c);
+      }
+      d4 H[DT][DT];
+      {
+        d4 CD[DT][DT];
+        mmT<DT, DT, DT, false>(C, DmT, CD, d);            // C Dm^T
+        mmT<DT, DT, DT, false>(DmT, CD, H, d);            // Dm C Dm^T
+      }
+      if (dt != 0.0) {
+        d4 Wt[DT][DT], WJ[DT][DT], H2[DT][DT];
+        load_W(Wt, W0 + (size_t)t * a.w_tstride, g, c);
+        mmT<DT, DT, DT, false>(Wt, JT, WJ, d);            // W J^T
+        mmT<DT, DT, DT, false>(JT, WJ, H2, d);            // J W J^T
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H[aa][b][r] = fma(H2[aa][b][r], dt, H[aa][b][r]);
+      }
+      mirror<IL, DT, true, false>(H, img, g, c);           // (H + H^T) / 2 (Smoothing.scala:95)
+      if (cond) {
+        if (g == 0) {
+#pragma unroll
+          for (int b = 0; b < DT; ++b) hv[16 * b + c] = jd[b] ? mv[16 * b + c] + hc[b] : 0.0;
+        }
+        wave_sync();
+        store_cond(H, t, g, c);
+      }
+      to_image<IL, DT, DT>(H, img, g, c);
+      wave_sync();
+      factor_to_keep();
+      have = true; gprev = gi; dtprev = dt;
+      wave_sync();
+      to_image<IL, DT, DT>(JT, img, g, c);                // J^T stays in the image for the steady-state steps that follow
+      wave_sync();
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) hv[16 * b + c] = jd[b] ? mv[16 * b + c] + hc[b] : 0.0;      // h = m + J (theta+ - a+)
+    }
+    wave_sync();
+    if (cond && reuse) {   // same conditional covariance as the step before: copy it from that record
+      d4 Hc[DT][DT];
+      const int so = (t + 1) * recb;
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g;
+            Hc[aa][b][r] = bld(rco, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so);
+          }
+      store_cond(Hc, t, g, c);
+    }
+    const double th = draw();
+    wave_sync();
+    if (lane < ND) hv[lane] = lane < d ? th : 0.0;        // hv <- theta_t
+    wave_sync();
+    if (a.stats) {   // system residual theta_{t+1} - G theta_t (always the table entry)
+      double gth[DT];
+      gather_vec<DT, K>(hv, rix, rvl, gth);
+      const double dts = (dt == 0.0) ? 1.0 : dt;
+      double df[DT];
+#pragma unroll
+      for (int b = 0; b < DT; ++b) { df[b] = jd[b] ? thv[16 * b + c] - gth[b] : 0.0; ssd[b] += df[b] * df[b] / dts; }
+      if (OUTER) {
+        if (g == 0) {
+#pragma unroll
+          for (int b = 0; b < DT; ++b) uv[16 * b + c] = df[b];
+        }
+        wave_sync();
+#pragma unroll
+        for (int aa = 0; aa < (OUTER ? DT : 1); ++aa)
+#pragma unroll
+          for (int b = 0; b < (OUTER ? DT : 1); ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) OUT[aa][b][r] += uv[16 * aa + 4 * r + g] * df[b] / dts;
+      }
+    }
+    wave_sync();
+    if (lane < ND) thv[lane] = hv[lane];
+    if (thout && lane < d) thout[(size_t)t * d + lane] = th;
+    wave_sync();
+    }
+  }
+  if (__ballot(lane < d && !isfinite(thv[lane < ND ? lane : 0])) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.stats) {
+    const int L = stats_len(d, p, a.flags);
+    double* so = a.stats + (size_t)n * L;
+    if (lane < p) { so[lane] = ssy; so[p + lane] = nob; }
+    if (lane == 0) so[L - 1] = (double)T;
+    if (OUTER) {
+#pragma unroll
+      for (int aa = 0; aa < (OUTER ? DT : 1); ++aa)
+#pragma unroll
+        for (int b = 0; b < (OUTER ? DT : 1); ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+            if (i < d && j < d) so[2 * p + i + j * d] = OUT[aa][b][r];
+          }
+    } else if (g == 0) {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (jd[b]) so[2 * p + 16 * b + c] = ssd[b];
+    }
+  }
+#ifdef DLM_STAMP
+  st |= n_reuse << 8;
+#endif
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
 }  // namespace w48
+
 
 // The per-wave kernels take the structured-G models; a dense G stays on dlm_tiled.hip.
 // One wave per series needs more series than the chip has SIMDs to pay off: up to one series per CU (N <= 256) the
@@ -1606,6 +2044,27 @@ hipError_t launch_wave48_simsmooth(const KArgs& a, int K, double* xplus, double*
   if (d2) return launch_w48_sims_k<2, 2>(b, K, xplus, ystar, s);
   if (p1) return launch_w48_sims_k<3, 1>(b, K, xplus, ystar, s);
   return launch_w48_sims_k<3, 2>(b, K, xplus, ystar, s);
+}
+
+// reference-form backward sampler on register tiles, 16 <= d <= 48 with a structured G (a.filt_in -> theta / cond / stats)
+bool wave48_sampler_supported(const KArgs& a) { return tiled_supported(a) && a.spb && wave48_wanted(a); }
+
+template <int DT>
+static hipError_t launch_w48_sampler_k(const KArgs& a, int K, hipStream_t s) {
+  const size_t lds = sizeof(double) * (size_t)(2 * 16 * DT * (16 * DT + 1) + 6 * 16 * DT);
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0 && a.stats;
+  if (K <= 2) {
+    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, true>), dim3(a.N), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, false>), dim3(a.N), dim3(64), lds, s, a);
+  } else {
+    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, true>), dim3(a.N), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, false>), dim3(a.N), dim3(64), lds, s, a);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_wave48_sampler(const KArgs& a, hipStream_t s) {
+  if (a.d <= 32) return launch_w48_sampler_k<2>(a, a.spb_k, s);
+  return launch_w48_sampler_k<3>(a, a.spb_k, s);
 }
 
 }  // namespace dlm

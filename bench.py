@@ -16,6 +16,8 @@ Other configs (so that the driver can time them; each prints the same one-line c
       sufficient statistics, dlm_stats_pool, ONE RCCL all-reduce of 2p + d + 1 doubles (dlm_gibbs_suffstats_allreduce on a
       communicator whose id travels through the torch.distributed store), the same conjugate draw on every rank
   c4  d = 40, p = 20 (20 x polynomial(2) under |*|), 2000 series: fused filter + smoother, fp64-MFMA bound
+  c4g the same model inside pooled Inverse-Wishart Gibbs (GibbsWishart.sample, GibbsWishart.scala:40-80): FFBS with
+      outer-product statistics on the device, pooling, the RCCL all-reduce of 2p + d^2 + 1 doubles, one W and V draw
   c5  SVD (square-root) filter, d = 13, 10 000 series
 
 Prints ONE JSON line on rank 0 with the extra objects
@@ -124,16 +126,16 @@ def cpu_baseline(config, mat, p, y_host, budget_s=12.0):
     else:
         cores, n2, t0 = 1, 0, time.perf_counter()
         while n2 < y_host.shape[0] and time.perf_counter() - t0 < budget_s:
-            if config == "c3":
+            if config in ("c3", "c4g"):
                 f = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y_host[n2])
                 z = oracle.normals(1, n2, mat.T + 1, mat.d)
                 th = oracle.backward_sample(om, p.w, f, z, factor="chol")["theta"]
-                oracle.gibbs_stats(om, y_host[n2], th)
+                oracle.gibbs_stats(om, y_host[n2], th, want_outer=(config == "c4g"))
             else:
                 oracle.svd_filter(om, p.v, p.w, p.m0, p.c0, y_host[n2])
             n2 += 1
         dt = time.perf_counter() - t0
-        what = ("oracle/dlm_oracle.c filter + backward sampler (Smoothing.step) + Gibbs sums" if config == "c3"
+        what = ("oracle/dlm_oracle.c filter + backward sampler (Smoothing.step) + Gibbs sums" if config in ("c3", "c4g")
                 else "oracle/dlm_oracle.c SVD filter (two one-sided Jacobi SVDs per step)") + ", one core, series after series"
     return {"value": n2 * mat.T / dt, "unit": "series*timesteps/s", "cores": cores, "kind": "port",
             "sample": f"{n2} of the {y_host.shape[0]} series x T={mat.T} (same inputs), {dt:.1f} s, {what}",
@@ -145,7 +147,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c4g", "c5"], default="c2")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the series of the job are sharded over the ranks (the contract case), weak = every rank runs all of them")
     ap.add_argument("--series", type=int, default=None, help="series of the whole job (strong) / per GPU (weak); default 10000 (c4: 2000)")
@@ -159,15 +161,15 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="extra DLM_OPT_* bits (e.g. 8 = force generic kernels)")
     args = ap.parse_args()
     cfg = args.config
-    steps = args.steps if args.steps is not None else {"c2": 20, "c3": 5, "c4": 5, "c5": 3}[cfg]
-    warmup = args.warmup if args.warmup is not None else {"c2": 3, "c3": 1, "c4": 1, "c5": 1}[cfg]
+    steps = args.steps if args.steps is not None else {"c2": 20, "c3": 5, "c4": 5, "c4g": 3, "c5": 3}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"c2": 3, "c3": 1, "c4": 1, "c4g": 1, "c5": 1}[cfg]
 
     import torch
     import torch.distributed as dist
     from bayesian_dlms_amd import _lib
     from bayesian_dlms_amd.dlm import materialise
     from bayesian_dlms_amd.engine import Engine
-    from bayesian_dlms_amd.gibbs import GibbsSampling, InverseGamma, shard_bounds
+    from bayesian_dlms_amd.gibbs import GibbsSampling, GibbsWishart, InverseGamma, InverseWishart, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,8 +180,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    mod, p = multivariate_c4() if cfg == "c4" else seasonal_c2()
-    total = args.series if args.series is not None else (2000 if cfg == "c4" else 10000)
+    mod, p = multivariate_c4() if cfg in ("c4", "c4g") else seasonal_c2()
+    total = args.series if args.series is not None else (2000 if cfg in ("c4", "c4g") else 10000)
     T = args.T
     if world > 1 and args.scaling == "strong":
         lo, hi = shard_bounds(total, world, rank)
@@ -234,9 +236,14 @@ def main():
             os.dup2(saved, 1); os.close(saved)
         comm_world = world
         sim = args.sampler == "simsmooth"
-        chain = GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p, mat.times, y, eng,
-                                     n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
-                                     allreduce=eng.allreduce_stats, simulation_smoother=sim)   # priors: SeasonalModel.scala:127
+        if cfg == "c3":
+            chain = GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p, mat.times, y, eng,
+                                         n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
+                                         allreduce=eng.allreduce_stats, simulation_smoother=sim)   # priors: SeasonalModel.scala:127
+        else:
+            chain = GibbsWishart.sample(mod, InverseGamma(5.0, 4.0), InverseWishart(d + 2.0, np.eye(d)), p, mat.times, y, eng,
+                                        n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
+                                        allreduce=eng.allreduce_stats, simulation_smoother=sim)
         last = {}
 
         def step():
@@ -280,6 +287,10 @@ def main():
             # algorithmic flops: filter 8 d^3 + 6 d^2 p + 2 p^3 / 3, RTS 8.67 d^3
             fwd_u, bwd_u, unit, peak, bound = 8.0 * d ** 3 + 6.0 * d * d * q + 2.0 * q ** 3 / 3.0, 8.67 * d ** 3, "TFLOP/s", MFMA_F64_PEAK_TFLOPS, "mfma"
             names = ("k_filter_", "k_smoother_")
+        elif cfg == "c4g":
+            # FFBS adds about 8 d^3 (J, H) plus the Cholesky factor d^3 / 3 to the filter's flops
+            fwd_u, bwd_u, unit, peak, bound = 8.0 * d ** 3 + 6.0 * d * d * q + 2.0 * q ** 3 / 3.0, 8.0 * d ** 3 + d ** 3 / 3.0, "TFLOP/s", MFMA_F64_PEAK_TFLOPS, "mfma"
+            names = ("k_filter_", "k_sampler_")
         else:
             fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * (2 * d + d * d), 0.0, "GB/s", HBM_PEAK_GBS, "hbm"
             names = ("k_svd_filter_", "")
@@ -287,18 +298,20 @@ def main():
         dom_u, dom_ms = (bwd_u, b_ms) if dom_is_bwd else (fwd_u, f_ms)
         scale = 1e9 if unit == "GB/s" else 1e12
         achieved = dom_u * nt / (dom_ms * 1e-3) / scale
-        short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16",
+        short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16", "wave-sampler": "w48", "wave-simsmooth": "w48",
                  "sparse16-simsmooth": "sp16", "svd-jacobi": "jacobi"}.get(variant, variant)
         kname = (names[1] if dom_is_bwd else names[0]) + short
         workloads = {
             "c2": f"C2: seasonal DLM polynomial(1)|+|seasonal(24,6), d=13, p=1, {job_series} series x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
             "c3": f"C3: the C2 model inside pooled d-Inverse-Gamma Gibbs, {job_series} series x T={T}: FFBS + on-device statistics + dlm_stats_pool + RCCL all-reduce + conjugate draw per iteration",
             "c4": f"C4: 20 x polynomial(2) under |*|, d=40, p=20, {job_series} series x T={T}, fused filter+smooth",
+            "c4g": f"C4 Gibbs: the C4 model inside pooled Inverse-Wishart Gibbs, {job_series} series x T={T}: FFBS + outer-product statistics + dlm_stats_pool + RCCL all-reduce + W, V draws per iteration",
             "c5": f"C5: SVD (square-root) filter on the C2 model, d=13, {job_series} series x T={T} (dlm_svd_filter_batch)",
         }
         line = {
             "metric": {"c2": "Kalman filter+smooth series*timesteps/sec", "c3": "Gibbs (FFBS + conjugate step) series*timesteps/sec",
-                       "c4": "Kalman filter+smooth series*timesteps/sec (d=40)", "c5": "SVD filter series*timesteps/sec"}[cfg],
+                       "c4": "Kalman filter+smooth series*timesteps/sec (d=40)", "c4g": "Gibbs (FFBS + Inverse-Wishart step) series*timesteps/sec (d=40)",
+                       "c5": "SVD filter series*timesteps/sec"}[cfg],
             "value": value, "unit": "series*timesteps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if (world > 1 and args.scaling == "weak") else "strong",
@@ -306,11 +319,11 @@ def main():
             "config": {"workload": workloads[cfg], "series_total": job_series, "series_per_gpu": N, "T": T, "d": d, "p": q,
                        "variant": variant, "records": args.records if cfg == "c2" else "dense",
                        "semantics": ({"textbook": "textbook (S = C - J (R+ - S+) J^T)", "literal-q1": "literal-q1 (Smoothing.scala:44: J X J)"}[args.semantics]
-                                     if cfg in ("c2", "c4") else ("Smoothing.step backward sampler" if cfg == "c3" and args.sampler == "reference"
-                                                                  else "simulation smoother" if cfg == "c3" else "sqrt(W) in the time update (Q2 off)")),
+                                     if cfg in ("c2", "c4") else ("Smoothing.step backward sampler" if cfg in ("c3", "c4g") and args.sampler == "reference"
+                                                                  else "simulation smoother" if cfg in ("c3", "c4g") else "sqrt(W) in the time update (Q2 off)")),
                        "missing_fraction": args.missing,
-                       "parallelism": f"series-sharded x{world}" + (", one RCCL all-reduce of %d doubles per iteration (comm world %d)" % (2 * q + d + 1, comm_world)
-                                                                    if cfg == "c3" else ", no collective")},
+                       "parallelism": f"series-sharded x{world}" + (", one RCCL all-reduce of %d doubles per iteration (comm world %d)" % (2 * q + (d if cfg == "c3" else d * d) + 1, comm_world)
+                                                                    if cfg in ("c3", "c4g") else ", no collective")},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic_from_profiles(kname, N, T, cfg) if not packed and args.missing == 0.0 else None,
                          "algorithmic_units_per_launch": dom_u * nt, "avg_launch_ms": dom_ms,
@@ -322,7 +335,7 @@ def main():
             line["roofline"]["peak_measured"] = pm
             line["roofline"]["frac_of_measured"] = achieved / pm
             line["roofline"]["path_GBps"] = (fwd_u + bwd_u) * nt / ((f_ms + b_ms) * 1e-3) / 1e9
-        if cfg == "c3":
+        if cfg in ("c3", "c4g"):
             st = last["state"]
             line["config"]["pooled_V"] = float(np.diag(st.p.v)[0])
             line["config"]["pooled_W_first"] = [float(x) for x in np.diag(st.p.w)[:3]]

@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdlm_oracle.so")
+# DLM_ORACLE_LIB selects another build of the same file (the AddressSanitizer build of `make -C oracle asan`)
+_LIB_PATH = os.environ.get("DLM_ORACLE_LIB") or os.path.join(_HERE, "libdlm_oracle.so")
 
 
 def build(force=False):

@@ -41,7 +41,7 @@ class _Eng:
         """Name of the variant the last call must have used, given the rule: a wave-* kernel of the d >= 16 range is
         its workgroup counterpart for the small batches of these tests under the production rule."""
         if self.rule == "production" and self._d >= 16:
-            return variant.replace("wave-", "tiled-")
+            return "generic" if variant == "wave-sampler" else variant.replace("wave-", "tiled-")   # (no workgroup form of the sampler)
         return variant
 
 
@@ -1141,9 +1141,14 @@ def test_time_varying_variance_streams(eng, case):
         np.testing.assert_allclose(draws["theta"][n], ref["theta"], rtol=1e-6, atol=1e-7)
     with pytest.raises(EngineError):
         eng.ffbs(mat, p, y, flags=_lib.OPT_FFBS_SIMSMOOTH)
-    if d <= 16 and q <= 16:
-        with pytest.raises(EngineError):
-            eng.svd_filter(mat, p, y)
+    if d <= 16 and q <= 16:   # the SVD entry points take the streams too (round 2): equal to the standard filter
+        sv = eng.svd_filter(mat, p, y)
+        assert np.all(sv["status"] == 0)
+        if q == 1:   # (with several components the SVD update masks sqrt(V)^-1 by selection -- valid for diagonal V only)
+            msv, Csv = _svd_cov(sv["svd"][0], d)
+            f0 = oracle.kf_filter(omodel(mat), Vs, Ws, p.m0, p.c0, y[0])
+            np.testing.assert_allclose(msv, f0["m"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(Csv.transpose(0, 2, 1).reshape(mat.T + 1, d * d), f0["C"], rtol=1e-6, atol=1e-7)
 
 
 def test_ar1_lane_per_series_golden_and_draws(eng, golden_dir):
@@ -1600,7 +1605,7 @@ def test_backward_sampling_from_existing_filter_records(eng, shape):
             mod = mod * Dlm.polynomial(2)
         mat = materialise(mod, np.arange(1, 31, dtype=np.float64))
         A = rng.standard_normal((20, 20))
-        p = DlmParameters(np.eye(10) * 1.2, A @ A.T / 20 + 0.1 * np.eye(20), np.zeros(20), np.eye(20)); expect = "generic"
+        p = DlmParameters(np.eye(10) * 1.2, A @ A.T / 20 + 0.1 * np.eye(20), np.zeros(20), np.eye(20)); expect = "wave-sampler"
     d, q, T = mat.d, mat.p, mat.T
     y = rng.standard_normal((4, T, q)).cumsum(axis=1)
     y[rng.random(y.shape) < 0.1] = np.nan
@@ -1782,3 +1787,61 @@ def test_svd_filter_and_sampler_with_variance_streams(eng, stream):
             kf = oracle.kf_filter(om, V, W, p.m0, p.c0, y[n])
             np.testing.assert_allclose(m, kf["m"], rtol=1e-6, atol=1e-7)
             np.testing.assert_allclose(C.transpose(0, 2, 1).reshape(T + 1, d * d), kf["C"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", ["c4_d40_p20", "d20_p6_irregular_missing", "d33_p17_wstream"])
+def test_reference_form_sampler_on_register_tiles_16_to_48(eng, shape):
+    """Smoothing.sampleDlm (Smoothing.scala:74-122) for 16 <= d <= 48 on register tiles (dlm_wave48.hip: k_sampler_w48):
+    conditional moments, draws and statistics equal the generic kernel's and the oracle's literal sampler with the
+    canonical (Cholesky) factor -- including the steady-state reuse of J, H and the factor on a long regular stretch."""
+    rng = np.random.default_rng(14)
+    wst = False
+    if shape == "c4_d40_p20":
+        mod = Dlm.polynomial(2)
+        for _ in range(19):
+            mod = mod * Dlm.polynomial(2)
+        T, q, d = 160, 20, 40
+        times = np.arange(1, T + 1, dtype=np.float64)
+        miss = 0.0
+    elif shape == "d20_p6_irregular_missing":
+        mod = Dlm.polynomial(2) + Dlm.seasonal(12, 3)
+        mod = mod * (Dlm.polynomial(1) + Dlm.seasonal(24, 2)) * Dlm.polynomial(3) * Dlm.polynomial(1) * Dlm.polynomial(2) * Dlm.polynomial(1)
+        times = np.cumsum(np.array([1, 1, 2, 1, 2, 3, 1] * 6, dtype=np.float64))
+        T, q, d = len(times), 6, 20
+        miss = 0.15
+    else:
+        mod = Dlm.polynomial(2)
+        for _ in range(15):
+            mod = mod * Dlm.polynomial(2)
+        mod = mod * Dlm.polynomial(1)
+        T, q, d = 30, 17, 33
+        times = np.arange(1, T + 1, dtype=np.float64)
+        miss, wst = 0.05, True
+    mat = materialise(mod, times)
+    assert (mat.d, mat.p) == (d, q)
+    A = rng.standard_normal((d, d))
+    W = A @ A.T / d + 0.1 * np.eye(d)
+    if wst:
+        B = rng.standard_normal((T, d, d)) * 0.1
+        W = W[None] + B @ B.transpose(0, 2, 1)
+    p = DlmParameters(np.eye(q) * 0.8, W, rng.standard_normal(d), np.eye(d) * 2.0)
+    N = 3
+    y = rng.standard_normal((N, T, q)).cumsum(axis=1)
+    if miss:
+        y[rng.random(y.shape) < miss] = np.nan
+    z = rng.standard_normal((N, T + 1, d))
+    for flags in (0, _lib.OPT_STATS_OUTER):
+        out = eng.ffbs(mat, p, y, z=z, flags=flags, want_cond=True)
+        assert eng.last_variant == eng.expect("wave-sampler") and np.all(out["status"] == 0)
+        gen = eng.ffbs(mat, p, y, z=z, flags=flags | _lib.OPT_FORCE_GENERIC, want_cond=True)
+        assert eng.last_variant == "generic"
+        np.testing.assert_allclose(out["theta"], gen["theta"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(out["cond"], gen["cond"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(out["stats"], gen["stats"], rtol=1e-7, atol=1e-8)
+    om = omodel(mat)
+    fo = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y[1])
+    ob = oracle.backward_sample(om, p.w if not wst else W, fo, z[1], factor="chol")
+    np.testing.assert_allclose(out["theta"][1], ob["theta"], rtol=1e-6, atol=1e-7)
+    ph = eng.ffbs(mat, p, y, seed=3, series_offset=11)      # Philox stream, no conditional records
+    pg = eng.ffbs(mat, p, y, seed=3, series_offset=11, flags=_lib.OPT_FORCE_GENERIC)
+    np.testing.assert_allclose(ph["theta"], pg["theta"], rtol=1e-7, atol=1e-8)

@@ -446,3 +446,50 @@ def test_svd_filter_with_variance_streams_is_the_kalman_filter():
     th = oracle.svd_backward_sample(M, W, sf, z, literal_q9=False)["theta"]
     np.testing.assert_allclose(th[T], kf["m"][T], rtol=1e-8, atol=1e-9)
     assert np.all(np.isfinite(th))
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """`make -C oracle asan` (ASan + UBSan build of the C restatement), then the filter / smoother / sampler / SVD /
+    statistics entry points on the golden file and on a d = 13 model in a child process that loads that build: any
+    out-of-bounds access or undefined behaviour aborts it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    script = tmp_path / "run.py"
+    script.write_text('''
+import csv, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["DLM_ROOT"])
+import oracle
+from bayesian_dlms_amd.dlm import Dlm, materialise
+rows = list(csv.reader(open(os.path.join(os.environ["DLM_ROOT"], "tests", "golden", "first_order_dlm.csv"))))[1:]
+y = np.array([float(r[1]) for r in rows])[:, None]
+mat = materialise(Dlm.polynomial(1), np.array([float(r[0]) for r in rows]))
+M = oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+f = oracle.kf_filter(M, [[2.0]], [[3.0]], [0.0], [[10.0]], y)
+s = oracle.smoother(M, f, compat_q1=True)
+assert np.isfinite(s["S"]).all()
+mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+mat = materialise(mod, np.cumsum(np.array([1, 1, 2, 0, 3] * 8, dtype=float)) + 1)
+M = oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+rng = np.random.default_rng(0)
+yy = rng.standard_normal((mat.T, 1)); yy[[3, 9]] = np.nan
+W = np.diag(np.linspace(0.1, 0.5, 13))
+f = oracle.kf_filter(M, [[1.0]], W, np.zeros(13), np.eye(13), yy)
+oracle.smoother(M, f)
+z = oracle.normals(3, 1, mat.T + 1, 13)
+th = oracle.backward_sample(M, W, f, z, factor="chol")["theta"]
+th2 = oracle.backward_sample(M, W, f, z, factor="eig")["theta"]
+st = oracle.gibbs_stats(M, yy, th, want_outer=True)
+sf = oracle.svd_filter(M, [[1.0]], W, np.zeros(13), np.diag(np.linspace(0.5, 2, 13)), yy)
+oracle.svd_backward_sample(M, W, sf, z, literal_q9=False)
+oracle.simulate(M, [[1.0]], W, np.zeros(13), np.eye(13), 5, 2)
+oracle.filter_smooth_batch(2, M, np.array([[1.0]]), W, np.zeros(13), np.eye(13), np.stack([yy, yy]), want_out=True)
+print("ASAN RUN OK")
+''')
+    env = dict(os.environ, DLM_ROOT=root, DLM_ORACLE_LIB=os.path.join(root, "oracle", "libdlm_oracle_asan.so"), LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ASAN RUN OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
