@@ -297,10 +297,9 @@ __device__ void wave_chol(double* img, int d, int g, int c) {
 // instantiation keeps none of that.
 // LL: also accumulate the prediction-error log-likelihood (its own instantiation: the expansion of log() in the loop
 // would cost the plain filter two waves per SIMD of occupancy).
-template <int K, bool SIM, bool IRR, bool LL = false>
-__global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
-                                                     double* __restrict__ side, double* __restrict__ xplus) {
-  __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS + (SIM ? 4 * IMG : 0)];
+template <int K, bool SIM, bool IRR, bool LL>
+__device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __restrict__ sp, double* __restrict__ side,
+                                            double* __restrict__ xplus, double* lds /* 4 WAVE_LDS (+ 4 IMG with SIM) doubles */) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
@@ -527,6 +526,13 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
+template <int K, bool SIM, bool IRR, bool LL = false>
+__global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a, const SparseT* __restrict__ sp,
+                                                     double* __restrict__ side, double* __restrict__ xplus) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS + (SIM ? 4 * IMG : 0)];
+  filter_body<K, SIM, IRR, LL>(a, sp, side, xplus, lds);
+}
+
 // ---------------------------------------------------------------------------------------
 // backward pass: MFMA for P C and C (P C); gathers for G^T M G
 //
@@ -535,14 +541,12 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
 // MFMA's B operand,  [C | m] - C [P C | -q] = [C - C P C | m + C q] = [S | s]:  the smoothed mean needs no
 // extraction from the product, and mean and covariance are read and stored by the same 4 instructions.
 // ---------------------------------------------------------------------------------------
+constexpr int SM_LDS = 2 * IMG + 3 * 16;   // backward pass: two images + three 16-vectors per wave
 template <int K, bool IRR>
-__global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
-                                                       const double* __restrict__ side) {
-  constexpr int SM_LDS = 2 * IMG + 3 * 16;   // two images + three 16-vectors per wave
-  __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
-  // two-slot ring per wave in dynamic LDS for the LDS-DMA prefetch; a slot is a raw record followed by one
+__device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __restrict__ sp, const double* __restrict__ side,
+                                              double* lds /* 4 SM_LDS doubles */, char* ring_all) {
+  // ring_all: two-slot ring per wave for the LDS-DMA prefetch; a slot is a raw record followed by one
   // zero double, which the padded lanes read.  Record t lives in slot t & 1 and is requested two steps ahead.
-  extern __shared__ __attribute__((aligned(16))) char ring_all[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
@@ -747,6 +751,14 @@ __global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const 
   for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(out[r]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+template <int K, bool IRR>
+__global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
+                                                       const double* __restrict__ side) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
+  extern __shared__ __attribute__((aligned(16))) char ring_all[];
+  smoother_body<K, IRR>(a, sp, side, lds, ring_all);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -298,7 +298,7 @@ def main():
         dom_u, dom_ms = (bwd_u, b_ms) if dom_is_bwd else (fwd_u, f_ms)
         scale = 1e9 if unit == "GB/s" else 1e12
         achieved = dom_u * nt / (dom_ms * 1e-3) / scale
-        short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16", "wave-sampler": "w48", "wave-simsmooth": "w48",
+        short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16", "sparse16-rts": "rts16", "wave-sampler": "w48", "wave-simsmooth": "w48",
                  "sparse16-simsmooth": "sp16", "svd-jacobi": "jacobi"}.get(variant, variant)
         kname = (names[1] if dom_is_bwd else names[0]) + short
         workloads = {

@@ -1845,3 +1845,4 @@ def test_reference_form_sampler_on_register_tiles_16_to_48(eng, shape):
     ph = eng.ffbs(mat, p, y, seed=3, series_offset=11)      # Philox stream, no conditional records
     pg = eng.ffbs(mat, p, y, seed=3, series_offset=11, flags=_lib.OPT_FORCE_GENERIC)
     np.testing.assert_allclose(ph["theta"], pg["theta"], rtol=1e-7, atol=1e-8)
+
