@@ -176,7 +176,7 @@ __device__ __forceinline__ double chol_draw(const double (&row)[15], int d, int 
 // Tab: SparseT (the d <= 15, p = 1 tables) or SparseBig (the tables of the multivariate paths); any p <= 64 -- the
 // observations only enter the statistics.
 template <int K, class Tab>
-__global__ __launch_bounds__(64) void k_sampler_sp16(KArgs a, const Tab* __restrict__ sp) {
+__global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __restrict__ sp) {   // two waves per SIMD: the step is a long dependent chain
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16 + 64];
   double* img = lds;       double* inv = lds + IMG;
   double* mv = inv + IMG;  double* thv = mv + 16;   double* uv = thv + 16;   double* zv = uv + 16;
