@@ -409,6 +409,15 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
     if (sd) { sd[0] = __builtin_nan(""); sd[1] = __builtin_nan(""); }
   }
 
+  // Steady state (regular grid, time-invariant model: the !IRR instantiation).  The covariance recursion of a
+  // time-invariant filter converges: once an update leaves C where it was (largest change <= 1e-13 Q, checked every fourth
+  // step), C_t, R_t, K_t and Q_t are those of the step before and only the mean moves -- a = G m, e = y - F.a,
+  // m = a + K e: a gather on one 16-vector instead of the congruence, the products with F and the rank-one update.  The
+  // record (the same C, the new m) is stored as always.  A missing observation takes the full step again (C changes),
+  // and the test starts over.  The backward pass learns from the sign of the side record's 1/Q that C_t is C_{t-1}.
+  const bool may_settle = !IRR && !SIM && !(a.flags & DLM_OPT_NO_STEADY);
+  bool steady = false;
+  double Kst = 0.0, rq_st = 0.0, Q_st = 0.0;
   double ychunk = 0.0;
   for (int t = 0; t < T; ++t) {
     if ((t & 63) == 0) {
@@ -441,6 +450,34 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
       for (int r = 0; r < 4; ++r) w[r] = (vr[r] && vc) ? Wt[(4 * r + g) * d + c] : 0.0;
     }
 
+    if (may_settle && steady && yt == yt) {
+#ifdef DLM_STAMP
+      st += 1 << 8;      // diagnostic build: steady steps of the forward pass in status bits 8..19
+#endif
+      // the mean rides in row 15 of the tile (lanes g == 3 of register 3) and in column 15
+      if (g == 3) vRF[c] = cc[3];
+      wave_sync();
+      double ac = vRF[idx[0]] * val[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) ac = fma(vRF[idx[s]], val[s], ac);      // a = G m (row 15 of the table: the unit row)
+      const double f = uniform_from_lane(row_sum(Fc * ac), 0);
+      const double e = yt - f, erq = e * rq_st;
+      const double mn = fma(Kst, e, ac);                                   // m = a + K e
+      wave_sync();                                                         // the reads of vRF above precede its rewrite
+      vRF[c] = mn;
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const double mr = vRF[4 * r + g]; cc[r] = col15 ? mr : cc[r]; }
+      cc[3] = (g == 3 && !col15) ? mn : cc[3];
+      if (LL) ll -= 0.5 * (1.8378770664093453 + log(Q_st) + e * erq);
+      side_store(rside, offS, (t + 1) * 16, erq, -rq_st);                  // 1/Q negated: "C_t is C_{t-1}" for the backward pass
+      if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q_st; }
+      const int so = (t + 1) * recb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], so, cc[r]);
+      wave_sync();
+      continue;
+    }
     // advState: a = G m, R = G C G^T + W dt   (dt == 0: a = m, R = C, KalmanFilter.scala:279-280)
     if (SIM) {
       vX[c] = xcol;
@@ -503,13 +540,23 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
       const double e = yt - f, rq = fast_rcp(Q), erq = e * rq;
       const double Kc = (col15 ? 0.0 : rfc) * rq;
       const double ngam = col15 ? erq : -Kc * fma(-Q, rq, 2.0);
+      const bool check = may_settle && bpri == nullptr && (t & 3) == 3;
+      d4 old = cc;
 #pragma unroll
       for (int r = 0; r < 3; ++r) cc[r] = fma(rfr[r], ngam, R[r]);
       cc[3] = (g == 3) ? fma(Kc, e, R[3]) : fma(rfr[3], ngam, R[3]);
+      if (check) {   // has the covariance stopped moving?  (column 15 and row 15 carry the mean: not compared)
+        const double tol = 1e-13 * Q;
+        bool moved = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) moved |= vc && !(r == 3 && g == 3) && !(fabs(cc[r] - old[r]) <= tol);
+        if (__ballot(moved) == 0ull) { steady = true; Kst = Kc; rq_st = rq; Q_st = Q; }
+      }
       if (LL) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * erq);   // -log N(y; f, Q); log(2 pi) = 1.83787...
       side_store(rside, offS, (t + 1) * 16, erq, rq);
     } else {
       cc = R;
+      steady = false;
       side_store(rside, offS, (t + 1) * 16, __builtin_nan(""), __builtin_nan(""));
     }
     if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
@@ -593,6 +640,8 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   d4 P = {0.0, 0.0, 0.0, 0.0};
   double qcol = 0.0;
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+  const bool may_settle = !(a.flags & DLM_OPT_NO_STEADY);
+  bool psteady = false, same_next = false;
 
   const int slotb = rinb + 16;
   char* ring = ring_all + wave * 2 * slotb;
@@ -627,7 +676,9 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       lds_fence(cc);
     }
     // the innovations are per-series scalars: keep them in SGPRs so `observed` is a scalar branch
-    const double eq = uniform_from_lane(neq, 0), iq = uniform_from_lane(niq, 0);
+    const double eq = uniform_from_lane(neq, 0), iqraw = uniform_from_lane(niq, 0);
+    const double iq = fabs(iqraw);                           // the forward pass negates 1/Q where C_t is C_{t-1} (its steady state)
+    const bool same_c = iqraw < 0.0;
     {
       const int tp = t > 0 ? t - 1 : 0;                      // record 0 is re-read harmlessly at the end
       neq = sd[2 * tp]; niq = sd[2 * tp + 1];
@@ -688,6 +739,23 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
         for (int s = 0; s < K; ++s) { idx[s] = sp[2 * gi + 1].idx[c][s]; val[s] = sp[2 * gi + 1].val[c][s]; }
         gcur = gi;
       }
+      // Steady state of the backward recursion: with C_t = C_{t+1} (the forward pass's mark) and P_t = P_{t+1} (found below),
+      // P_{t-1} = P_t -- the rank-two update and the congruence are skipped and only q moves.  [P C | P K] and the output
+      // product are computed as always (same operands, same values).
+      if (!IRR && psteady && same_next && observed) {
+#ifdef DLM_STAMP
+        st += 1 << 20;   // diagnostic build: steady steps of the backward pass in status bits 20..31
+#endif
+        const double kq = uniform_from_lane(row_sum(kcol * qcol), 0);
+        vR[c] = fma(Fc, eq - kq, qcol);
+        wave_sync();
+        qcol = vR[idx[0]] * val[0];
+#pragma unroll
+        for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
+        vQ[c] = -qcol;
+        wave_sync();
+      } else {
+      psteady = false;
       d4 M = P;
       double rcol = qcol;
       if (observed) {
@@ -722,7 +790,15 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       // amplified by the update: removing it every 8th step keeps it at rounding level.
       // Like Smoothing.smoothStep (Smoothing.scala:41) this always uses the table entry g(dt), also for
       // dt == 0 where the filter made an identity advance; only polynomial-type g ignore dt, see DESIGN.md.
-      P = congruence<K>(M, imgA, imgB, idx, val, g, c, (t & 7) == 0);              // G^T M G (first sync covers vR)
+      const d4 Pn = congruence<K>(M, imgA, imgB, idx, val, g, c, (t & 7) == 0);    // G^T M G (first sync covers vR)
+      if (!IRR && may_settle && observed && same_c && (t & 3) == 2) {   // has P stopped moving (and will the next C be this one)?
+        const double tol = 1e-13 * iq;
+        bool moved = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) moved |= !(fabs(Pn[r] - P[r]) <= tol);
+        psteady = __ballot(moved) == 0ull;
+      }
+      P = Pn;
       qcol = vR[idx[0]] * val[0];
 #pragma unroll
       for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
@@ -732,7 +808,9 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       asm volatile("" ::"v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]));
 #endif
       STAMP(4)
+      }
     }
+    same_next = same_c;
 
     // output: [S_t | s_t] = [C_t | m_t] - C_t [P_t C_t | -q_t]
     const int so = t * recb;

@@ -322,6 +322,7 @@ def main():
                                      if cfg in ("c2", "c4") else ("Smoothing.step backward sampler" if cfg in ("c3", "c4g") and args.sampler == "reference"
                                                                   else "simulation smoother" if cfg in ("c3", "c4g") else "sqrt(W) in the time update (Q2 off)")),
                        "missing_fraction": args.missing,
+                       "steady_state_steps": "off (DLM_OPT_NO_STEADY)" if flags & _lib.OPT_NO_STEADY else "on where the covariance recursion has settled (DESIGN.md 4.5)",
                        "parallelism": f"series-sharded x{world}" + (", one RCCL all-reduce of %d doubles per iteration (comm world %d)" % (2 * q + (d if cfg == "c3" else d * d) + 1, comm_world)
                                                                     if cfg in ("c3", "c4g") else ", no collective")},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": unit,

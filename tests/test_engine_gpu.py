@@ -1846,3 +1846,49 @@ def test_reference_form_sampler_on_register_tiles_16_to_48(eng, shape):
     pg = eng.ffbs(mat, p, y, seed=3, series_offset=11, flags=_lib.OPT_FORCE_GENERIC)
     np.testing.assert_allclose(ph["theta"], pg["theta"], rtol=1e-7, atol=1e-8)
 
+
+
+def test_steady_state_steps_of_the_structured_kernels(eng):
+    """Once the covariance recursion has settled (regular grid, no missing observation) the d <= 15 kernels advance only the
+    mean (forward: a = G m, m = a + K e; backward: q alone) and mark it in the side record; DLM_OPT_NO_STEADY recomputes
+    everything every step.  Same numbers to 1e-11, against the oracle to the usual tolerance, and a gap in the data takes
+    the full path again."""
+    rng = np.random.default_rng(31)
+    mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+    T = 700
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    p = DlmParameters([[1.0]], np.diag([0.3, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4]), np.zeros(13), np.eye(13))   # settles within ~80 steps
+    y = rng.standard_normal((6, T, 1)).cumsum(axis=1)
+    y[1, 300:305, 0] = np.nan            # a gap: leaves the steady state, re-enters it later
+    y[2, 10::97, 0] = np.nan             # scattered missing values
+    fast = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "sparse16" and np.all(fast["status"] == 0)
+    full = eng.filter_smooth(mat, p, y, flags=_lib.OPT_NO_STEADY)
+    np.testing.assert_allclose(fast["filt"], full["filt"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(fast["smooth"], full["smooth"], rtol=1e-10, atol=1e-11)
+    # the covariance really is frozen on the settled stretch of an undisturbed series ...
+    C = fast["filt"][0][:, 13:]
+    assert np.array_equal(C[400], C[399]) and np.array_equal(C[600], C[400])
+    # ... and moves again after the gap
+    C1 = fast["filt"][1][:, 13:]
+    assert not np.array_equal(C1[305], C1[299])
+    for n in (0, 1, 2):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, Cc = split(fast["filt"][n], 13); sm, S = split(fast["smooth"][n], 13)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(Cc, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+    ll = eng.loglik(mat, p, y)["loglik"]
+    ll0 = eng.loglik(mat, p, y, flags=_lib.OPT_NO_STEADY)["loglik"]
+    np.testing.assert_allclose(ll, ll0, rtol=1e-11)
+    np.testing.assert_allclose(ll[0], oracle.loglik(omodel(mat), oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[0]), y[0]), rtol=1e-9)
+    fq = eng.filter(mat, p, y, want_fq=True)["fq"]
+    f0 = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[0])
+    np.testing.assert_allclose(fq[0, 1:, 0], f0["f"][1:, 0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(fq[0, 1:, 1], f0["Q"][1:, 0], rtol=1e-9, atol=1e-10)
+    # the simulation smoother and the samplers read positive 1/Q from their own forward passes: unaffected
+    z = rng.standard_normal((6, T + 1, 14))
+    a_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    b_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_STEADY)
+    np.testing.assert_array_equal(a_["theta"], b_["theta"])
