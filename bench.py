@@ -174,9 +174,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # DLM_BENCH_BACKEND=gloo with DLM_BENCH_DEVICE=0 rehearses the multi-rank control flow with every rank on one GPU
+    # (tests/test_full_size_gpu.py; timings of such a run mean nothing).  The driver's runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("DLM_BENCH_BACKEND", "nccl")
+    if "DLM_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["DLM_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -224,26 +232,34 @@ def main():
             status.copy_(eng.svd_filter(mat, p, y, flags=flags)["status"])
     else:
         # pooled-parameter Gibbs over all ranks: the communicator id goes through the torch.distributed store
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)            # RCCL prints a version banner on stdout when a communicator is created: keep stdout to the ONE JSON line
-        try:
-            eng.comm_init_rank(world, rank, uid[0])
-        finally:
-            os.dup2(saved, 1); os.close(saved)
+        if backend == "nccl":
+            uid = [eng.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)            # RCCL prints a version banner on stdout when a communicator is created: keep stdout to the ONE JSON line
+            try:
+                eng.comm_init_rank(world, rank, uid[0])
+            finally:
+                os.dup2(saved, 1); os.close(saved)
+            allreduce = eng.allreduce_stats
+        else:                        # rehearsal on one GPU: the same sum through the torch.distributed backend given
+            def allreduce(t):
+                c = t.cpu()
+                if world > 1:
+                    dist.all_reduce(c)
+                return c
         comm_world = world
         sim = args.sampler == "simsmooth"
         if cfg == "c3":
             chain = GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p, mat.times, y, eng,
                                          n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
-                                         allreduce=eng.allreduce_stats, simulation_smoother=sim)   # priors: SeasonalModel.scala:127
+                                         allreduce=allreduce, simulation_smoother=sim)   # priors: SeasonalModel.scala:127
         else:
             chain = GibbsWishart.sample(mod, InverseGamma(5.0, 4.0), InverseWishart(d + 2.0, np.eye(d)), p, mat.times, y, eng,
                                         n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
-                                        allreduce=eng.allreduce_stats, simulation_smoother=sim)
+                                        allreduce=allreduce, simulation_smoother=sim)
         last = {}
 
         def step():
@@ -265,7 +281,7 @@ def main():
     elapsed = time.perf_counter() - t0
     variant = eng.last_variant
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -161,3 +161,30 @@ def test_small_multivariate_full_size(eng):
     yh = rng.standard_normal((10000, 1000, 4)).cumsum(axis=1)
     yh[rng.random(yh.shape) < 0.03] = np.nan
     _properties(eng, mat, p, torch.as_tensor(yh, device="cuda"), [0, 9999, 4242], "wave-mfma", 1e-8, 1e-7)
+
+
+@pytest.mark.parametrize("config", ["c2", "c3"])
+def test_bench_multi_rank_control_flow_rehearsal(config, tmp_path):
+    """bench.py with two ranks (the driver's launch shape: RANK / WORLD_SIZE / MASTER_* in the environment) on the one GPU
+    of this box, torch.distributed over gloo (two RCCL ranks cannot share a device): strong scaling shards the job's
+    series, rank 0 prints ONE JSON line with the whole-job value; for c3 the pooled statistics are summed over the ranks and
+    every rank makes the same draw.  The timings of such a run mean nothing -- this is the control flow only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--config", config, "--series", "1200", "--T", "120"]
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561" if config == "c2" else "29562",
+               DLM_BENCH_BACKEND="gloo", DLM_BENCH_DEVICE="0")
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]     # rank 0 alone reports
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0 and j["status_nonzero_series"] == 0
+    assert j["config"]["series_total"] == 1200 and j["config"]["series_per_gpu"] == 600
+    if config == "c3":
+        assert "comm world 2" in j["config"]["parallelism"] and np.isfinite(j["config"]["pooled_V"])
