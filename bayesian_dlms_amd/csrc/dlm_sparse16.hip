@@ -28,7 +28,10 @@ constexpr int LD = 17;                        // leading dimension of an LDS ima
 constexpr int IMG = 16 * LD;                  // doubles per image
 constexpr int WAVE_LDS = 2 * IMG + 8 * 16;    // two images + eight 16-vectors per wave
 
-constexpr int SM_WAVES = 4, FI_WAVES = 5;     // waves per SIMD the register allocator must at least allow (backward / forward kernels)
+#ifndef DLM_SM_WAVES
+#define DLM_SM_WAVES 4
+#endif
+constexpr int SM_WAVES = DLM_SM_WAVES, FI_WAVES = 5;     // waves per SIMD the register allocator must at least allow (backward / forward kernels)
 
 // One dependent chain of four: two chains of two were measured slower (profiles/r01_pmc_notes.md).
 __device__ __forceinline__ d4 mmT(const d4& x, const d4& y) {  // X^T * Y
@@ -608,7 +611,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   const bool vc = c < d, col15 = (c == 15);
 
   const double V = a.V[(size_t)n * a.v_stride];
-  double rV = 1.0 / V;   // 1 / V_t of the record's observation when time-varying (IRR instantiation)
+  double rV = 1.0 / V;   // regular instantiation: parked in LDS below (a uniform value the compiler keeps in a vector register).  1 / V_t of the record's observation when time-varying (IRR instantiation)
   const bool pout = (a.packed & 2) != 0;                          // smoothed records (output): packed with DLM_OPT_PACKED_SYM, dense otherwise
   const int recb = pout ? packed_rec_bytes(d) : rec * 8;
   const int rinb = (a.packed & 1) ? packed_rec_bytes(d) : rec * 8; // filtered records (input): packed when engine-internal or DLM_OPT_PACKED_SYM
@@ -626,7 +629,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   bool va[4];      // this lane's register r carries an element of the augmented record
   int offA[4];     // its byte offset inside a record (OOB otherwise: loads give 0, stores are dropped)
   int ldsA[4];     // the same inside a ring slot (padded lanes read the slot's zero double)
-  double Fc = vc ? a.F[c] : 0.0;
+  double Fcr = vc ? a.F[c] : 0.0;   // F[c] (regular instantiation: read from column 16 of image A where needed)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * r + g;
@@ -637,6 +640,14 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     if (a.packed & 1) { const int hi = i > c ? i : c, lo = i > c ? c : i; ldsA[r] = va[r] ? (vc ? (d + hi * (hi + 1) / 2 + lo) * 8 : i * 8) : rinb; }
     else ldsA[r] = va[r] ? offD : rinb;
   }
+  // Regular instantiation: F[4r+g] waits in the spare column 16 of image A (the images have a leading dimension of 17) and is
+  // read where a step needs it -- eight registers that decide whether five waves fit a SIMD.
+  if (!IRR) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + 16] = Fr[r];
+    imgB[16] = rV;
+  }
+  const unsigned fr_lds = lds_addr_of(imgA + g * LD + 16);
   d4 P = {0.0, 0.0, 0.0, 0.0};
   double qcol = 0.0;
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
@@ -648,12 +659,20 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   const unsigned ring_lds = lds_addr_of(ring);
   const i4 rdma = rsrc_words(bin, (unsigned)((size_t)(T + 1) * rinb));
   const int n16 = rinb / 16;                          // d (d + 1) is even (and packed records are padded): whole 16 B pieces
+  const int n16m = (d * 8 + 15) / 16;                 // the mean alone (it leads the record in both layouts)
   if (lane < 2) *(double*)(ring + lane * slotb + rinb) = 0.0;
+  // The side records run two steps ahead of the recursion: the forward pass's mark on record t-1 (1/Q negated: C_{t-1} is
+  // C_{t-2}) decides at step t how much of record t-2 is requested -- the whole record, or only its mean when the covariance is
+  // the one already in the registers (64 % of the records of the C2 bench: 104 instead of 1456 bytes read).
+  double ceq = sd[2 * T], ciq = sd[2 * T + 1];
+  double neq, niq;
+  { const int t1 = T > 0 ? T - 1 : 0; neq = sd[2 * t1]; niq = sd[2 * t1 + 1]; }
   dma_record(rdma, ring_lds + (T & 1) * slotb, T * rinb, lane, n16);
-  { const int t1 = T > 0 ? T - 1 : 0; dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * rinb, lane, n16); }
-  double neq = sd[2 * T], niq = sd[2 * T + 1];
+  { const int t1 = T > 0 ? T - 1 : 0;
+    dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * rinb, lane, (!IRR && uniform_from_lane(ciq, 0) < 0.0) ? n16m : n16); }
   vQ[c] = 0.0;
-  d4 out = {0.0, 0.0, 0.0, 0.0};
+  d4 out = {0.0, 0.0, 0.0, 0.0};                     // the record stored last (assigned in every step before its store)
+  d4 cc = {0.0, 0.0, 0.0, 0.0};
 
 #ifdef DLM_STAMP
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = stamp();
@@ -666,27 +685,31 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     if (t == T) vm_wait<1>();
     else if (t == T - 1) vm_wait<5>();
     else vm_wait<9>();
-    d4 cc;
+    // C_t is C_{t+1} (the mark on record t+1): only the mean of record t was requested, the covariance stays in the registers
+    const bool inherit = !IRR && same_next;
+    d4 nr;                                                   // the record as fetched: [C_t | m_t], or only m_t in column 15
     {
       const unsigned slot = ring_lds + (t & 1) * slotb;
-      cc[0] = lds_read64<0>(slot + ldsA[0]);
-      cc[1] = lds_read64<0>(slot + ldsA[1]);
-      cc[2] = lds_read64<0>(slot + ldsA[2]);
-      cc[3] = lds_read64<0>(slot + ldsA[3]);
-      lds_fence(cc);
+      nr[0] = lds_read64<0>(slot + ldsA[0]);
+      nr[1] = lds_read64<0>(slot + ldsA[1]);
+      nr[2] = lds_read64<0>(slot + ldsA[2]);
+      nr[3] = lds_read64<0>(slot + ldsA[3]);
+      lds_fence(nr);
     }
     // the innovations are per-series scalars: keep them in SGPRs so `observed` is a scalar branch
-    const double eq = uniform_from_lane(neq, 0), iqraw = uniform_from_lane(niq, 0);
+    const double eq = uniform_from_lane(ceq, 0), iqraw = uniform_from_lane(ciq, 0);
     const double iq = fabs(iqraw);                           // the forward pass negates 1/Q where C_t is C_{t-1} (its steady state)
     const bool same_c = iqraw < 0.0;
+    const bool mean_only = !IRR && uniform_from_lane(niq, 0) < 0.0;   // C_{t-1} is C_{t-2}: record t-2 needs only its mean
+    ceq = neq; ciq = niq;
     {
-      const int tp = t > 0 ? t - 1 : 0;                      // record 0 is re-read harmlessly at the end
+      const int tp = t > 1 ? t - 2 : 0;                      // record 0 is re-read harmlessly at the end
       neq = sd[2 * tp]; niq = sd[2 * tp + 1];
     }
     const bool observed = (iq == iq) && t > 0;
     if (IRR && a.f_stride && t > 0) {                        // F of the observation at record t
       const double* Ft = a.F + (size_t)(t - 1) * a.f_stride;
-      Fc = vc ? Ft[c] : 0.0;
+      Fcr = vc ? Ft[c] : 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) Fr[r] = (4 * r + g < d) ? Ft[4 * r + g] : 0.0;
     }
@@ -696,16 +719,63 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       rV = 1.0 / Vt;
     }
 
-    // K_t = C_t F / V  (column 15 would give F.m: masked)
-    double kcol = 0.0;
+    // Steady state of the whole backward step: C_t = C_{t+1} (the forward pass's mark) and P_t = P_{t+1} (found below) give
+    // P_{t-1} = P_t and S_t = S_{t+1}.  What is left of the step is the mean: s_t = m_t + C_t q_t (four FMAs per lane on the
+    // symmetric C, one cross-row sum, a transposition through LDS), q_{t-1} = G^T [q_t + F (e_t/Q_t - K.q_t)] -- no MFMA, no
+    // rank-two update, no congruence -- and the record store (the covariance registers of the step before, the new mean).
+    if (!IRR && psteady && same_next && observed) {
+#ifdef DLM_STAMP
+      st += 1 << 20;   // diagnostic build: steady steps of the backward pass in status bits 20..31
+#endif
+      { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rinb, lane, mean_only ? n16m : n16); }
+      d4 nqr;
+      {
+        const unsigned bq = lds_addr_of(vQ + g);             // -q_t, published by the last step's closing wave_sync
+        nqr[0] = lds_read64<0>(bq); nqr[1] = lds_read64<32>(bq); nqr[2] = lds_read64<64>(bq); nqr[3] = lds_read64<96>(bq);
+        lds_fence(nqr);
+      }
+      double ncq = 0.0;                                      // -(C q)[c]: C symmetric, so the column sum serves (lanes c == 15 sum the mean: unused)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) kcol = fma(cc[r], Fr[r], kcol);
-    kcol = (observed && vc) ? sum_g(kcol) * rV : 0.0;
-    vK[c] = kcol;
+      for (int r = 0; r < 4; ++r) ncq = fma(cc[r], nqr[r], ncq);
+      ncq = sum_g(ncq);
+      const double kq = uniform_from_lane(row_sum(vK[c] * qcol), 0);   // K_t is K_{t+1}: still in vK
+      vR[c] = fma(IRR ? Fcr : imgA[c * LD + 16], eq - kq, qcol);
+      imgB[c * LD + 15] = ncq;                               // column 15 of the parked S_t: one read per register fetches [S | -C q]
+      wave_sync();
+      qcol = vR[idx[0]] * val[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
+      d4 ns;
+      {
+        const unsigned bs = lds_addr_of(imgB + g * LD + c);
+        ns[0] = lds_read64<0>(bs); ns[1] = lds_read64<4 * LD * 8>(bs); ns[2] = lds_read64<8 * LD * 8>(bs); ns[3] = lds_read64<12 * LD * 8>(bs);
+        lds_fence(ns);
+      }
+      vQ[c] = -qcol;
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[r] = col15 ? nr[r] - ns[r] : ns[r];   // cc keeps C_t (its column 15 is not used on this path)
+    } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cc[r] = (inherit && !col15) ? cc[r] : nr[r];
+
+    // K_t = C_t F / V  (column 15 would give F.m: masked); it is K_{t+1} when the covariance was inherited
+    if (!inherit) {
+      d4 fr;
+      if (IRR) { fr[0] = Fr[0]; fr[1] = Fr[1]; fr[2] = Fr[2]; fr[3] = Fr[3]; }
+      else {
+        fr[0] = lds_read64<0>(fr_lds); fr[1] = lds_read64<4 * LD * 8>(fr_lds); fr[2] = lds_read64<8 * LD * 8>(fr_lds); fr[3] = lds_read64<12 * LD * 8>(fr_lds);
+        lds_fence(fr);
+      }
+      double ks = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ks = fma(cc[r], fr[r], ks);
+      vK[c] = (observed && vc) ? sum_g(ks) * (IRR ? rV : imgB[16]) : 0.0;
+    }
     wave_sync();                                             // also publishes vQ of the last step
     // the slot just read is free again: request record t-2 into it (always issued, so that the operation
     // count behind every request is the same; below record 0 it re-reads record 0, which nobody uses)
-    { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rinb, lane, n16); }
+    { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rinb, lane, mean_only ? n16m : n16); }
     d4 kr, nqr;
     {
       const unsigned bk = lds_addr_of(vK + g), bq = lds_addr_of(vQ + g);
@@ -739,22 +809,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
         for (int s = 0; s < K; ++s) { idx[s] = sp[2 * gi + 1].idx[c][s]; val[s] = sp[2 * gi + 1].val[c][s]; }
         gcur = gi;
       }
-      // Steady state of the backward recursion: with C_t = C_{t+1} (the forward pass's mark) and P_t = P_{t+1} (found below),
-      // P_{t-1} = P_t -- the rank-two update and the congruence are skipped and only q moves.  [P C | P K] and the output
-      // product are computed as always (same operands, same values).
-      if (!IRR && psteady && same_next && observed) {
-#ifdef DLM_STAMP
-        st += 1 << 20;   // diagnostic build: steady steps of the backward pass in status bits 20..31
-#endif
-        const double kq = uniform_from_lane(row_sum(kcol * qcol), 0);
-        vR[c] = fma(Fc, eq - kq, qcol);
-        wave_sync();
-        qcol = vR[idx[0]] * val[0];
-#pragma unroll
-        for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
-        vQ[c] = -qcol;
-        wave_sync();
-      } else {
+      {
       psteady = false;
       d4 M = P;
       double rcol = qcol;
@@ -764,20 +819,24 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
         wave_sync();
         d4 pk;                                               // (P K)[4r+g]
         double pkc;                                          // (P K)[c]
+        d4 fr;                                               // F[4r+g]
         {
           const unsigned br = lds_addr_of(imgA + g * LD + 15), bc = lds_addr_of(imgA + c * LD + 15);
           pk[0] = lds_read64<0>(br); pk[1] = lds_read64<4 * LD * 8>(br);
           pk[2] = lds_read64<8 * LD * 8>(br); pk[3] = lds_read64<12 * LD * 8>(br);
           pkc = lds_read64<0>(bc);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pk), "+v"(pkc)::"memory");
+          if (IRR) { fr[0] = Fr[0]; fr[1] = Fr[1]; fr[2] = Fr[2]; fr[3] = Fr[3]; }
+          else { fr[0] = lds_read64<8>(br); fr[1] = lds_read64<4 * LD * 8 + 8>(br); fr[2] = lds_read64<8 * LD * 8 + 8>(br); fr[3] = lds_read64<12 * LD * 8 + 8>(br); }
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pk), "+v"(pkc), "+v"(fr)::"memory");
         }
-        const double kk = row_sum(kcol * (g < 2 ? qcol : pkc));   // rows 0-1: K.q, rows 2-3: K.(P K)
+        const double kk = row_sum(vK[c] * (g < 2 ? qcol : pkc));  // rows 0-1: K.q, rows 2-3: K.(P K)
         const double kq = uniform_from_lane(kk, 0), kpk = uniform_from_lane(kk, 32);
         const double sc = iq + kpk;
+        const double Fc = IRR ? Fcr : imgA[c * LD + 16];
         rcol = fma(Fc, eq - kq, qcol);
+        const double u = fma(Fc, sc, -pkc);                  // F_i F_c (1/Q + K'PK) - F_i (PK)_c - (PK)_i F_c = F_i u_c - (PK)_i F_c
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          M[r] = fma(-pk[r], Fc, fma(-Fr[r], pkc, fma(Fr[r] * Fc, sc, P[r])));
+        for (int r = 0; r < 4; ++r) M[r] = fma(-pk[r], Fc, fma(fr[r], u, P[r]));
       }
       vR[c] = rcol;
       wave_sync();                                           // column-15 reads precede the image rewrite
@@ -810,12 +869,19 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       STAMP(4)
       }
     }
-    same_next = same_c;
-
     // output: [S_t | s_t] = [C_t | m_t] - C_t [P_t C_t | -q_t]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = cc[r] - x2[r];
+    if (!IRR && psteady) {                                   // the steady steps may begin: S_t waits for them in the idle image
+#pragma unroll
+      for (int r = 0; r < 4; ++r) imgB[(4 * r + g) * LD + c] = out[r];
+      wave_sync();
+    }
+    }
+    same_next = same_c;
     const int so = t * recb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { out[r] = cc[r] - x2[r]; buf_store(rout, bout, offA[r], so, out[r]); }
+    for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], so, out[r]);
     STAMP(5)
   }
 #ifdef DLM_STAMP
