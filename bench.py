@@ -342,7 +342,7 @@ def main():
                        "parallelism": f"series-sharded x{world}" + (", one RCCL all-reduce of %d doubles per iteration (comm world %d)" % (2 * q + (d if cfg == "c3" else d * d) + 1, comm_world)
                                                                     if cfg in ("c3", "c4g") else ", no collective")},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": traffic_from_profiles(kname, N, T, cfg) if not packed and args.missing == 0.0 else None,
+                         "frac": achieved / peak, "traffic": traffic_from_profiles(kname, N, T, cfg) if not packed and args.missing == 0.0 and not (flags & _lib.OPT_NO_STEADY) and args.semantics == "textbook" else None,
                          "algorithmic_units_per_launch": dom_u * nt, "avg_launch_ms": dom_ms,
                          "forward_ms": f_ms, "backward_ms": b_ms},
             "status_nonzero_series": status_bad,
@@ -351,6 +351,10 @@ def main():
             pm = measure_copy_peak(torch, dev)
             line["roofline"]["peak_measured"] = pm
             line["roofline"]["frac_of_measured"] = achieved / pm
+            tr = line["roofline"]["traffic"]
+            if tr:   # what actually crossed the HBM interface per launch (PMC, profiles/), as a rate: below `achieved` where the
+                     # backward pass fetches only the mean of a record whose covariance it already holds
+                line["roofline"]["traffic_GBps"] = tr / (dom_ms * 1e-3) / 1e9
             line["roofline"]["path_GBps"] = (fwd_u + bwd_u) * nt / ((f_ms + b_ms) * 1e-3) / 1e9
         if cfg in ("c3", "c4g"):
             st = last["state"]

@@ -1887,6 +1887,19 @@ def test_steady_state_steps_of_the_structured_kernels(eng):
     f0 = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[0])
     np.testing.assert_allclose(fq[0, 1:, 0], f0["f"][1:, 0], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(fq[0, 1:, 1], f0["Q"][1:, 0], rtol=1e-9, atol=1e-10)
+    # the backward pass fetches only the mean of a record whose covariance it already holds: the same with packed records on
+    # either side (DLM_OPT_PACKED_SYM: packed in and out; want_filt=False: packed engine-internal records in, dense out)
+    pk = eng.filter_smooth(mat, p, y, flags=_lib.OPT_PACKED_SYM)
+    np.testing.assert_allclose(eng.unpack_records(13, pk["smooth"]), fast["smooth"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(eng.unpack_records(13, pk["filt"]), fast["filt"], rtol=1e-12, atol=1e-13)
+    so = eng.filter_smooth(mat, p, y, want_filt=False)
+    np.testing.assert_allclose(so["smooth"], fast["smooth"], rtol=1e-12, atol=1e-13)
+    # a series that ends inside its steady stretch, one that never reaches it (T = 40), and T = 1
+    for Ts in (40, 1):
+        ms = materialise(mod, np.arange(1, Ts + 1, dtype=np.float64))
+        a1 = eng.filter_smooth(ms, p, y[:, :Ts])
+        b1 = eng.filter_smooth(ms, p, y[:, :Ts], flags=_lib.OPT_NO_STEADY)
+        np.testing.assert_allclose(a1["smooth"], b1["smooth"], rtol=1e-11, atol=1e-12)
     # the simulation smoother and the samplers read positive 1/Q from their own forward passes: unaffected
     z = rng.standard_normal((6, T + 1, 14))
     a_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)

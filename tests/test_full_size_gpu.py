@@ -2,6 +2,8 @@
 batch): (i) the batch is a set of independent series -- any series run on its own gives bit-identical records;
 (ii) the backward pass starts from the last filtered state; (iii) smoothing never increases a variance and every
 covariance stays symmetric with a positive diagonal; (iv) a few series are compared with the oracle at full length."""
+import os
+
 import numpy as np
 import pytest
 
