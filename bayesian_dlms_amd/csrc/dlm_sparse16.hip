@@ -31,7 +31,10 @@ constexpr int WAVE_LDS = 2 * IMG + 8 * 16;    // two images + eight 16-vectors p
 #ifndef DLM_SM_WAVES
 #define DLM_SM_WAVES 4
 #endif
-constexpr int SM_WAVES = DLM_SM_WAVES, FI_WAVES = 5;     // waves per SIMD the register allocator must at least allow (backward / forward kernels)
+#ifndef DLM_FI_WAVES
+#define DLM_FI_WAVES 5
+#endif
+constexpr int SM_WAVES = DLM_SM_WAVES, FI_WAVES = DLM_FI_WAVES;     // waves per SIMD the register allocator must at least allow (backward / forward kernels)
 
 // One dependent chain of four: two chains of two were measured slower (profiles/r01_pmc_notes.md).
 __device__ __forceinline__ d4 mmT(const d4& x, const d4& y) {  // X^T * Y
@@ -194,9 +197,8 @@ __device__ __forceinline__ d4 congruence_pass2(const d4& y, double* imgB, const 
 // rank-2 update treats P as exactly symmetric, and an antisymmetric rounding component would otherwise
 // escape the contraction (I - F K^T) . (I - K F^T).
 template <int K>
-__device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB, const int (&idx)[K],
-                                         const double (&val)[K], int g, int c, bool sym = false,
-                                         const d4* add = nullptr) {   // add: Z = T X T^T + *add for free
+__device__ __forceinline__ d4 congruence_pass1(const d4& x, double* imgA, const int (&idx)[K],
+                                               const double (&val)[K], int g, int c, bool sym) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + c] = x[r];
   wave_sync();
@@ -232,6 +234,13 @@ __device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB
       y[r] = acc;
     }
   }
+  return y;
+}
+template <int K>
+__device__ __forceinline__ d4 congruence(const d4& x, double* imgA, double* imgB, const int (&idx)[K],
+                                         const double (&val)[K], int g, int c, bool sym = false,
+                                         const d4* add = nullptr) {   // add: Z = T X T^T + *add for free
+  const d4 y = congruence_pass1<K>(x, imgA, idx, val, g, c, sym);
   return congruence_pass2<K>(y, imgB, idx, val, g, c, add);
 }
 
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
 // extraction from the product, and mean and covariance are read and stored by the same 4 instructions.
 // ---------------------------------------------------------------------------------------
 constexpr int SM_LDS = 2 * IMG + 3 * 16;   // backward pass: two images + three 16-vectors per wave
-template <int K, bool IRR>
+template <int K, bool IRR, bool PIPE = false>
 __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __restrict__ sp, const double* __restrict__ side,
                                               double* lds /* 4 SM_LDS doubles */, char* ring_all) {
   // ring_all: two-slot ring per wave for the LDS-DMA prefetch; a slot is a raw record followed by one
@@ -687,14 +696,16 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     else vm_wait<9>();
     // C_t is C_{t+1} (the mark on record t+1): only the mean of record t was requested, the covariance stays in the registers
     const bool inherit = !IRR && same_next;
-    d4 nr;                                                   // the record as fetched: [C_t | m_t], or only m_t in column 15
     {
       const unsigned slot = ring_lds + (t & 1) * slotb;
+      d4 nr;                                                 // the record as fetched: [C_t | m_t], or only m_t in column 15
       nr[0] = lds_read64<0>(slot + ldsA[0]);
       nr[1] = lds_read64<0>(slot + ldsA[1]);
       nr[2] = lds_read64<0>(slot + ldsA[2]);
       nr[3] = lds_read64<0>(slot + ldsA[3]);
       lds_fence(nr);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cc[r] = (inherit && !col15) ? cc[r] : nr[r];   // (holding nr for the steady step instead costs 8 VGPRs: 4 waves per SIMD)
     }
     // the innovations are per-series scalars: keep them in SGPRs so `observed` is a scalar branch
     const double eq = uniform_from_lane(ceq, 0), iqraw = uniform_from_lane(ciq, 0);
@@ -754,10 +765,8 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       vQ[c] = -qcol;
       wave_sync();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[r] = col15 ? nr[r] - ns[r] : ns[r];   // cc keeps C_t (its column 15 is not used on this path)
+      for (int r = 0; r < 4; ++r) out[r] = col15 ? cc[r] - ns[r] : ns[r];
     } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cc[r] = (inherit && !col15) ? cc[r] : nr[r];
 
     // K_t = C_t F / V  (column 15 would give F.m: masked); it is K_{t+1} when the covariance was inherited
     if (!inherit) {
@@ -787,7 +796,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
 #pragma unroll
     for (int r = 0; r < 4; ++r) b1[r] = col15 ? kr[r] : cc[r];
     STAMP(0)
-    const d4 x1 = mmT(P, b1);                                // [P C | P K]
+    const d4 x1 = mmT(P, b1);                                // [P C | P K]  (two chains of two for small batches: measured slower)
     d4 b2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) b2[r] = col15 ? nqr[r] : x1[r];
@@ -797,7 +806,11 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     asm volatile("" ::"v"(b2[0]), "v"(b2[1]), "v"(b2[2]), "v"(b2[3]));
 #endif
     STAMP(1)
-    const d4 x2 = mmT(cc, b2);                               // A operand = [C | m]^T: row 15 of the product is never stored
+    // A operand = [C | m]^T: row 15 of the product is never stored.  PIPE (batches that leave a wave alone on its SIMD): the four
+    // MFMAs are spread over the recursion below -- a wave issues in order, and a dependent fp64 MFMA holds it for ~200 cycles.
+    d4 x2;
+#define X2_STEP(k) { x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cc[k], b2[k], x2, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (PIPE) { x2[0] = 0.0; x2[1] = 0.0; x2[2] = 0.0; x2[3] = 0.0; __builtin_amdgcn_sched_barrier(0); X2_STEP(0) } else x2 = mmT(cc, b2);
     STAMP(2)
 
     if (t > 0) {
@@ -813,6 +826,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       psteady = false;
       d4 M = P;
       double rcol = qcol;
+      if constexpr (PIPE) X2_STEP(1)
       if (observed) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + c] = x1[r];
@@ -838,6 +852,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) M[r] = fma(-pk[r], Fc, fma(fr[r], u, P[r]));
       }
+      if constexpr (PIPE) X2_STEP(2)
       vR[c] = rcol;
       wave_sync();                                           // column-15 reads precede the image rewrite
 #ifdef DLM_STAMP
@@ -849,7 +864,12 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       // amplified by the update: removing it every 8th step keeps it at rounding level.
       // Like Smoothing.smoothStep (Smoothing.scala:41) this always uses the table entry g(dt), also for
       // dt == 0 where the filter made an identity advance; only polynomial-type g ignore dt, see DESIGN.md.
-      const d4 Pn = congruence<K>(M, imgA, imgB, idx, val, g, c, (t & 7) == 0);    // G^T M G (first sync covers vR)
+      d4 Pn;                                                                       // G^T M G (first sync covers vR)
+      if constexpr (PIPE) {
+        const d4 yc = congruence_pass1<K>(M, imgA, idx, val, g, c, (t & 7) == 0);
+        X2_STEP(3)
+        Pn = congruence_pass2<K>(yc, imgB, idx, val, g, c, nullptr);
+      } else Pn = congruence<K>(M, imgA, imgB, idx, val, g, c, (t & 7) == 0);
       if (!IRR && may_settle && observed && same_c && (t & 3) == 2) {   // has P stopped moving (and will the next C be this one)?
         const double tol = 1e-13 * iq;
         bool moved = false;
@@ -868,7 +888,8 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
 #endif
       STAMP(4)
       }
-    }
+    } else if constexpr (PIPE) { X2_STEP(1) X2_STEP(2) X2_STEP(3) }
+#undef X2_STEP
     // output: [S_t | s_t] = [C_t | m_t] - C_t [P_t C_t | -q_t]
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[r] = cc[r] - x2[r];
@@ -897,12 +918,12 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
-template <int K, bool IRR>
-__global__ __launch_bounds__(256, SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
+template <int K, bool IRR, bool PIPE = false>
+__global__ __launch_bounds__(256, PIPE ? 2 : SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                        const double* __restrict__ side) {
   __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
   extern __shared__ __attribute__((aligned(16))) char ring_all[];
-  smoother_body<K, IRR>(a, sp, side, lds, ring_all);
+  smoother_body<K, IRR, PIPE>(a, sp, side, lds, ring_all);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1138,6 +1159,7 @@ static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side
   const size_t ring = (size_t)wpb * 2 * (((a.packed & 1) ? packed_rec_bytes(a.d) : (a.d + a.d * a.d) * 8) + 16);   // dynamic LDS: DMA ring, 2 slots per wave
   const dim3 grid((a.N + wpb - 1) / wpb), blk(64 * wpb);
   if (a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), grid, blk, ring, s, a, sp, side);
+  else if (wpb == 1 && !(a.flags & DLM_OPT_NO_PIPE)) hipLaunchKernelGGL((k_smoother_sp16<K, false, true>), grid, blk, ring, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), grid, blk, ring, s, a, sp, side);
   return hipGetLastError();
 }

@@ -61,7 +61,8 @@ enum {
   DLM_OPT_FORCE_WAVE = 1u << 19,        /* 16 <= d <= 48: wave-per-series kernels also for batches of <= 256 series    */
   DLM_OPT_NO_SPARSE_F = 1u << 20,       /* treat F as dense                                                            */
   DLM_OPT_NO_SMALL_BATCH = 1u << 21,    /* d <= 15: the throughput kernels also for batches that leave SIMDs idle      */
-  DLM_OPT_NO_STEADY = 1u << 22          /* d <= 15: every step recomputes the covariance recursion, also once it has settled */
+  DLM_OPT_NO_STEADY = 1u << 22,         /* d <= 15: every step recomputes the covariance recursion, also once it has settled */
+  DLM_OPT_NO_PIPE = 1u << 23            /* d <= 15, small batches: the output product's MFMAs in one block (as at full occupancy) */
 };
 
 /* per-series status bits */

@@ -232,3 +232,30 @@ def test_chain_and_data_csv_round_trip(tmp_path, golden_dir):
     assert open(g).readline().strip() == "time,observation,state"
     back = streaming.read_data(g)
     assert back[0].observation[0] == 1.5 and np.isnan(back[1].observation[0]) and back[2].time == 3.0
+
+
+def test_headline_kernels_keep_their_occupancy(tmp_path):
+    """The C2 kernels are tuned to a register budget: the backward kernel of the K = 2 regular instantiation at <= 96 VGPRs (five
+    waves per SIMD) and the forward kernel at <= 96 (five), with no spills.  A change that costs a wave per SIMD costs ~3 % of the
+    headline and shows up nowhere else -- so the build is checked here (device-only assembly of dlm_sparse16.hip, ~10 s)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from bayesian_dlms_amd import build as b
+    out = tmp_path / "sp16.s"
+    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-S", "--cuda-device-only", "-o", str(out), os.path.join(root, "bayesian_dlms_amd", "csrc", "dlm_sparse16.hip")],
+                          stderr=subprocess.DEVNULL)
+    meta = {}
+    name = None
+    for line in open(out):
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s*\.(vgpr_count|vgpr_spill_count):\s+(\d+)", line)
+        if m and name:
+            meta.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    bwd = [v for k, v in meta.items() if "k_smoother_sp16ILi2ELb0ELb0E" in k]
+    fwd = [v for k, v in meta.items() if "k_filter_sp16ILi2ELb0ELb0ELb0E" in k]
+    assert len(bwd) == 1 and len(fwd) == 1, sorted(meta)
+    assert bwd[0]["vgpr_count"] <= 96 and bwd[0]["vgpr_spill_count"] == 0, bwd
+    assert fwd[0]["vgpr_count"] <= 96 and fwd[0]["vgpr_spill_count"] == 0, fwd
