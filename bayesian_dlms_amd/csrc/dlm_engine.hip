@@ -405,7 +405,14 @@ const char* dlm_last_variant(const dlm_engine* e) { return e ? e->variant : "non
 
 int dlm_engine_set_stream(dlm_engine* e, void* hip_stream) {
   if (!e) return DLM_ERR_ARG;
-  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  hipStream_t next = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  if (next != e->stream) {
+    // the engine's workspaces (side records, tables, staged parameters) belong to whatever runs on its stream: work still in
+    // flight from DLM_OPT_ASYNC calls on the old stream is drained before anything is launched on the new one
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->stream = next;
+  }
   return DLM_OK;
 }
 

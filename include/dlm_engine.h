@@ -114,7 +114,8 @@ int dlm_engine_create(int device, dlm_engine **out);
 void dlm_engine_destroy(dlm_engine *e);
 const char *dlm_last_error(const dlm_engine *e);
 const char *dlm_version(void);
-/* Launch on a caller-owned hipStream_t (NULL = the engine's own stream). */
+/* Launch on a caller-owned hipStream_t (NULL = the engine's own stream).  The engine's workspaces are shared by its calls: a
+ * change of stream first drains the work still in flight on the old one (DLM_OPT_ASYNC calls). */
 int dlm_engine_set_stream(dlm_engine *e, void *hip_stream);
 int dlm_engine_sync(dlm_engine *e);
 /* Name of the kernel variant the last call dispatched to ("generic", "mfma16", ...). */
