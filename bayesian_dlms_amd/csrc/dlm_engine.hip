@@ -268,7 +268,8 @@ int ensure_xplus(dlm_engine* e, const KArgs& k) {
 }
 
 int ensure_ystar(dlm_engine* e, const KArgs& k) {
-  const size_t need = sizeof(double) * (size_t)k.N * (size_t)k.T * (size_t)k.p;
+  // innovations [N][T][p], then one byte per record [N][T+1]: the marks "C_t is C_{t-1}" of the per-wave forward kernel's steady steps
+  const size_t need = sizeof(double) * (size_t)k.N * (size_t)k.T * (size_t)k.p + (((size_t)k.N * (size_t)(k.T + 1) + 15) & ~(size_t)15);
   if (need > e->ystar_bytes) {
     if (e->ystar) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->ystar)); e->ystar = nullptr; e->ystar_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->ystar, need));

@@ -589,6 +589,17 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
   for (int b = 0; b < PT; ++b) ynext[b] = bld(ry, T > 0 ? yoff[b] : OOB, 0);
   bool warm = false;
   double ll = 0.0;   // prediction-error log-likelihood of the series (every lane holds it)
+  // Steady state (time-invariant model, regular grid, every component observed): the covariance recursion converges -- within 30
+  // steps for the C4 model -- and from then on R, Q and the gain are those of the step before: a step is a = G m, e = y - F^T a,
+  // m = a + K e (K^T parked in the image, which a steady step does not use otherwise) and the record store, C from the registers.
+  // Tested every fourth step against the record written the step before (re-read from L2: a copy of C would cost 72 registers
+  // this kernel does not have); a missing component takes the full path again.  marks[t] = 1 tells the backward pass that
+  // C_t is C_{t-1} (one byte per record behind the innovations).
+  const bool may_settle = out && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !pri && !fq && !a.loglik &&
+                          !(a.flags & DLM_OPT_NO_STEADY);
+  unsigned char* marks = innov ? (unsigned char*)(innov + (size_t)a.N * T * p) + (size_t)n * (T + 1) : nullptr;
+  if (marks && lane == 0) marks[0] = 0;
+  bool steady = false;
 
   for (int t = 0; t < T; ++t) {
     // opaque copies of the lane coordinates: the compiler would otherwise hoist the few dozen address computations of
@@ -606,6 +617,51 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
     double ycur[PT];
 #pragma unroll
     for (int b = 0; b < PT; ++b) { ycur[b] = ynext[b]; ynext[b] = bld(ry, t + 1 < T ? yoff[b] : OOB, (t + 1 < T ? t + 1 : 0) * p * 8); }
+    bool missing_here = false;
+#pragma unroll
+    for (int b = 0; b < PT; ++b) missing_here |= jp[b] && !(ycur[b] == ycur[b]);
+    const bool all = __ballot(missing_here) == 0ull;       // every component of y_t observed
+    if (steady && all) {
+      double an[DT];
+      gather_vec<DT, K>(mv, tix, tvl, an);                          // a = G m
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) av[16 * b + c] = an[b];
+      wave_sync();
+      double fcol[PT];
+      if (KF > 0) {
+#pragma unroll
+        for (int b = 0; b < PT; ++b) {
+          double s_ = 0.0;
+#pragma unroll
+          for (int s = 0; s < KFA; ++s) s_ = fma(av[fix[b][s]], fvl[b][s], s_);
+          fcol[b] = s_;
+        }
+      } else {
+        d4 Fm[DT][PT];
+        f_tiles<DT, PT>(Fl, Fm, g, c);
+        matTvec<DT, PT>(Fm, av, g, fcol);
+      }
+#pragma unroll
+      for (int b = 0; b < PT; ++b) {
+        const double e = ycur[b] - fcol[b];
+        bst(res, g == 0 ? yoff[b] : OOB, t * p * 8, e);
+        if (g == 0) ev[16 * b + c] = jp[b] ? e : 0.0;
+      }
+      wave_sync();
+#pragma unroll
+      for (int b = 0; b < DT; ++b) {                                // K e: K^T[j][i] waits at img[j * IL + i]; this lane takes j = g, g + 4, ...
+        double s_ = 0.0;
+        for (int j = g; j < p; j += 4) s_ = fma(img[j * IL + 16 * b + c], ev[j], s_);
+        s_ = sum_g(s_);
+        if (g == 0 && jd[b]) mv[16 * b + c] = av[16 * b + c] + s_;
+      }
+      wave_sync();
+      store_record(rfo, mv, t + 1, g, c);
+      if (marks && lane == 0) marks[t + 1] = 1;
+      continue;
+    }
+    steady = false;
+    if (marks && lane == 0) marks[t + 1] = 0;
 
     // ---- advance: a = G m, R = G C G^T + W dt (into C's registers), dt == 0: identity
     if (dt != 0.0) {
@@ -779,6 +835,26 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
 #pragma unroll
         for (int b = aa; b < DT; ++b) C[aa][b] -= U[aa][b];
       mirror<IL, DT, false>(C, img, g, c);
+      if (may_settle && all && (t & 3) == 3) {   // has the covariance stopped moving?  record t holds C_{t-1}
+        double dmax = 0.0, cmax = 0.0;
+        const int so = t * recb;
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * aa + 4 * r + g;
+              const double old = bld(rfo, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so);
+              dmax = fmax(dmax, fabs(C[aa][b][r] - old)); cmax = fmax(cmax, fabs(C[aa][b][r]));
+            }
+        for (int o_ = 32; o_ > 0; o_ >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o_)); cmax = fmax(cmax, __shfl_xor(cmax, o_)); }
+        if (dmax <= 1e-13 * cmax) {
+          steady = true;
+          wave_sync();
+          to_image<IL, PT, DT>(KT, img, g, c);                      // K^T for the steady steps
+        }
+      }
     }
     wave_sync();
     store_record(rfo, mv, t + 1, g, c);

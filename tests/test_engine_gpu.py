@@ -1905,3 +1905,48 @@ def test_steady_state_steps_of_the_structured_kernels(eng):
     a_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
     b_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_STEADY)
     np.testing.assert_array_equal(a_["theta"], b_["theta"])
+
+
+def test_steady_state_steps_of_the_per_wave_kernels(eng):
+    """16 <= d <= 48 (k_filter_w48 / k_smoother_w48): once the covariance recursion has settled on a regular, fully observed
+    stretch the forward step is a = G m, e = y - F^T a, m = a + K e with the gain parked in LDS, and the record is marked for the
+    backward pass.  Same numbers as with DLM_OPT_NO_STEADY to 1e-10, the usual tolerance against the oracle, frozen covariances
+    on the settled stretch, the full path again after a (partially) missing observation."""
+    rng = np.random.default_rng(53)
+    mod = Dlm.polynomial(2)
+    for _ in range(9):
+        mod = mod * Dlm.polynomial(2)              # d = 20, p = 10
+    T = 160
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    d, q = mat.d, mat.p
+    A = rng.standard_normal((d, d))
+    p = DlmParameters(np.eye(q), A @ A.T / d + 0.1 * np.eye(d), np.zeros(d), np.eye(d))
+    y = rng.standard_normal((5, T, q)).cumsum(axis=1)
+    y[1, 80, :] = np.nan                 # a wholly missing observation
+    y[2, 90, 3] = np.nan                 # a partially missing one
+    y[3, rng.random((T, q)) < 0.1] = np.nan
+    fast = eng.filter_smooth(mat, p, y, flags=_lib.OPT_FORCE_WAVE)
+    assert eng.last_variant == "wave-mfma" and np.all(fast["status"] == 0)
+    full = eng.filter_smooth(mat, p, y, flags=_lib.OPT_FORCE_WAVE | _lib.OPT_NO_STEADY)
+    np.testing.assert_allclose(fast["filt"], full["filt"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(fast["smooth"], full["smooth"], rtol=1e-9, atol=1e-10)
+    C = fast["filt"][0][:, d:]
+    assert np.array_equal(C[120], C[119]) and np.array_equal(C[150], C[100])          # frozen on the settled stretch
+    Cn = full["filt"][0][:, d:]
+    assert not np.array_equal(Cn[120], Cn[119])                                        # (the full path keeps rounding about)
+    C1 = fast["filt"][1][:, d:]
+    assert not np.array_equal(C1[81], C1[79]) and np.array_equal(C1[150], C1[149])     # leaves at the gap, settles again
+    for n in range(4):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, Cc = split(fast["filt"][n], d); sm, S = split(fast["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(Cc, f["C"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-7, atol=1e-8)
+    # filter alone (no innovation buffer, no marks) and the simulation smoother's forward pass (filters y* in place)
+    fo = eng.filter(mat, p, y, flags=_lib.OPT_FORCE_WAVE)
+    np.testing.assert_allclose(fo["filt"], full["filt"], rtol=1e-10, atol=1e-11)
+    z = rng.standard_normal((5, T + 1, d + q))
+    a_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_FORCE_WAVE)
+    b_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_FORCE_WAVE | _lib.OPT_NO_STEADY)
+    np.testing.assert_allclose(a_["theta"], b_["theta"], rtol=1e-9, atol=1e-10)
