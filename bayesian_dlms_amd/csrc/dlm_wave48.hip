@@ -79,6 +79,22 @@ __device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, int voff, int soff
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
+// 16-byte stores.  One wave per SIMD can keep at most 63 vector-memory operations in flight: with 8 bytes per lane a step's 39
+// record stores are all the bandwidth a wave can ask for.  A lane of the tile layout holds rows 4 r + g of its column;
+// v_permlane16_swap of registers r and r + 1 leaves it with two ADJACENT rows of one of them (even d: 16 contiguous bytes).
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x, double y) {
+  const u4 v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x), (unsigned)__double2loint(y), (unsigned)__double2hiint(y)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+// registers (x: rows 4 r + g, y: rows 4 (r + 1) + g)  ->  (lo, hi) = rows (base, base + 1), base = 4 (r + (g & 1)) + (g & 2)
+__device__ __forceinline__ void pair_rows(double x, double y, double& lo, double& hi) {
+  const u2 l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const u2 h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  lo = __hiloint2double((int)h[0], (int)l[0]);
+  hi = __hiloint2double((int)h[1], (int)l[1]);
+}
+
 // Z[a][b] = sum_k X[k][a]^T Y[k][b] over the first `rows` rows of the operands (MFMAs of all-padding k-blocks are
 // skipped).  UP: only the tiles a <= b.  Consecutive MFMAs go to different accumulators.
 template <int KT, int MT, int NT, bool UP>
@@ -567,8 +583,22 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
   for (int b = 0; b < DT; ++b) moff[b] = (jd[b] && g == 0) ? (16 * b + c) * 8 : OOB;
   wave_sync();
 
+  const bool d_even = (d & 1) == 0;
   auto store_record = [&](const __amdgpu_buffer_rsrc_t& rfo, const double* mv, int t, int g, int c) {
     const int so = t * recb;
+    if (d_even) {
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            double lo, hi;
+            pair_rows(C[aa][b][r], C[aa][b][r + 1], lo, hi);
+            const int i = 16 * aa + 4 * (r + (g & 1)) + (g & 2);
+            bst4(rfo, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so, lo, hi);
+          }
+    } else {
 #pragma unroll
     for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
@@ -578,6 +608,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
           const int i = 16 * aa + 4 * r + g;
           bst(rfo, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so, C[aa][b][r]);
         }
+    }
 #pragma unroll
     for (int b = 0; b < DT; ++b) bst(rfo, moff[b], so, mv[16 * b + c]);
   };
@@ -620,8 +651,13 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
     bool missing_here = false;
 #pragma unroll
     for (int b = 0; b < PT; ++b) missing_here |= jp[b] && !(ycur[b] == ycur[b]);
-    const bool all = __ballot(missing_here) == 0ull;       // every component of y_t observed
-    if (steady && all) {
+    bool all = __ballot(missing_here) == 0ull;             // every component of y_t observed
+    if (__builtin_amdgcn_readfirstlane((int)(steady && all))) {
+      // a stretch of steady steps as a loop of its own: one back edge, so that the wait for the next observation counts the
+      // stores behind it (vmcnt(42)) -- at the head of the big loop, where two paths meet, it would be vmcnt(0): every step
+      // would sit out the latency of its 39 record stores.  (The flags are read through readfirstlane: a branch the compiler
+      // takes for divergent would make t a vector register and every buffer store a waterfall loop.)
+      do {
       double an[DT];
       gather_vec<DT, K>(mv, tix, tvl, an);                          // a = G m
 #pragma unroll
@@ -658,7 +694,16 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
       wave_sync();
       store_record(rfo, mv, t + 1, g, c);
       if (marks && lane == 0) marks[t + 1] = 1;
-      continue;
+      if (++t >= T) break;
+      missing_here = false;
+#pragma unroll
+      for (int b = 0; b < PT; ++b) {
+        ycur[b] = ynext[b]; ynext[b] = bld(ry, t + 1 < T ? yoff[b] : OOB, (t + 1 < T ? t + 1 : 0) * p * 8);
+        missing_here |= jp[b] && !(ycur[b] == ycur[b]);
+      }
+      all = __ballot(missing_here) == 0ull;
+      } while (all);
+      if (t >= T) break;     // (otherwise: step t, whose observation is in ycur, takes the full path below)
     }
     steady = false;
     if (marks && lane == 0) marks[t + 1] = 0;
@@ -849,7 +894,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
               dmax = fmax(dmax, fabs(C[aa][b][r] - old)); cmax = fmax(cmax, fabs(C[aa][b][r]));
             }
         for (int o_ = 32; o_ > 0; o_ >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o_)); cmax = fmax(cmax, __shfl_xor(cmax, o_)); }
-        if (dmax <= 1e-13 * cmax) {
+        if (__builtin_amdgcn_readfirstlane((int)(dmax <= 1e-13 * cmax))) {   // (every lane holds the same maxima: a scalar flag)
           steady = true;
           wave_sync();
           to_image<IL, PT, DT>(KT, img, g, c);                      // K^T for the steady steps
@@ -1032,6 +1077,17 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
       matTvec<DT, DT>(C, qv, g, cq);                              // C q
       if constexpr (VI_LDS) vi_matvec(ev, g, c, vcol); else matTvec<PT, PT>(Vi, ev, g, vcol);   // v = Vm^-1 e
       const int so = t * recb;
+      if ((d & 1) == 0) {   // 16 bytes per lane: rows (i, i + 1) of the lane's column, i = 16 aa + 8 h + 2 g
+#pragma unroll
+        for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+          for (int b = 0; b < DT; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int i = 16 * aa + 8 * h + 2 * g;
+              bst4(rout, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so, img[i * IL + 16 * b + c], img[(i + 1) * IL + 16 * b + c]);
+            }
+      } else {
 #pragma unroll
       for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
@@ -1041,6 +1097,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
             const int i = 16 * aa + 4 * r + g;
             bst(rout, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so, img[i * IL + 16 * b + c]);
           }
+      }
 #pragma unroll
       for (int b = 0; b < DT; ++b) bst(rout, g == 0 ? moff[b] : OOB, so, mcol[b] + cq[b]);
       request(t - 1, g, c, !mk);
