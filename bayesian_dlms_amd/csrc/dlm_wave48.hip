@@ -85,7 +85,7 @@ __device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t r, int voff, int soff
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, int voff, int soff, double x, double y) {
   const u4 v = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x), (unsigned)__double2loint(y), (unsigned)__double2hiint(y)};
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);   // (nontemporal stores measured slower: 22.1 against 18.7 ms at C4)
 }
 // registers (x: rows 4 r + g, y: rows 4 (r + 1) + g)  ->  (lo, hi) = rows (base, base + 1), base = 4 (r + (g & 1)) + (g & 2)
 __device__ __forceinline__ void pair_rows(double x, double y, double& lo, double& hi) {
