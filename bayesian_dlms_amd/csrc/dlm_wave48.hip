@@ -2024,7 +2024,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
     }
     wave_sync();
     double hc[DT];
-    if (reuse) {
+    if (__builtin_expect(reuse, 1)) {   // (the likely path: the register allocator then spills in the full step, not here)
 #ifdef DLM_STAMP
       ++n_reuse;
 #endif
