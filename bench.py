@@ -358,8 +358,10 @@ def main():
             line["roofline"]["frac_of_measured"] = achieved / pm
             tr = line["roofline"]["traffic"]
             if tr:   # what actually crossed the HBM interface per launch (PMC, profiles/), as a rate: below `achieved` where the
-                     # backward pass fetches only the mean of a record whose covariance it already holds
+                     # backward pass fetches only the mean of a record whose covariance it already holds -- and
+                     # the fraction of the copy rate is that of the bytes really moved
                 line["roofline"]["traffic_GBps"] = tr / (dom_ms * 1e-3) / 1e9
+                line["roofline"]["frac_of_measured"] = line["roofline"]["traffic_GBps"] / pm
             line["roofline"]["path_GBps"] = (fwd_u + bwd_u) * nt / ((f_ms + b_ms) * 1e-3) / 1e9
         if cfg in ("c3", "c4g"):
             st = last["state"]
