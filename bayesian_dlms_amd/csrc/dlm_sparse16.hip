@@ -427,7 +427,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
   // m = a + K e: a gather on one 16-vector instead of the congruence, the products with F and the rank-one update.  The
   // record (the same C, the new m) is stored as always.  A missing observation takes the full step again (C changes),
   // and the test starts over.  The backward pass learns from the sign of the side record's 1/Q that C_t is C_{t-1}.
-  const bool may_settle = !IRR && !SIM && !(a.flags & DLM_OPT_NO_STEADY);
+  const bool may_settle = !IRR && !(a.flags & DLM_OPT_NO_STEADY);   // (the simulation smoother's pass too: y* has the covariance recursion of y)
   bool steady = false;
   double Kst = 0.0, rq_st = 0.0, Q_st = 0.0;
   double ychunk = 0.0;
@@ -468,7 +468,28 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
 #endif
       // the mean rides in row 15 of the tile (lanes g == 3 of register 3) and in column 15
       if (g == 3) vRF[c] = cc[3];
+      if (SIM) {   // x+ and the normals of the next four records, as in the full step
+        vX[c] = xcol;
+        if ((t & 3) == 0) {
+          const int tr = t + 1 + g;
+          double zz = 0.0;
+          if (c <= d && tr <= T) zz = zin ? zin[(size_t)tr * (d + 1) + c] : philox_normal(a.seed, series, (unsigned)tr, (unsigned)c);
+          vZ[lane] = zz;
+        }
+      }
       wave_sync();
+      if (SIM) {   // x+_t = G x+_{t-1} + L_W z ;  y*_t = y_t - F^T x+_t - sqrt(V) z_v   (regular grid: dt = 1)
+        const double* zr = vZ + 16 * (t & 3);
+        double xg = vX[idx[0]] * val[0];
+#pragma unroll
+        for (int s = 1; s < K; ++s) xg = fma(vX[idx[s]], val[s], xg);
+        double wl;
+        if (wdiag) wl = wsd * zr[c];
+        else { wl = 0.0; for (int k = 0; k <= c && k < d; ++k) wl = fma(imgW[c * LD + k], zr[k], wl); }
+        xcol = vc ? wl + xg : 0.0;
+        yt = yt - fma(sqV, zr[d], row_sum(Fc * xcol));
+        if (g == 0 && vc) xp[(size_t)(t + 1) * d + c] = xcol;
+      }
       double ac = vRF[idx[0]] * val[0];
 #pragma unroll
       for (int s = 1; s < K; ++s) ac = fma(vRF[idx[s]], val[s], ac);      // a = G m (row 15 of the table: the unit row)
@@ -989,14 +1010,19 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
   double neq = sd[2 * T], niq = sd[2 * T + 1];
   double ychunk = 0.0;
 
+  bool inh = false;       // C_t is C_{t+1} (the forward pass's mark on record t + 1: 1 / Q negated): K_t is K_{t+1}
+  double kcs = 0.0;
   for (int t = T; t >= 0; --t) {
     const d4 cc = ncc;
     const double mcol = nm, xcol = nx;
     const double eq = uniform_from_lane(neq, 0), iq = uniform_from_lane(niq, 0);
+    const bool same_prev = !IRR && iq < 0.0;                 // C_{t-1} is C_t: the next record is fetched as its mean alone
     {
       const int tp = t > 0 ? t - 1 : 0;
+      if (!same_prev) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], tp * recb);
+        for (int r = 0; r < 4; ++r) ncc[r] = buf_load(rin, bin, offC[r], tp * recb);
+      }
       nm = buf_load(rin, bin, offMl, tp * recb);
       nx = vc ? xp[(size_t)tp * d + c] : 0.0;
       neq = sd[2 * tp]; niq = sd[2 * tp + 1];
@@ -1061,12 +1087,15 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
       rV = 1.0 / Vt;
     }
     if (observed) {
-      double kc = 0.0;
+      if (!inh) {
+        double kc = 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) kc = fma(cc[r], Fr[r], kc);
-      kc = sum_g(kc) * rV;
-      rcol = fma(Fc, eq - row_sum(kc * qcol), qcol);
+        for (int r = 0; r < 4; ++r) kc = fma(cc[r], Fr[r], kc);
+        kcs = sum_g(kc) * rV;
+      }
+      rcol = fma(Fc, eq - row_sum(kcs * qcol), qcol);
     }
+    inh = same_prev;
     const int gi = (IRR && a.g_index) ? a.g_index[t - 1] : 0;   // G of the step into record t
     const double dtt = (IRR && a.dt) ? a.dt[t - 1] : 1.0;
     if (IRR && gi != gcol) {

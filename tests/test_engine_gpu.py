@@ -1900,11 +1900,16 @@ def test_steady_state_steps_of_the_structured_kernels(eng):
         a1 = eng.filter_smooth(ms, p, y[:, :Ts])
         b1 = eng.filter_smooth(ms, p, y[:, :Ts], flags=_lib.OPT_NO_STEADY)
         np.testing.assert_allclose(a1["smooth"], b1["smooth"], rtol=1e-11, atol=1e-12)
-    # the simulation smoother and the samplers read positive 1/Q from their own forward passes: unaffected
+    # the simulation smoother's forward pass (y* has the covariance recursion of y) takes the same steady steps, its backward
+    # pass the mean-only records: same draws and statistics to 1e-10
     z = rng.standard_normal((6, T + 1, 14))
-    a_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
-    b_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_STEADY)
-    np.testing.assert_array_equal(a_["theta"], b_["theta"])
+    a_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH, want_stats=True)
+    b_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_STEADY, want_stats=True)
+    np.testing.assert_allclose(a_["theta"], b_["theta"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(a_["stats"], b_["stats"], rtol=1e-9)
+    ph = eng.ffbs(mat, p, y, seed=5, flags=_lib.OPT_FFBS_SIMSMOOTH)          # the Philox stream
+    pg = eng.ffbs(mat, p, y, seed=5, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_STEADY)
+    np.testing.assert_allclose(ph["theta"], pg["theta"], rtol=1e-10, atol=1e-11)
 
 
 def test_steady_state_steps_of_the_per_wave_kernels(eng):
