@@ -1188,7 +1188,10 @@ static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side
   const size_t ring = (size_t)wpb * 2 * (((a.packed & 1) ? packed_rec_bytes(a.d) : (a.d + a.d * a.d) * 8) + 16);   // dynamic LDS: DMA ring, 2 slots per wave
   const dim3 grid((a.N + wpb - 1) / wpb), blk(64 * wpb);
   if (a.g_index || a.dt || a.f_stride || a.v_tstride || a.w_tstride) hipLaunchKernelGGL((k_smoother_sp16<K, true>), grid, blk, ring, s, a, sp, side);
-  else if (wpb == 1 && !(a.flags & DLM_OPT_NO_PIPE)) hipLaunchKernelGGL((k_smoother_sp16<K, false, true>), grid, blk, ring, s, a, sp, side);
+#ifndef DLM_PIPE_MAX
+#define DLM_PIPE_MAX 3072   // up to three waves per SIMD (measured: 1.86 -> 1.78 ms at 2500 series, 3.00 -> 3.17 at 5000)
+#endif
+  else if (a.N <= DLM_PIPE_MAX && !(a.flags & DLM_OPT_NO_PIPE)) hipLaunchKernelGGL((k_smoother_sp16<K, false, true>), grid, blk, ring, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), grid, blk, ring, s, a, sp, side);
   return hipGetLastError();
 }
