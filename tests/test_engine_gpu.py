@@ -1955,3 +1955,33 @@ def test_steady_state_steps_of_the_per_wave_kernels(eng):
     a_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_FORCE_WAVE)
     b_ = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_FORCE_WAVE | _lib.OPT_NO_STEADY)
     np.testing.assert_allclose(a_["theta"], b_["theta"], rtol=1e-9, atol=1e-10)
+
+
+def test_svd_filter_steady_state_reuse(eng):
+    """Once the posterior factors have stopped moving (largest change <= 1e-11 of the largest entry) the SVD filter reuses both
+    decompositions and only the mean moves; DLM_OPT_FORCE_GENERIC recomputes them every step.  Same covariances and means to 1e-8
+    (the path is held to 1e-7), against the Kalman filter of the oracle, and the full path again after a missing observation."""
+    rng = np.random.default_rng(61)
+    mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+    T = 400
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    p = DlmParameters([[1.0]], np.diag([0.3, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4]), np.zeros(13), np.eye(13))   # settles within ~80 steps
+    y = rng.standard_normal((3, T, 1)).cumsum(axis=1)
+    y[1, 250, 0] = np.nan
+    fast = eng.svd_filter(mat, p, y)
+    assert eng.last_variant == "svd-jacobi" and np.all(fast["status"] == 0)
+    full = eng.svd_filter(mat, p, y, flags=_lib.OPT_FORCE_GENERIC)
+    om = omodel(mat)
+    for n in range(3):
+        m, C = _svd_cov(fast["svd"][n], 13)
+        m2, C2 = _svd_cov(full["svd"][n], 13)
+        np.testing.assert_allclose(m, m2, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(C, C2, rtol=1e-8, atol=1e-9)
+        kf = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y[n])
+        np.testing.assert_allclose(m, kf["m"], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(C.transpose(0, 2, 1).reshape(T + 1, 169), kf["C"], rtol=1e-7, atol=1e-8)
+    # frozen factors on the settled stretch of the undisturbed series; moving again after the gap of series 1
+    r0 = fast["svd"][0]
+    assert np.array_equal(r0[300, 13:], r0[299, 13:])
+    r1 = fast["svd"][1]
+    assert not np.array_equal(r1[252, 13:], r1[249, 13:])
