@@ -71,6 +71,9 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // keeps its (up to 4) rows of the two columns in registers from the inner products to the rotation.
 // warm: V already holds an orthogonal matrix close to the answer (the right vectors of the same decomposition one
 // time step earlier): A is first multiplied by it, after which one or two sweeps suffice instead of six to ten.
+#ifndef JACOBI_ENDGAME
+#define JACOBI_ENDGAME 1e-13
+#endif
 __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V, double* sig, bool warm = false) {
   if (!warm) {
     for (int k = lane; k < n * n; k += 64) M17(V, k % n, k / n) = (k % n == k / n) ? 1.0 : 0.0;
@@ -127,7 +130,7 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
       // columns count as orthogonal once |a.b| <= 1e-14 |a||b| (fp64 dot products of <= 32 terms)
       const double g2 = ga * ga, ab = al * be;
       const bool rot = act && ga != 0.0 && g2 > 1e-28 * ab;
-      big_any |= act && g2 > 1e-16 * ab;   // a rotation above 1e-8: not yet in the quadratic endgame
+      big_any |= act && g2 > JACOBI_ENDGAME * ab;   // a rotation above 3e-7: not yet in the quadratic endgame
       if (rot) {
         // tan of the rotation angle from the raw hardware estimates (~1e-7 relative: any t gives an exact rotation,
         // a slightly wrong one only costs a little convergence); c and s from it at full accuracy, c^2 + s^2 = 1
@@ -151,9 +154,9 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
       }
       rot_any |= rot;
     }
-    // Converged when a sweep rotated nothing -- or when all its rotations were below 1e-8: the off-diagonal mass
-    // then drops quadratically to ~1e-16 within this very sweep, and the verification sweep (a third of the work
-    // with a warm start) can be skipped.
+    // Converged when a sweep rotated nothing -- or when all its rotations were below 3e-7: the off-diagonal mass
+    // then drops quadratically to ~1e-13 within this very sweep (two decades below the 1e-11 at which factors count as
+    // settled), and the verification sweep (a third of the work with a warm start) can be skipped.
     conv = (__ballot(rot_any) == 0ull) || (__ballot(big_any) == 0ull);
   }
   ssync();
