@@ -358,7 +358,7 @@ size_t svd_sampler_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 1
 #ifndef SVD_SETTLE_TOL
 #define SVD_SETTLE_TOL 1e-11
 #endif
-__global__ __launch_bounds__(64) void k_svd_filter(KArgs a, double* __restrict__ rec_out) {
+__global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restrict__ rec_out) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = 2 * d + dd;
