@@ -687,7 +687,8 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
 #pragma unroll
       for (int b = 0; b < DT; ++b) {                                // K e: K^T[j][i] waits at img[j * IL + i]; this lane takes j = g, g + 4, ...
         double s_ = 0.0;
-        for (int j = g; j < p; j += 4) s_ = fma(img[j * IL + 16 * b + c], ev[j], s_);
+#pragma unroll
+        for (int jj = 0; jj < 4 * PT; ++jj) s_ = fma(img[(4 * jj + g) * IL + 16 * b + c], ev[4 * jj + g], s_);   // (rows beyond p are zero padding: a compile-time trip count lets the LDS reads go out together)
         s_ = sum_g(s_);
         if (g == 0 && jd[b]) mv[16 * b + c] = av[16 * b + c] + s_;
       }
