@@ -16,6 +16,7 @@ OPT_STATS_OUTER = 1 << 4
 OPT_ASYNC = 1 << 5
 OPT_FFBS_SIMSMOOTH = 1 << 6
 OPT_PACKED_SYM = 1 << 7
+OPT_MODEL_UNCHANGED = 1 << 8
 OPT_NO_LANE = 1 << 16
 OPT_NO_SAMPLER16 = 1 << 17
 OPT_NO_WAVE = 1 << 18

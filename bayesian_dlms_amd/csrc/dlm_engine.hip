@@ -42,6 +42,18 @@ struct dlm_engine {
   bool has_comm = false;
   std::set<void*> buffers;     // dlm_buffer_alloc allocations still owned by the caller (released at destroy)
   hipEvent_t order_ev = nullptr;   // dlm_engine_wait_stream / dlm_stream_wait_engine
+  // The structure analysis of the last call (what analyse_g left behind), reused by DLM_OPT_MODEL_UNCHANGED and -- in host
+  // mode, where the tables can be compared -- whenever G and F are bit for bit the same: two stream round trips per call less.
+  struct Analysis {
+    bool valid = false;
+    int d = 0, p = 0, n_g = 0, branch = 0;      // branch: 0 none, 1 structured d <= 15 tables, 2 per-wave / tiled tables
+    long long f_stride = 0;
+    unsigned generic = 0;
+    int sparse_k = 0, spb_k = 0, spf_k = 0;
+    bool have_spb = false, have_spf = false;
+    std::vector<double> g_host, f_host;         // host-mode calls: the tables analysed
+  } an;
+  bool an_touched = true;
 };
 
 namespace {
@@ -116,6 +128,8 @@ class Stager {
 
 int check_common(dlm_engine* e, const dlm_model_desc* m, const dlm_params_desc* p, const dlm_options* o) {
   if (!e) return DLM_ERR_ARG;
+  if (!e->an_touched) e->an.valid = false;   // the call before this one took a model but did not analyse it: DLM_OPT_MODEL_UNCHANGED speaks of ITS model
+  e->an_touched = false;
   if (!m || !p || !o) return fail(e, DLM_ERR_ARG, "null descriptor");
   if (m->d < 1 || m->p < 1 || m->T < 1 || m->N < 1) return fail(e, DLM_ERR_ARG, "d, p, T, N must be >= 1 (the reference throws on empty input, KalmanFilter.scala:116-117)");
   if (!m->F || !m->G || m->n_g < 1) return fail(e, DLM_ERR_ARG, "model tables F/G missing");
@@ -201,7 +215,41 @@ int analyse_g_tiled(dlm_engine* e, KArgs& k, const double* G_user, bool host_mod
   return DLM_OK;
 }
 
+int analyse_g_fresh(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode);
+
+// analyse_g with the cache of the last call's result in front of it
 int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
+  dlm_engine::Analysis& an = e->an;
+  e->an_touched = true;
+  const int branch = tiled_analysis_wanted(k) ? 2 : (fast_shape_ok(k) ? 1 : 0);
+  const unsigned generic = k.flags & DLM_OPT_FORCE_GENERIC;
+  bool same = an.valid && an.d == k.d && an.p == k.p && an.n_g == k.n_g && an.branch == branch && an.f_stride == k.f_stride &&
+              an.generic == generic;
+  const size_t gn = (size_t)k.d * k.d * (size_t)k.n_g, fn = (size_t)k.d * k.p;
+  if (same && host_mode) {   // host pointers: compare the tables themselves (the caller's F is staged by now: compare the user's copy of G and our copy of F's source)
+    same = an.g_host.size() == gn && memcmp(an.g_host.data(), G_user, gn * sizeof(double)) == 0;
+    if (same && branch == 2 && !k.f_stride) same = false;   // (F of a host-mode call is only known staged: analysed afresh, it is one small copy)
+  } else if (same) same = (k.flags & DLM_OPT_MODEL_UNCHANGED) != 0;
+  if (same) {
+    e->sparse_k = an.sparse_k;
+    k.spb = an.have_spb ? e->spb_dev : nullptr;
+    k.spb_k = an.spb_k;
+    k.spf = an.have_spf ? e->spf_dev : nullptr;
+    k.spf_k = an.spf_k;
+    return DLM_OK;
+  }
+  an.valid = false;
+  const int rc = analyse_g_fresh(e, k, G_user, host_mode);
+  if (rc) return rc;
+  an.valid = true; an.d = k.d; an.p = k.p; an.n_g = k.n_g; an.branch = branch; an.f_stride = k.f_stride; an.generic = generic;
+  an.sparse_k = e->sparse_k; an.spb_k = k.spb_k; an.spf_k = k.spf_k; an.have_spb = k.spb != nullptr; an.have_spf = k.spf != nullptr;
+  an.g_host.clear();
+  if (host_mode) an.g_host.assign(G_user, G_user + gn);
+  (void)fn;
+  return DLM_OK;
+}
+
+int analyse_g_fresh(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   e->sparse_k = 0;
   k.spb = nullptr;
   if (tiled_analysis_wanted(k)) return analyse_g_tiled(e, k, G_user, host_mode);

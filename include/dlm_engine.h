@@ -55,6 +55,8 @@ enum {
   DLM_OPT_PACKED_SYM = 1u << 7,         /* state records leave PACKED: [mean (d) | lower triangle of the covariance by rows],
                                            dlm_packed_record_doubles(d) doubles per record (see below)              */
   /* Kernel-selection overrides: measurements and tests only, results do not depend on them.           */
+  DLM_OPT_MODEL_UNCHANGED = 1u << 8,    /* device-memory calls: F, G and the time grid are bit for bit those of this engine's previous call -- its
+                                         * analysis of their structure is reused (a host-memory call compares the tables itself)   */
   DLM_OPT_NO_LANE = 1u << 16,           /* no lane-per-series kernels (d <= 5, p = 1)                                  */
   DLM_OPT_NO_SAMPLER16 = 1u << 17,      /* no register-tile backward sampler: the generic kernel                       */
   DLM_OPT_NO_WAVE = 1u << 18,           /* 16 <= d <= 48: the workgroup-per-series kernels instead of wave-per-series  */

@@ -1985,3 +1985,35 @@ def test_svd_filter_steady_state_reuse(eng):
     assert np.array_equal(r0[300, 13:], r0[299, 13:])
     r1 = fast["svd"][1]
     assert not np.array_equal(r1[252, 13:], r1[249, 13:])
+
+
+def test_structure_analysis_cache_follows_the_model(eng):
+    """The engine keeps the structure analysis of the last call (DLM_OPT_MODEL_UNCHANGED from the Python layer when the staged F, G
+    and time grid are bit for bit the same; host-memory calls compare the tables themselves).  Same model, other parameters:
+    reused; another model of the same shape, or an entry point in between that analyses nothing: analysed afresh."""
+    from bayesian_dlms_amd.engine import Engine
+    import torch
+    rng = np.random.default_rng(67)
+    T = 50
+    times = np.arange(1, T + 1, dtype=np.float64)
+    modA = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+    modB = Dlm.polynomial(1) + Dlm.seasonal(12, 6)          # same d = 13, another G
+    matA, matB = materialise(modA, times), materialise(modB, times)
+    p1 = DlmParameters([[1.0]], np.diag(rng.uniform(0.1, 0.5, 13)), np.zeros(13), np.eye(13))
+    p2 = DlmParameters([[2.0]], np.diag(rng.uniform(0.1, 0.5, 13)), np.ones(13), 2.0 * np.eye(13))
+    y = torch.as_tensor(rng.standard_normal((4, T, 1)).cumsum(axis=1), device="cuda")
+    fresh = lambda mat, p: {k: v.cpu().numpy() for k, v in Engine(0).filter_smooth(mat, p, y).items() if k in ("filt", "smooth")}
+    seq = [(matA, p1), (matA, p1), (matA, p2), (matB, p2), (matB, p1), (matA, p1)]
+    for i, (mat, p) in enumerate(seq):
+        out = eng.filter_smooth(mat, p, y)
+        ref = fresh(mat, p)
+        np.testing.assert_array_equal(out["filt"].cpu().numpy(), ref["filt"], err_msg=f"call {i}")
+        np.testing.assert_array_equal(out["smooth"].cpu().numpy(), ref["smooth"], err_msg=f"call {i}")
+        if i == 3:   # an entry point that analyses nothing, on yet another model of the same shape, in between
+            eng.svd_filter(matA, p1, y)
+    # host-memory calls: the tables are compared by the engine itself
+    yh = y.cpu().numpy()
+    for mat, p in seq[2:5]:
+        out = eng.filter_smooth(mat, p, yh)
+        ref = fresh(mat, p)
+        np.testing.assert_array_equal(out["filt"], ref["filt"])
