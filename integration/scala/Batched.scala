@@ -83,6 +83,7 @@ object Native {
   val StatsOuter = 1 << 4         // GibbsWishart statistics
   val FfbsSimSmooth = 1 << 6      // Durbin-Koopman simulation smoother instead of backward sampling
   val PackedSym = 1 << 7
+  val ModelUnchanged = 1 << 8     // F, G and the time grid are those of this engine's previous call: its structure analysis is reused
   val NoSteady = 1 << 22          // every step recomputes the covariance recursion, also once it has settled (the reference's arithmetic, step for step)
   /** every reference quirk switched on: results are the reference's arithmetic, not the textbook's (SURVEY Q1 / Q2 / Q9) */
   val LiteralReference = SmootherCompatQ1 | SvdRawWQ2 | SvdSamplerQ9
