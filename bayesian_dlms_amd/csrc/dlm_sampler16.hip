@@ -274,6 +274,9 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
     nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
   }
+  const bool f1 = p == 1 && !a.f_stride;
+  const double Fl1 = (f1 && lane < d) ? a.F[lane] : 0.0;
+  double ych = 0.0;
   for (int t = T - 1; t >= 0; --t) {
     // the normals of records t, t-1, t-2, t-3 (16 components each) are drawn together, one per lane, every fourth step:
     // the generator is the same few hundred instructions whether 13 lanes or 64 need a value
@@ -285,7 +288,17 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
-    if (a.stats && y && lane < p) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
+    if (a.stats && y && f1) {
+      // one observation component, time-invariant F (C2 / C3): F.theta by a wave reduction on registers.  The loop below issues d
+      // dependent global loads -- ~4000 cycles of every step for a wave with one neighbour on its SIMD (measured: the whole
+      // steady step took 3.6 us)
+      const int kk = (T - 1 - t) & 63;                       // the observations 64 at a time: a load per step would be waited for at once,
+      if (kk == 0) ych = (t - lane >= 0) ? y[t - lane] : 0.0;   // together with the record requested for the next step
+      const double yv = readlane_d(ych, kk);
+      double part = lane < d ? Fl1 * thv[lane] : 0.0;
+      for (int o_ = 8; o_ > 0; o_ >>= 1) part += __shfl_xor(part, o_);
+      if (lane == 0 && yv == yv) { ssy += (yv - part) * (yv - part); nob += 1.0; }
+    } else if (a.stats && y && lane < p) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
       const double yv = y[(size_t)t * p + lane];
       if (yv == yv) {
         const double* Fj = a.F + (size_t)t * a.f_stride + (size_t)lane * d;
