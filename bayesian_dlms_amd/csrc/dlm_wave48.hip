@@ -1160,7 +1160,27 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
               const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
               Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? Vr[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
             }
-        if (direct_inverse<PT>(Vm, Vi, p, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
+        // a diagonal V_m (the usual case: independent measurement errors) inverts entry by entry -- with partially missing
+        // observations the pattern changes at nearly every step, and the direct inverse is p sequential pivots each time
+        bool offd = false;
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) offd |= (16 * aa + 4 * r + g != 16 * b + c) && Vm[aa][b][r] != 0.0;
+        if (__ballot(offd) == 0ull) {
+#pragma unroll
+          for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+            for (int b = 0; b < PT; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const bool dg = (16 * aa + 4 * r + g == 16 * b + c) && jp[b];
+                if (dg && !(Vm[aa][b][r] > 0.0)) st |= DLM_ST_NOT_PD;
+                Vi[aa][b][r] = dg ? 1.0 / Vm[aa][b][r] : 0.0;
+              }
+        } else if (direct_inverse<PT>(Vm, Vi, p, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
 #pragma unroll
         for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
@@ -1603,7 +1623,25 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
               const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
               Vm[aa][b][r] = (i < p && jp[b]) ? ((__shfl(obs[aa], 4 * r + g) != 0.0 && obs[b] != 0.0) ? V[i + j * p] : (i == j ? 1.0 : 0.0)) : 0.0;
             }
-        if (direct_inverse<PT>(Vm, Vi, p, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
+        bool offd = false;   // a diagonal V_m inverts entry by entry (see k_smoother_w48)
+#pragma unroll
+        for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+          for (int b = 0; b < PT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) offd |= (16 * aa + 4 * r + g != 16 * b + c) && Vm[aa][b][r] != 0.0;
+        if (__ballot(offd) == 0ull) {
+#pragma unroll
+          for (int aa = 0; aa < PT; ++aa)
+#pragma unroll
+            for (int b = 0; b < PT; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const bool dg = (16 * aa + 4 * r + g == 16 * b + c) && jp[b];
+                if (dg && !(Vm[aa][b][r] > 0.0)) st |= DLM_ST_NOT_PD;
+                Vi[aa][b][r] = dg ? 1.0 / Vm[aa][b][r] : 0.0;
+              }
+        } else if (direct_inverse<PT>(Vm, Vi, p, img, inv, lane, g, c)) st |= DLM_ST_NOT_PD;
 #pragma unroll
         for (int aa = 0; aa < PT; ++aa)
 #pragma unroll
