@@ -68,6 +68,46 @@ def test_c2_full_size_properties(eng):
     _properties(eng, mat, p, y, [0, 4999, 9999, 1234, 7777], "sparse16", 1e-8, 1e-7)
 
 
+def test_c2_full_size_steady_state_path(eng):
+    """The bench workload itself (no missing values): 64 % of the forward and 19 % of the backward steps take the steady-state
+    path and the backward pass fetches most records as their mean alone.  The same properties, the oracle at full length, and the
+    whole batch against the run with DLM_OPT_NO_STEADY (every step the full recursion)."""
+    import torch
+    from bench import seasonal_c2, simulate
+    mod, p = seasonal_c2()
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    y = torch.as_tensor(simulate(mat, p, 10000, seed=20261005), device="cuda")
+    _properties(eng, mat, p, y, [0, 4999, 9999, 4321], "sparse16", 1e-8, 1e-7)
+    a = eng.filter_smooth(mat, p, y)
+    C = a["filt"][:, :, 13:]
+    assert torch.equal(C[:, 900], C[:, 600])                       # frozen covariances on the settled stretch
+    b = eng.filter_smooth(mat, p, y, flags=_lib.OPT_NO_STEADY)
+    for k in ("filt", "smooth"):
+        diff = float((a[k] - b[k]).abs().max())
+        scale = float(b[k].abs().max())
+        assert diff <= 1e-10 * scale, (k, diff, scale)
+
+
+def test_c4_full_size_steady_state_path(eng):
+    """BASELINE configs[3] without missing components: the covariance recursion settles within 30 steps and both per-wave passes
+    stream records from then on.  Properties, oracle at full length, and the batch against DLM_OPT_NO_STEADY."""
+    import torch
+    mod = Dlm.polynomial(2)
+    for _ in range(19):
+        mod = mod * Dlm.polynomial(2)
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    rng = np.random.default_rng(41); A = np.random.default_rng(40).standard_normal((40, 40))
+    p = DlmParameters(np.eye(20), A @ A.T / 40 + 0.1 * np.eye(40), np.zeros(40), np.eye(40))
+    y = torch.as_tensor(rng.standard_normal((2000, 1000, 20)).cumsum(axis=1), device="cuda")
+    _properties(eng, mat, p, y, [0, 1999, 1024], "wave-mfma", 1e-7, 1e-6)
+    a = eng.filter_smooth(mat, p, y)
+    b = eng.filter_smooth(mat, p, y, flags=_lib.OPT_NO_STEADY)
+    for k in ("filt", "smooth"):
+        diff = float((a[k] - b[k]).abs().max())
+        scale = float(b[k].abs().max())
+        assert diff <= 1e-9 * scale, (k, diff, scale)
+
+
 def test_c4_full_size_properties(eng):
     """BASELINE configs[3]: |*| of 20 polynomial(2), d = 40, p = 20, 2000 series x T = 1000 (SURVEY 8d inputs)."""
     import torch
