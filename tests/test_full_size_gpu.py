@@ -174,6 +174,35 @@ def test_c3_full_size_ffbs_properties(eng):
     assert abs(float(zsc.mean())) < 2e-3 and abs(float(zsc.var()) - 1.0) < 5e-3   # 1.3e8 standardised draws
 
 
+def test_c3_full_size_reference_form_sampler(eng):
+    """BASELINE configs[2] with the reference's backward sampler (Smoothing.sampleDlm, the default of dlm_ffbs_batch): 10 000
+    series x T = 1000 on the register-tile kernel with its steady-state reuse of J, H and the factor.  The same seed reproduces the
+    draw, a shard with series_offset draws the same states, a few series equal the generic kernel's draws (the reference's
+    operation sequence in LDS) at full length, and the statistics are those of the states."""
+    import torch
+    from bench import seasonal_c2, simulate
+    mod, p = seasonal_c2()
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    y = torch.as_tensor(simulate(mat, p, 10000, seed=78), device="cuda")
+    a = eng.ffbs(mat, p, y, seed=11)
+    assert eng.last_variant == "sparse16-sampler" and int((a["status"] != 0).sum().item()) == 0
+    b = eng.ffbs(mat, p, y, seed=11)
+    assert torch.equal(a["theta"], b["theta"]) and torch.equal(a["stats"], b["stats"])
+    lo, hi = 6250, 7500                                    # rank 5 of 8
+    c = eng.ffbs(mat, p, y[lo:hi], seed=11, series_offset=lo)
+    assert torch.equal(c["theta"], a["theta"][lo:hi]) and torch.equal(c["stats"], a["stats"][lo:hi])
+    pick = [0, 5000, 9999]
+    for n in pick:
+        g = eng.ffbs(mat, p, y[n:n + 1], seed=11, series_offset=n, flags=_lib.OPT_NO_SAMPLER16)
+        assert eng.last_variant == "generic"
+        np.testing.assert_allclose(a["theta"][n].cpu().numpy(), g["theta"][0].cpu().numpy(), rtol=1e-7, atol=1e-7)
+        st = oracle.gibbs_stats(_om(mat), y[n].cpu().numpy(), a["theta"][n].cpu().numpy())
+        got = a["stats"][n].cpu().numpy()
+        np.testing.assert_allclose(got[0], st["ssy"][0], rtol=1e-9)
+        np.testing.assert_allclose(got[2:15], st["ss"], rtol=1e-9)
+        assert got[1] == st["n"][0] and got[-1] == 1000
+
+
 def test_c1_shape_at_scale_lane_kernels(eng):
     """BASELINE configs[0]'s model (first-order DLM, T = 1000) over 200 000 series, and a linear-growth model over 100 000
     with an irregular grid: one lane per series (dlm_lane.hip) through the same properties."""
