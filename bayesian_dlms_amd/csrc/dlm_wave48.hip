@@ -2282,9 +2282,15 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
 bool wave48_small_shape(const KArgs& a) {
   return a.d >= 1 && a.d <= 15 && a.p >= 2 && a.p <= 32 && ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);
 }
+// A time-invariant model on a regular grid takes the per-wave kernels at every batch size: their steady-state steps (a few
+// microseconds once the covariance recursion has settled: C4 at 250 series 6.8 ms) beat the workgroup kernels' 10.8 us per step
+// (24.4 ms) by more than the latter win when nothing settles (58.5 against 63.6 ms with 5 % of the components missing).
+static bool steady_capable(const KArgs& a) {
+  return !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !(a.flags & DLM_OPT_NO_STEADY);
+}
 static bool wave48_wanted(const KArgs& a) {
   if (a.flags & DLM_OPT_NO_WAVE) return false;
-  return wave48_small_shape(a) || a.N > 256 || (a.flags & DLM_OPT_FORCE_WAVE);
+  return wave48_small_shape(a) || a.N > 256 || (a.flags & DLM_OPT_FORCE_WAVE) || steady_capable(a);
 }
 static bool shape_ok(const KArgs& a) { return tiled_supported(a) || wave48_small_shape(a); }
 bool wave48_small_ok(const KArgs& a) { return wave48_small_shape(a) && a.spb && !(a.flags & DLM_OPT_NO_WAVE); }

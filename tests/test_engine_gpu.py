@@ -18,9 +18,10 @@ VARIANTS = [0, _lib.OPT_FORCE_GENERIC]
 
 
 class _Eng:
-    """The engine under one of the two dispatch rules for 16 <= d <= 48: "production" (wave-per-series kernels above 256
-    series, workgroup-per-series kernels below) or "per-wave" (DLM_OPT_FORCE_WAVE on every call, so that the handful of
-    series of a parity case runs the kernels a production batch runs).  Every test of this module runs under both."""
+    """The engine on one of its two kernel families for 16 <= d <= 48: "workgroup" (DLM_OPT_NO_WAVE: the workgroup-per-series
+    kernels, which production takes for up to 256 series of a model that is not time-invariant) or "per-wave"
+    (DLM_OPT_FORCE_WAVE: the wave-per-series kernels, which production takes otherwise).  Every test of this module runs under
+    both; test_dispatch_rule_of_the_multivariate_kernels checks which one production picks."""
 
     def __init__(self, engine, rule):
         self._e, self.rule, self._d = engine, rule, 0
@@ -34,18 +35,20 @@ class _Eng:
             self._d = mat.d
             if self.rule == "per-wave":
                 kw["flags"] = kw.get("flags", 0) | _lib.OPT_FORCE_WAVE
+            elif mat.d >= 16 and not (kw.get("flags", 0) & _lib.OPT_FORCE_WAVE):
+                kw["flags"] = kw.get("flags", 0) | _lib.OPT_NO_WAVE
             return attr(mat, *a, **kw)
         return call
 
     def expect(self, variant):
         """Name of the variant the last call must have used, given the rule: a wave-* kernel of the d >= 16 range is
         its workgroup counterpart for the small batches of these tests under the production rule."""
-        if self.rule == "production" and self._d >= 16:
+        if self.rule == "workgroup" and self._d >= 16:
             return "generic" if variant == "wave-sampler" else variant.replace("wave-", "tiled-")   # (no workgroup form of the sampler)
         return variant
 
 
-@pytest.fixture(scope="module", params=["production", "per-wave"])
+@pytest.fixture(scope="module", params=["workgroup", "per-wave"])
 def eng(request):
     from bayesian_dlms_amd.engine import Engine
     e = Engine(0)
@@ -2017,3 +2020,29 @@ def test_structure_analysis_cache_follows_the_model(eng):
         out = eng.filter_smooth(mat, p, yh)
         ref = fresh(mat, p)
         np.testing.assert_array_equal(out["filt"], ref["filt"])
+
+
+def test_dispatch_rule_of_the_multivariate_kernels():
+    """16 <= d <= 48 with a structured G: more than 256 series, or a time-invariant model on a regular grid at any batch size (its
+    steady-state steps), take the wave-per-series kernels; a handful of series on an irregular grid the workgroup-per-series ones."""
+    from bayesian_dlms_amd.engine import Engine
+    e = Engine(0)
+    rng = np.random.default_rng(71)
+    mod = Dlm.polynomial(2)
+    for _ in range(9):
+        mod = mod * Dlm.polynomial(2)              # d = 20, p = 10
+    A = rng.standard_normal((20, 20))
+    p = DlmParameters(np.eye(10), A @ A.T / 20 + 0.1 * np.eye(20), np.zeros(20), np.eye(20))
+    T = 40
+    reg = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    irr = materialise(mod, np.cumsum(rng.integers(1, 3, T)).astype(np.float64))
+    y = rng.standard_normal((4, T, 10)).cumsum(axis=1)
+    e.filter_smooth(reg, p, y)
+    assert e.last_variant == "wave-mfma"
+    e.filter_smooth(reg, p, y, flags=_lib.OPT_NO_STEADY)
+    assert e.last_variant == "tiled-mfma"
+    e.filter_smooth(irr, p, y)
+    assert e.last_variant == "tiled-mfma"
+    e.filter_smooth(irr, p, rng.standard_normal((300, T, 10)).cumsum(axis=1))
+    assert e.last_variant == "wave-mfma"
+    e.close()
