@@ -429,7 +429,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
   // and the test starts over.  The backward pass learns from the sign of the side record's 1/Q that C_t is C_{t-1}.
   const bool may_settle = !IRR && !(a.flags & DLM_OPT_NO_STEADY);   // (the simulation smoother's pass too: y* has the covariance recursion of y)
   bool steady = false;
-  double Kst = 0.0, rq_st = 0.0, Q_st = 0.0;
+  double Kst = 0.0, rq_st = 0.0, Q_st = 0.0, lq_st = 0.0;
   double ychunk = 0.0;
   for (int t = 0; t < T; ++t) {
     if ((t & 63) == 0) {
@@ -502,7 +502,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const double mr = vRF[4 * r + g]; cc[r] = col15 ? mr : cc[r]; }
       cc[3] = (g == 3 && !col15) ? mn : cc[3];
-      if (LL) ll -= 0.5 * (1.8378770664093453 + log(Q_st) + e * erq);
+      if (LL) ll -= 0.5 * (lq_st + e * erq);                                 // log(2 pi) + log Q of the settled forecast variance: computed once
       side_store(rside, offS, (t + 1) * 16, erq, -rq_st);                  // 1/Q negated: "C_t is C_{t-1}" for the backward pass
       if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q_st; }
       const int so = (t + 1) * recb;
@@ -583,7 +583,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
         bool moved = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) moved |= vc && !(r == 3 && g == 3) && !(fabs(cc[r] - old[r]) <= tol);
-        if (__ballot(moved) == 0ull) { steady = true; Kst = Kc; rq_st = rq; Q_st = Q; }
+        if (__ballot(moved) == 0ull) { steady = true; Kst = Kc; rq_st = rq; Q_st = Q; if (LL) lq_st = 1.8378770664093453 + log(Q); }
       }
       if (LL) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * erq);   // -log N(y; f, Q); log(2 pi) = 1.83787...
       side_store(rside, offS, (t + 1) * 16, erq, rq);
