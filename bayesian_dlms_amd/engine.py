@@ -207,6 +207,9 @@ class Engine:
             mkey = (mat.d, mat.p, mat.T, mat.n_g, mat.f_stride, host[:mend].tobytes())
             cache = getattr(self, "_staged", None)
             oflags = flags
+            small = host.size <= (1 << 20)          # per-series or per-step parameter tables are not worth comparing: uploaded as before
+            if not small:
+                cache = None
             if cache is not None and not (flags & _lib.OPT_ASYNC) and cache["dev"] == be.device:
                 if cache["mkey"] == mkey:
                     oflags |= _lib.OPT_MODEL_UNCHANGED
@@ -215,7 +218,7 @@ class Engine:
                 blob = None
             if blob is None:
                 blob = be.torch.as_tensor(host, device=be.device)
-            self._staged = None if (flags & _lib.OPT_ASYNC) else {"host": host, "blob": blob, "mkey": mkey, "dev": be.device}
+            self._staged = None if ((flags & _lib.OPT_ASYNC) or not small) else {"host": host, "blob": blob, "mkey": mkey, "dev": be.device}
             base = blob.data_ptr()
             bufs = {"blob": blob}
             P = lambda name: (base + offs[name]) if name in offs else None
