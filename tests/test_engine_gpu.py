@@ -2046,3 +2046,45 @@ def test_dispatch_rule_of_the_multivariate_kernels():
     e.filter_smooth(irr, p, rng.standard_normal((300, T, 10)).cumsum(axis=1))
     assert e.last_variant == "wave-mfma"
     e.close()
+
+
+@pytest.mark.parametrize("knz", [1, 3, 4])
+def test_steady_state_steps_for_every_sparsity_instantiation(eng, knz):
+    """The structured d <= 15 kernels are instantiated for 1..4 nonzeros per row and column of G (the C2 model has 2): a stable
+    circulant G with `knz` nonzeros per row, d = 8, long enough to settle.  Fast path against DLM_OPT_NO_STEADY and the oracle,
+    with a gap in one series, packed records, and the log-likelihood."""
+    rng = np.random.default_rng(80 + knz)
+    d, T = 8, 500
+    Gm = np.zeros((d, d))
+    coef = {1: [0.9], 3: [0.6, 0.25, -0.2], 4: [0.5, 0.3, -0.2, 0.15]}[knz]
+    for i in range(d):
+        for s_, cf in enumerate(coef):
+            Gm[i, (i + s_) % d] = cf
+    Fv = np.array([1.0, 0.0, 1.0, 0.5, 0.0, 1.0, 0.0, -0.5]).reshape(-1, 1)
+    mod = Dlm(lambda t: Fv, lambda dt: Gm)
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    p = DlmParameters([[0.7]], np.diag(rng.uniform(0.1, 0.5, d)), np.zeros(d), np.eye(d))
+    y = rng.standard_normal((4, T, 1))
+    y[1, 200:203, 0] = np.nan
+    fast = eng.filter_smooth(mat, p, y)
+    assert eng.last_variant == "sparse16" and np.all(fast["status"] == 0)
+    full = eng.filter_smooth(mat, p, y, flags=_lib.OPT_NO_STEADY)
+    np.testing.assert_allclose(fast["filt"], full["filt"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(fast["smooth"], full["smooth"], rtol=1e-10, atol=1e-11)
+    C = fast["filt"][0][:, d:]
+    assert np.array_equal(C[450], C[300])                    # it did settle
+    for n in (0, 1):
+        f, s = oracle_filter_smooth(mat, p, y[n])
+        m, Cc = split(fast["filt"][n], d); sm, S = split(fast["smooth"][n], d)
+        np.testing.assert_allclose(m, f["m"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(Cc, f["C"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(sm, s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(S, s["S"], rtol=1e-8, atol=1e-9)
+    pk = eng.filter_smooth(mat, p, y, flags=_lib.OPT_PACKED_SYM)
+    np.testing.assert_allclose(eng.unpack_records(d, pk["smooth"]), fast["smooth"], rtol=1e-12, atol=1e-13)
+    ll = eng.loglik(mat, p, y)["loglik"]
+    ll0 = eng.loglik(mat, p, y, flags=_lib.OPT_NO_STEADY)["loglik"]
+    np.testing.assert_allclose(ll, ll0, rtol=1e-11)
+    a_ = eng.ffbs(mat, p, y, seed=3, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    b_ = eng.ffbs(mat, p, y, seed=3, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_STEADY)
+    np.testing.assert_allclose(a_["theta"], b_["theta"], rtol=1e-9, atol=1e-10)
