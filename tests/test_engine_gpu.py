@@ -2088,3 +2088,37 @@ def test_steady_state_steps_for_every_sparsity_instantiation(eng, knz):
     a_ = eng.ffbs(mat, p, y, seed=3, flags=_lib.OPT_FFBS_SIMSMOOTH)
     b_ = eng.ffbs(mat, p, y, seed=3, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_STEADY)
     np.testing.assert_allclose(a_["theta"], b_["theta"], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("k", [4, 8, 12, 17, 24])
+def test_steady_state_steps_across_the_per_wave_instantiations(k):
+    """|*| of k linear-growth models: d = 2k, p = k -- one tile per dimension (k = 4, 8), two tiles for d (12), three for d and two
+    for p (17, and 24: d = 48), with Vm^-1 in registers or in LDS as the instantiation has it.  Steady-state steps against
+    DLM_OPT_NO_STEADY and the oracle, on the per-wave kernels, with a partially missing observation in one series."""
+    from bayesian_dlms_amd.engine import Engine
+    e = Engine(0)
+    rng = np.random.default_rng(90 + k)
+    mod = Dlm.polynomial(2)
+    for _ in range(k - 1):
+        mod = mod * Dlm.polynomial(2)
+    T = 140
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    d, q = mat.d, mat.p
+    A = rng.standard_normal((d, d))
+    p = DlmParameters(np.eye(q) * 0.8, A @ A.T / d + 0.2 * np.eye(d), np.zeros(d), np.eye(d))
+    y = rng.standard_normal((3, T, q)).cumsum(axis=1)
+    y[1, 70, q // 2] = np.nan
+    fast = e.filter_smooth(mat, p, y, flags=_lib.OPT_FORCE_WAVE)
+    assert e.last_variant == "wave-mfma" and np.all(fast["status"] == 0)
+    full = e.filter_smooth(mat, p, y, flags=_lib.OPT_FORCE_WAVE | _lib.OPT_NO_STEADY)
+    np.testing.assert_allclose(fast["filt"], full["filt"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(fast["smooth"], full["smooth"], rtol=1e-9, atol=1e-10)
+    C = fast["filt"][0][:, d:]
+    assert np.array_equal(C[130], C[110])                    # settled (and frozen) well before the end
+    f, s = oracle_filter_smooth(mat, p, y[1])
+    m, Cc = split(fast["filt"][1], d); sm, S = split(fast["smooth"][1], d)
+    np.testing.assert_allclose(m, f["m"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(Cc, f["C"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sm, s["s"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(S, s["S"], rtol=1e-7, atol=1e-8)
+    e.close()
