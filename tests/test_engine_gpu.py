@@ -2121,4 +2121,9 @@ def test_steady_state_steps_across_the_per_wave_instantiations(k):
     np.testing.assert_allclose(Cc, f["C"], rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(sm, s["s"], rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(S, s["S"], rtol=1e-7, atol=1e-8)
+    # F treated as dense (DLM_OPT_NO_SPARSE_F): the forward pass keeps its steady steps (products with F on the matrix pipe), the
+    # backward pass has none
+    dn = e.filter_smooth(mat, p, y, flags=_lib.OPT_FORCE_WAVE | _lib.OPT_NO_SPARSE_F)
+    np.testing.assert_allclose(dn["filt"], full["filt"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(dn["smooth"], full["smooth"], rtol=1e-8, atol=1e-9)
     e.close()
