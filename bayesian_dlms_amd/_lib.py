@@ -17,6 +17,9 @@ OPT_ASYNC = 1 << 5
 OPT_FFBS_SIMSMOOTH = 1 << 6
 OPT_PACKED_SYM = 1 << 7
 OPT_MODEL_UNCHANGED = 1 << 8
+OPT_COUNT_STEPS = 1 << 9
+OPT_TRUST_MODEL_UNCHANGED = 1 << 10
+OPT_LOGLIK_LITERAL_Q7 = 1 << 11
 OPT_NO_LANE = 1 << 16
 OPT_NO_SAMPLER16 = 1 << 17
 OPT_NO_WAVE = 1 << 18
@@ -85,6 +88,7 @@ SYMBOLS = [
     ("dlm_smooth_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V]),
     ("dlm_filter_smooth_batch", ctypes.c_int, [_V, _MP, _PP, _V, _OP, _V, _V, _V]),
     ("dlm_last_timing", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_double * 2)]),
+    ("dlm_last_counters", ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_uint64 * 4)]),
     ("dlm_ffbs_batch", ctypes.c_int, [_V, _MP, _PP, _V, _V, _OP, _V, _V, _V, _V, _V]),
     ("dlm_stats_len", ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32]),
     ("dlm_backward_sample_batch", ctypes.c_int, [_V, _MP, _PP, _V, _V, _V, _OP, _V, _V, _V, _V]),

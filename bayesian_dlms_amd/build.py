@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdlm_engine.so")
-SOURCES = ["dlm_engine.hip", "dlm_generic.hip", "dlm_mfma16.hip", "dlm_sparse16.hip", "dlm_sampler16.hip", "dlm_tiled.hip", "dlm_wave48.hip", "dlm_svd.hip", "dlm_ar1.hip", "dlm_lane.hip", "dlm_gibbs.hip"]
+SOURCES = ["dlm_engine.hip", "dlm_generic.hip", "dlm_mfma16.hip", "dlm_sparse16.hip", "dlm_sampler16.hip", "dlm_tiled.hip", "dlm_wave48.hip", "dlm_svd.hip", "dlm_ar1.hip", "dlm_lane.hip", "dlm_gibbs.hip", "dlm_loglik.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS = BASE_FLAGS + ["-mllvm", "-amdgpu-mfma-vgpr-form"]

@@ -54,6 +54,14 @@ struct dlm_engine {
     std::vector<double> g_host, f_host;         // host-mode calls: the tables analysed
   } an;
   bool an_touched = true;
+  // DLM_OPT_COUNT_STEPS: [4] device counters the kernels add to (KArgs::counters), read by dlm_last_counters
+  unsigned long long* counters = nullptr;
+  // DLM_OPT_MODEL_UNCHANGED is verified on the device: model_sum[0] = checksum of (F, G, g_index, dt) at the last fresh
+  // analysis, [1] = scratch; a mismatch raises *model_bad (pinned host memory the kernel writes through model_bad_dev)
+  unsigned long long* model_sum = nullptr;
+  int* model_bad = nullptr;
+  int* model_bad_dev = nullptr;
+  bool model_sum_valid = false;
 };
 
 namespace {
@@ -61,6 +69,13 @@ namespace {
 int fail(dlm_engine* e, int code, const std::string& msg) {
   if (e) e->err = msg;
   return code;
+}
+
+// the device checksum of a DLM_OPT_MODEL_UNCHANGED call did not match the model the engine analysed: its results are invalid
+int promise_broken(dlm_engine* e) {
+  *e->model_bad = 0;
+  e->an.valid = false;
+  return fail(e, DLM_ERR_ARG, "DLM_OPT_MODEL_UNCHANGED was set, but F, G or the time grid differ from the model of the previous call (device checksum): the results of this call are invalid -- drop the flag when the model changes");
 }
 
 #define HIP_TRY(e, expr)                                                                    \
@@ -113,6 +128,7 @@ class Stager {
     } else if (!async) {
       HIP_TRY(e_, hipStreamSynchronize(e_->stream));
     }
+    if ((host_ || !async) && e_->model_bad && *e_->model_bad) return promise_broken(e_);
     return DLM_OK;
   }
 
@@ -141,6 +157,16 @@ int check_common(dlm_engine* e, const dlm_model_desc* m, const dlm_params_desc* 
   if (o->mem != DLM_MEM_DEVICE && o->mem != DLM_MEM_HOST) return fail(e, DLM_ERR_ARG, "opts->mem");
   if (m->d > 64 || m->p > 64) return fail(e, DLM_ERR_UNSUPPORTED, "d and p are limited to 64 in this build");
   HIP_TRY(e, hipSetDevice(e->device));
+  return DLM_OK;
+}
+
+// DLM_OPT_COUNT_STEPS: the kernels of this call count their short steps into the engine's counters
+int want_counters(dlm_engine* e, KArgs& k) {
+  k.counters = nullptr;
+  if (!(k.flags & DLM_OPT_COUNT_STEPS)) return DLM_OK;
+  if (!e->counters) HIP_TRY(e, hipMalloc((void**)&e->counters, 4 * sizeof(unsigned long long)));
+  HIP_TRY(e, hipMemsetAsync(e->counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  k.counters = e->counters;
   return DLM_OK;
 }
 
@@ -217,10 +243,52 @@ int analyse_g_tiled(dlm_engine* e, KArgs& k, const double* G_user, bool host_mod
 
 int analyse_g_fresh(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode);
 
+// 64-bit checksum of the model tables (F, G, g_index, dt) of a device-memory call: one 256-thread block, every 64-bit word
+// mixed with its position (splitmix64 finaliser) and summed.  store != 0: remember it (fresh analysis); store == 0: compare with
+// the remembered one and raise *bad (pinned host memory) on a mismatch -- the check behind DLM_OPT_MODEL_UNCHANGED.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x;
+}
+__global__ __launch_bounds__(256) void k_model_checksum(const double* F, long long nF, const double* G, long long nG, const int* gi,
+                                                        const double* dt, long long T, unsigned long long* sums, int store, int* bad) {
+  __shared__ unsigned long long part[256];
+  unsigned long long acc = 0;
+  const unsigned long long* f = (const unsigned long long*)F;
+  const unsigned long long* g = (const unsigned long long*)G;
+  const unsigned long long* q = (const unsigned long long*)dt;
+  for (long long i = threadIdx.x; i < nF; i += 256) acc += mix64(f[i] + 0x9e3779b97f4a7c15ull * (unsigned long long)(i + 1));
+  for (long long i = threadIdx.x; i < nG; i += 256) acc += mix64(g[i] + 0xc2b2ae3d27d4eb4full * (unsigned long long)(i + 1));
+  if (gi) for (long long i = threadIdx.x; i < T; i += 256) acc += mix64((unsigned long long)(unsigned)gi[i] + 0x165667b19e3779f9ull * (unsigned long long)(i + 1));
+  if (dt) for (long long i = threadIdx.x; i < T; i += 256) acc += mix64(q[i] + 0x27d4eb2f165667c5ull * (unsigned long long)(i + 1));
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const unsigned long long v = part[0] + mix64((unsigned long long)nF) + mix64((unsigned long long)nG * 3 + (gi ? 1 : 0) + (dt ? 2 : 0)) + mix64((unsigned long long)T * 7);
+    if (store) sums[0] = v;
+    else if (sums[0] != v) { __threadfence_system(); *bad = 1; }
+  }
+}
+int model_checksum(dlm_engine* e, const KArgs& k, bool store) {
+  if (!e->model_sum) {
+    HIP_TRY(e, hipMalloc((void**)&e->model_sum, 2 * sizeof(unsigned long long)));
+    HIP_TRY(e, hipHostMalloc((void**)&e->model_bad, sizeof(int), hipHostMallocMapped));
+    *e->model_bad = 0;
+    HIP_TRY(e, hipHostGetDevicePointer((void**)&e->model_bad_dev, e->model_bad, 0));
+  }
+  const long long nF = (long long)(k.f_stride ? k.T : 1) * k.d * k.p, nG = (long long)k.n_g * k.d * k.d;
+  hipLaunchKernelGGL(k_model_checksum, dim3(1), dim3(256), 0, e->stream, k.F, nF, k.G, nG, k.g_index, k.dt, (long long)k.T,
+                     e->model_sum, store ? 1 : 0, e->model_bad_dev);
+  HIP_TRY(e, hipGetLastError());
+  return DLM_OK;
+}
+
 // analyse_g with the cache of the last call's result in front of it
 int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   dlm_engine::Analysis& an = e->an;
   e->an_touched = true;
+  { const int rcc = want_counters(e, k); if (rcc) return rcc; }   // (every kernel-launching entry point of the filter family passes through here)
   const int branch = tiled_analysis_wanted(k) ? 2 : (fast_shape_ok(k) ? 1 : 0);
   const unsigned generic = k.flags & DLM_OPT_FORCE_GENERIC;
   bool same = an.valid && an.d == k.d && an.p == k.p && an.n_g == k.n_g && an.branch == branch && an.f_stride == k.f_stride &&
@@ -229,7 +297,11 @@ int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   if (same && host_mode) {   // host pointers: compare the tables themselves (the caller's F is staged by now: compare the user's copy of G and our copy of F's source)
     same = an.g_host.size() == gn && memcmp(an.g_host.data(), G_user, gn * sizeof(double)) == 0;
     if (same && branch == 2 && !k.f_stride) same = false;   // (F of a host-mode call is only known staged: analysed afresh, it is one small copy)
-  } else if (same) same = (k.flags & DLM_OPT_MODEL_UNCHANGED) != 0;
+  } else if (same) {
+    same = (k.flags & DLM_OPT_MODEL_UNCHANGED) != 0 && e->model_sum_valid;
+    // the promise is verified on the device (no host round trip: a mismatch surfaces when the call synchronises)
+    if (same && !(k.flags & DLM_OPT_TRUST_MODEL_UNCHANGED)) { const int rc = model_checksum(e, k, false); if (rc) return rc; }
+  }
   if (same) {
     e->sparse_k = an.sparse_k;
     k.spb = an.have_spb ? e->spb_dev : nullptr;
@@ -246,6 +318,8 @@ int analyse_g(dlm_engine* e, KArgs& k, const double* G_user, bool host_mode) {
   an.g_host.clear();
   if (host_mode) an.g_host.assign(G_user, G_user + gn);
   (void)fn;
+  e->model_sum_valid = false;
+  if (!host_mode) { const int rc2 = model_checksum(e, k, true); if (rc2) return rc2; e->model_sum_valid = true; }   // what a later DLM_OPT_MODEL_UNCHANGED call is checked against
   return DLM_OK;
 }
 
@@ -442,6 +516,9 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->fws) (void)hipFree(e->fws);
   if (e->spb_dev) (void)hipFree(e->spb_dev);
   if (e->spf_dev) (void)hipFree(e->spf_dev);
+  if (e->counters) (void)hipFree(e->counters);
+  if (e->model_sum) (void)hipFree(e->model_sum);
+  if (e->model_bad) (void)hipHostFree(e->model_bad);
   for (void* b : e->buffers) (void)hipFree(b);
   if (e->order_ev) (void)hipEventDestroy(e->order_ev);
   for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -468,6 +545,19 @@ int dlm_engine_set_stream(dlm_engine* e, void* hip_stream) {
 int dlm_engine_sync(dlm_engine* e) {
   if (!e) return DLM_ERR_ARG;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->model_bad && *e->model_bad) return promise_broken(e);   // a DLM_OPT_ASYNC call whose DLM_OPT_MODEL_UNCHANGED did not hold
+  return DLM_OK;
+}
+
+int dlm_last_counters(dlm_engine* e, uint64_t out[4]) {
+  if (!e || !out) return DLM_ERR_ARG;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!e->counters) return fail(e, DLM_ERR_ARG, "no call with DLM_OPT_COUNT_STEPS has been made");
+  HIP_TRY(e, hipSetDevice(e->device));
+  unsigned long long h[4];
+  HIP_TRY(e, hipMemcpyAsync(h, e->counters, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  for (int i = 0; i < 4; ++i) out[i] = h[i];
   return DLM_OK;
 }
 
@@ -719,6 +809,20 @@ int dlm_loglik_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
+  if (opts->flags & DLM_OPT_LOGLIK_LITERAL_Q7) {
+    // KalmanFilter.likelihood as written (KalmanFilter.scala:299-306): filter into a workspace, then the transition density of
+    // the filtered means (dlm_loglik.hip)
+    if (params->w_tstride) return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_LOGLIK_LITERAL_Q7 takes a time-invariant W (KalmanFilter.likelihood is given p.w)");
+    const size_t d = model->d, rec = d + d * d;
+    const size_t recs = N * (T + 1) * rec * sizeof(double), wsb = dlm::loglik_q7_ws_bytes(k);
+    if ((rc = ensure_fws(e, recs + wsb))) return rc;
+    double* ll_out = k.loglik;
+    k.filt = e->fws; k.loglik = nullptr;
+    if ((rc = run_filter(e, k, false))) return rc;
+    k.loglik = ll_out;
+    HIP_TRY(e, dlm::launch_loglik_q7(k, e->fws, (char*)e->fws + recs, e->stream));
+    return st.finish(opts->flags & DLM_OPT_ASYNC);
+  }
   if ((rc = run_filter(e, k, false))) return rc;   // k.filt == nullptr: the forward kernels store nothing
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
@@ -900,6 +1004,7 @@ int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   e->variant = "svd-jacobi";
+  if ((rc = want_counters(e, k))) return rc;
   if ((rc = mark(e, 0))) return rc;
   HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
   if ((rc = mark(e, 1)) || (rc = mark(e, 2))) return rc;
@@ -925,6 +1030,7 @@ int dlm_svd_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_par
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
   e->variant = "svd-jacobi";
+  if ((rc = want_counters(e, k))) return rc;
   if ((rc = mark(e, 0))) return rc;
   HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
   if ((rc = mark(e, 1))) return rc;

@@ -35,6 +35,8 @@ struct KArgs {
   int spf_k;           // largest nonzero count per column / row of F (1..4)
   unsigned flags;
   unsigned long long seed, series_offset;
+  unsigned long long* counters;   // engine-owned [4], zeroed per call (nullable): steady (short) steps taken by the forward [0] / backward [1] kernel,
+                                  // series served by the shared-covariance kernels [2], series sent to their own full recursion [3]
 };
 
 // Packed record of the structured fast path's internal workspaces: [m (d) | lower triangle of C by rows], padded to a
@@ -129,6 +131,61 @@ hipError_t launch_ar1_ffbs(int N, int T, const double* times, const double* y, c
 hipError_t launch_dinvgamma_step(int d, int p, int N, const double* stats, double av, double bv, double aw, double bw,
                                  unsigned long long seed, unsigned long long series_offset, unsigned long long iteration,
                                  double* Vout, double* Wout, hipStream_t s);
+
+// ---- KalmanFilter.likelihood literally (transition density of the filtered means), dlm_loglik.hip ------
+size_t loglik_q7_ws_bytes(const KArgs& a);
+hipError_t launch_loglik_q7(const KArgs& a, const double* records, void* ws, hipStream_t s);   // a.loglik [N] <- records [N][T+1][d+dd]
+
+// ---- when may a converged covariance recursion stop being recomputed? -------------------------------------------------
+// The reference recomputes C_t, R_t, K_t, Q_t (KalmanFilter.scala:64-107) and the smoother's matrices (Smoothing.scala:31-47)
+// at every step.  The kernels may stop once the recursion has converged -- but a small ONE-STEP change says little about the
+// distance to the limit when the recursion contracts slowly (small W / V): what remains is the geometric tail
+// delta * rho / (1 - rho).  settle_test bounds that tail.  `delta` is the largest change of an entry over one step and
+// `scale` the largest entry of the matrix (both wave-uniform); tests come every `period` steps on an uninterrupted regular
+// stretch (settle_reset otherwise).  With r = delta_k / delta_{k-1} (= rho^period) and 1 / (1 - rho) <= period / (1 - r):
+//     settled  <=>  period * delta_k / (1 - r)  <=  DLM_SETTLE_TOL * scale,
+// where r is the LARGER of the last two estimates, each taken from two consecutive tests whose changes stand clear of the
+// rounding noise of the recursion's own arithmetic (`noise`, relative to scale: 32 eps for the covariance recursions; a
+// change below it counts as that level and gives no new estimate).  At least three tests, r < 1.  A recursion too slow to
+// be resolved above the noise floor (rho > ~0.993 per step at period 4) never settles: it is recomputed at every step like
+// the reference's.  What the rule assumes: from the test on, successive changes shrink at least as fast as the larger of
+// the two measured ratios (the convergence is geometric by then).  NumPy replay against the every-step recursion:
+// tools/settle_replay.py (the frozen matrix stays within DLM_SETTLE_TOL * max|C| for W scaled by 1 .. 1e-6 and V = 1e4 at
+// T up to 40 000; the round-2 rule -- one step's change <= 1e-13 Q -- was off by up to 6e-9 there); GPU tests of every
+// kernel that freezes, in the slow regime: tests/test_settle_gpu.py.
+constexpr double DLM_SETTLE_TOL = 1e-12;
+// The state of the test -- the relative change at the previous test (< 0: none) and the last two estimates of rho^period
+// (2: none yet) -- lives in three floats of the wave's LDS (`st`): kept in registers it cost the d <= 15 backward kernel its
+// fifth wave per SIMD.  Every lane reads and writes the same values (the maxima are wave-uniform): no lane masking, and the
+// LDS queue of a wave is in order.
+constexpr int SETTLE_FLOATS = 4;
+__device__ __forceinline__ float settle_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ void settle_reset(float* st) { st[0] = -1.f; st[1] = 2.f; st[2] = 2.f; }
+// (single precision throughout -- the callers bring their maxima into float range with a power-of-two factor --: a double
+// division at the point where a kernel holds the most live values costs it a dozen registers)
+__device__ __forceinline__ bool settle_test(float* st, float delta, float scale, int period, float noise = 7.1e-15f) {
+  const float x = delta * __builtin_amdgcn_rcpf(scale);
+  float prev = st[0], rate = st[1], rate_prev = st[2];
+  bool ok = false;
+  if (!(x >= 0.f) || !(x < 1e30f)) { prev = -1.f; rate = 2.f; rate_prev = 2.f; }   // NaN / Inf / empty matrix: start over
+  else {
+    const float xe = fmaxf(x, noise);
+    if (prev > 8.f * noise && x >= noise) { rate_prev = rate; rate = xe * __builtin_amdgcn_rcpf(prev); }   // a clean pair
+    const float r = fmaxf(rate, rate_prev);
+    ok = r < 1.f && (float)period * xe <= (float)DLM_SETTLE_TOL * (1.f - r);
+    ok |= (x == 0.f && prev == 0.f);                             // a fixed point reached bit for bit
+    prev = x > 0.f ? xe : 0.f;
+  }
+  st[0] = prev; st[1] = rate; st[2] = rate_prev;
+  return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+}
+// NaN-proof |a - b| for the maxima that feed settle_test (fmax drops a NaN operand)
+__device__ __forceinline__ double settle_absdiff(double a, double b) { const double v = fabs(a - b); return v == v ? v : __builtin_inf(); }
+// 2^-k for x = f * 2^k (f in [1, 2)), x a positive normal wave-uniform double: brings matrices of x's order of magnitude into float range
+__device__ __forceinline__ double settle_pow2_inverse_of(double x) {
+  const int e = (__builtin_amdgcn_readfirstlane(__double2hiint(x)) >> 20) & 0x7ff;
+  return (e > 0 && e < 0x7fe) ? __hiloint2double((2046 - e) << 20, 0) : __builtin_nan("");   // NaN: the test starts over
+}
 
 // ---- counter-based normals (same stream as oracle_normal in oracle/dlm_oracle.c) ------
 __device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {

@@ -175,9 +175,6 @@ __device__ __forceinline__ double chol_draw(const double (&row)[15], int d, int 
 
 // Tab: SparseT (the d <= 15, p = 1 tables) or SparseBig (the tables of the multivariate paths); any p <= 64 -- the
 // observations only enter the statistics.
-#ifndef SAMPLER_SETTLE_TOL
-#define SAMPLER_SETTLE_TOL 1e-11
-#endif
 template <int K, class Tab>
 __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __restrict__ sp) {   // two waves per SIMD: the step is a long dependent chain
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16 + 64];
@@ -327,7 +324,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     if (have && gi == gprev && dt == dtprev && !a.w_tstride) {
       bool moved = false;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) moved |= !(fabs(C[r] - Cp[r]) <= SAMPLER_SETTLE_TOL * cmaxp);   // relative to the largest entry of C (the draws are held to 1e-7: J, H and the factor of a covariance within 1e-11 serve)
+      for (int r = 0; r < 4; ++r) moved |= !(fabs(C[r] - Cp[r]) <= DLM_SETTLE_TOL * cmaxp);   // THIS step's record against the covariance J, H and the factor were computed from: a bound on the distance itself (no drift can build up), relative to the largest entry of C
       reuse = __ballot(moved) == 0ull;
     }
     d4 JT, H;
@@ -575,7 +572,7 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
     if (have && gi == gprev && dt == dtprev && !a.w_tstride) {
       bool moved = false;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) moved |= !(fabs(C[r] - Cp[r]) <= 1e-13 * cmaxp);
+      for (int r = 0; r < 4; ++r) moved |= !(fabs(C[r] - Cp[r]) <= DLM_SETTLE_TOL * cmaxp);   // this step's record against the covariance of the last full step: a bound on the distance itself
       reuse = __ballot(moved) == 0ull;
     }
     d4 JT, J, R;

@@ -26,7 +26,7 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 constexpr int LD = 17;                        // leading dimension of an LDS image
 constexpr int IMG = 16 * LD;                  // doubles per image
-constexpr int WAVE_LDS = 2 * IMG + 8 * 16;    // two images + eight 16-vectors per wave
+constexpr int WAVE_LDS = 2 * IMG + 8 * 16 + 2;    // two images + eight 16-vectors + the state of the steady-state test per wave
 
 #ifndef DLM_SM_WAVES
 #define DLM_SM_WAVES 4
@@ -34,6 +34,10 @@ constexpr int WAVE_LDS = 2 * IMG + 8 * 16;    // two images + eight 16-vectors p
 #ifndef DLM_FI_WAVES
 #define DLM_FI_WAVES 5
 #endif
+#ifndef DLM_SM_WAVES_K2
+#define DLM_SM_WAVES_K2 5
+#endif
+constexpr int SM_WAVES_K2 = DLM_SM_WAVES_K2;   // backward kernel, at most two nonzeros per row / column of G (C2): five waves fit with one value spilled into the every-8th-step branch
 constexpr int SM_WAVES = DLM_SM_WAVES, FI_WAVES = DLM_FI_WAVES;     // waves per SIMD the register allocator must at least allow (backward / forward kernels)
 
 // One dependent chain of four: two chains of two were measured slower (profiles/r01_pmc_notes.md).
@@ -78,6 +82,32 @@ __device__ __forceinline__ double sum_g(double v) {
   return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
 }
 
+// max over the 64 lanes; every lane gets it (the steady-state tests: every fourth step at most)
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, row_ror<8>(v)); v = fmax(v, row_ror<4>(v)); v = fmax(v, row_ror<2>(v)); v = fmax(v, row_ror<1>(v));
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = fmax(__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1]));
+  lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+  l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return fmax(__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1]));
+}
+
+// two float maxima at the price of one 64-bit reduction: a rides in the low, b in the high word through the same shuffles
+__device__ __forceinline__ void wave_max2f(float& a, float& b) {
+#define DLM_MAX2F_ROW(N) { a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x120 + N, 0xf, 0xf, true))); \
+                           b = fmaxf(b, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x120 + N, 0xf, 0xf, true))); }
+  DLM_MAX2F_ROW(8) DLM_MAX2F_ROW(4) DLM_MAX2F_ROW(2) DLM_MAX2F_ROW(1)
+#undef DLM_MAX2F_ROW
+  u2 l = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(a), (unsigned)__float_as_int(a), false, false);
+  u2 h = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(b), (unsigned)__float_as_int(b), false, false);
+  a = fmaxf(__int_as_float((int)l[0]), __int_as_float((int)l[1])); b = fmaxf(__int_as_float((int)h[0]), __int_as_float((int)h[1]));
+  l = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(a), (unsigned)__float_as_int(a), false, false);
+  h = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(b), (unsigned)__float_as_int(b), false, false);
+  a = fmaxf(__int_as_float((int)l[0]), __int_as_float((int)l[1])); b = fmaxf(__int_as_float((int)h[0]), __int_as_float((int)h[1]));
+}
 // 1/x from v_rcp_f64 and two Newton steps (about 1 ulp): 5 VALU instructions instead of the 11 of the IEEE
 // division expansion.  The forward pass is bound by VALU issue, and every lane computes this scalar.
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -422,13 +452,17 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
   }
 
   // Steady state (regular grid, time-invariant model: the !IRR instantiation).  The covariance recursion of a
-  // time-invariant filter converges: once an update leaves C where it was (largest change <= 1e-13 Q, checked every fourth
-  // step), C_t, R_t, K_t and Q_t are those of the step before and only the mean moves -- a = G m, e = y - F.a,
+  // time-invariant filter converges: once C is within DLM_SETTLE_TOL max|C| of its limit (settle_test, dlm_internal.h: the
+  // geometric tail of the one-step changes, tested every fourth step -- NOT a one-step change alone, which says nothing when
+  // the recursion contracts slowly), C_t, R_t, K_t and Q_t are those of the step before and only the mean moves -- a = G m, e = y - F.a,
   // m = a + K e: a gather on one 16-vector instead of the congruence, the products with F and the rank-one update.  The
   // record (the same C, the new m) is stored as always.  A missing observation takes the full step again (C changes),
   // and the test starts over.  The backward pass learns from the sign of the side record's 1/Q that C_t is C_{t-1}.
   const bool may_settle = !IRR && !(a.flags & DLM_OPT_NO_STEADY);   // (the simulation smoother's pass too: y* has the covariance recursion of y)
   bool steady = false;
+  float* settle = (float*)(imgA + 2 * IMG + 8 * 16);   // state of the steady-state test (dlm_internal.h)
+  settle_reset(settle);
+  unsigned nsteady = 0;   // steady steps taken (KArgs::counters[0])
   double Kst = 0.0, rq_st = 0.0, Q_st = 0.0, lq_st = 0.0;
   double ychunk = 0.0;
   for (int t = 0; t < T; ++t) {
@@ -463,9 +497,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
     }
 
     if (may_settle && steady && yt == yt) {
-#ifdef DLM_STAMP
-      st += 1 << 8;      // diagnostic build: steady steps of the forward pass in status bits 8..19
-#endif
+      ++nsteady;
       // the mean rides in row 15 of the tile (lanes g == 3 of register 3) and in column 15
       if (g == 3) vRF[c] = cc[3];
       if (SIM) {   // x+ and the normals of the next four records, as in the full step
@@ -578,18 +610,21 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
 #pragma unroll
       for (int r = 0; r < 3; ++r) cc[r] = fma(rfr[r], ngam, R[r]);
       cc[3] = (g == 3) ? fma(Kc, e, R[3]) : fma(rfr[3], ngam, R[3]);
-      if (check) {   // has the covariance stopped moving?  (column 15 and row 15 carry the mean: not compared)
-        const double tol = 1e-13 * Q;
-        bool moved = false;
+      if (check) {   // has the covariance reached its limit?  (column 15 and row 15 carry the mean: not compared)
+        const double sc = settle_pow2_inverse_of(Q);        // single precision after scaling by a power of two near 1 / Q (C is of the order of Q at most)
+        float dl = 0.f, mx = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) moved |= vc && !(r == 3 && g == 3) && !(fabs(cc[r] - old[r]) <= tol);
-        if (__ballot(moved) == 0ull) { steady = true; Kst = Kc; rq_st = rq; Q_st = Q; if (LL) lq_st = 1.8378770664093453 + log(Q); }
+        for (int r = 0; r < 4; ++r)
+          if (vc && !(r == 3 && g == 3)) { dl = fmaxf(dl, (float)(settle_absdiff(cc[r], old[r]) * sc)); mx = fmaxf(mx, (float)(fabs(cc[r]) * sc)); }
+        wave_max2f(dl, mx);
+        if (settle_test(settle, dl, mx, 4)) { steady = true; Kst = Kc; rq_st = rq; Q_st = Q; if (LL) lq_st = 1.8378770664093453 + log(Q); }
       }
       if (LL) ll -= 0.5 * (1.8378770664093453 + log(Q) + e * erq);   // -log N(y; f, Q); log(2 pi) = 1.83787...
       side_store(rside, offS, (t + 1) * 16, erq, rq);
     } else {
       cc = R;
       steady = false;
+      settle_reset(settle);
       side_store(rside, offS, (t + 1) * 16, __builtin_nan(""), __builtin_nan(""));
     }
     if (fq && lane == 0) { fq[2 * (t + 1)] = f; fq[2 * (t + 1) + 1] = Q; }
@@ -599,6 +634,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
     wave_sync();   // the images are rewritten at the top of the next step
   }
   if (LL && a.loglik && lane == 0) a.loglik[n] = ll;
+  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(cc[r]);
@@ -621,7 +657,7 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
 // MFMA's B operand,  [C | m] - C [P C | -q] = [C - C P C | m + C q] = [S | s]:  the smoothed mean needs no
 // extraction from the product, and mean and covariance are read and stored by the same 4 instructions.
 // ---------------------------------------------------------------------------------------
-constexpr int SM_LDS = 2 * IMG + 3 * 16;   // backward pass: two images + three 16-vectors per wave
+constexpr int SM_LDS = 2 * IMG + 3 * 16 + 2;   // backward pass: two images + three 16-vectors + the state of the steady-state test per wave
 template <int K, bool IRR, bool PIPE = false>
 __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __restrict__ sp, const double* __restrict__ side,
                                               double* lds /* 4 SM_LDS doubles */, char* ring_all) {
@@ -682,7 +718,11 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   double qcol = 0.0;
   int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
   const bool may_settle = !(a.flags & DLM_OPT_NO_STEADY);
-  bool psteady = false, same_next = false;
+  bool psteady = false, same_next = false, was_steady = false, chk = false;
+  float chk_dl = 0.f, chk_mx = 0.f;
+  float* settle = (float*)(imgA + 2 * IMG + 3 * 16);   // state of the steady-state test (dlm_internal.h)
+  settle_reset(settle);
+  unsigned nsteady = 0;   // steady steps taken (KArgs::counters[1])
 
   const int slotb = rinb + 16;
   char* ring = ring_all + wave * 2 * slotb;
@@ -756,9 +796,8 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     // symmetric C, one cross-row sum, a transposition through LDS), q_{t-1} = G^T [q_t + F (e_t/Q_t - K.q_t)] -- no MFMA, no
     // rank-two update, no congruence -- and the record store (the covariance registers of the step before, the new mean).
     if (!IRR && psteady && same_next && observed) {
-#ifdef DLM_STAMP
-      st += 1 << 20;   // diagnostic build: steady steps of the backward pass in status bits 20..31
-#endif
+      ++nsteady;
+      was_steady = true;
       { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rinb, lane, mean_only ? n16m : n16); }
       d4 nqr;
       {
@@ -891,12 +930,20 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
         X2_STEP(3)
         Pn = congruence_pass2<K>(yc, imgB, idx, val, g, c, nullptr);
       } else Pn = congruence<K>(M, imgA, imgB, idx, val, g, c, (t & 7) == 0);
-      if (!IRR && may_settle && observed && same_c && (t & 3) == 2) {   // has P stopped moving (and will the next C be this one)?
-        const double tol = 1e-13 * iq;
-        bool moved = false;
+      // has P reached its limit (and will the next C be this one)?  The same geometric-tail test as in the forward pass,
+      // relative to max|P|; any step off the settled, observed stretch starts it over.
+      if (!IRR && may_settle) {
+        if (!(observed && same_c) || was_steady) { settle_reset(settle); was_steady = false; }   // off the settled, observed stretch, or back from steady steps: start over
+        else if ((t & 3) == 2) {
+          // (in single precision after scaling by a power of two near Q -- P is of the order of 1 / Q --: the kernel has no
+          // vector register to spare, and the test only needs the ratio of two maxima to a few digits)
+          const double sc = settle_pow2_inverse_of(iq);
+          float dl = 0.f, mx = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) moved |= !(fabs(Pn[r] - P[r]) <= tol);
-        psteady = __ballot(moved) == 0ull;
+          for (int r = 0; r < 4; ++r) { dl = fmaxf(dl, (float)(settle_absdiff(Pn[r], P[r]) * sc)); mx = fmaxf(mx, (float)(fabs(Pn[r]) * sc)); }
+          wave_max2f(dl, mx);
+          chk_dl = settle_uniform(dl); chk_mx = settle_uniform(mx); chk = true;   // judged at the end of the step, where fewer values are live
+        }
       }
       P = Pn;
       qcol = vR[idx[0]] * val[0];
@@ -914,6 +961,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     // output: [S_t | s_t] = [C_t | m_t] - C_t [P_t C_t | -q_t]
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[r] = cc[r] - x2[r];
+    if (!IRR && chk) { psteady = settle_test(settle, chk_dl, chk_mx, 4); chk = false; }
     if (!IRR && psteady) {                                   // the steady steps may begin: S_t waits for them in the idle image
 #pragma unroll
       for (int r = 0; r < 4; ++r) imgB[(4 * r + g) * LD + c] = out[r];
@@ -931,6 +979,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     for (int k = 0; k < 8; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)(T + 1));
 #endif
   vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
+  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[1], (unsigned long long)nsteady);
   // P and q carry any non-finite value down to record 0: test the last output
   bool bad = false;
 #pragma unroll
@@ -940,7 +989,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
 }
 
 template <int K, bool IRR, bool PIPE = false>
-__global__ __launch_bounds__(256, PIPE ? 2 : SM_WAVES) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
+__global__ __launch_bounds__(256, PIPE ? 2 : (K <= 2 ? SM_WAVES_K2 : SM_WAVES)) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                        const double* __restrict__ side) {
   __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
   extern __shared__ __attribute__((aligned(16))) char ring_all[];

@@ -348,16 +348,13 @@ __device__ __forceinline__ SvdLds carve_filter(double* sm, int d, int p) {
 }
 size_t svd_filter_lds_bytes(int d, int p) {
   const int n = d > p ? d : p;
-  return sizeof(double) * (size_t)(8 * 16 + 3 * n * SL + d * SL + p * SL + n * svd_filter_stl(d, p) + 8 + 16) + 16;
+  return sizeof(double) * (size_t)(8 * 16 + 3 * n * SL + d * SL + p * SL + n * svd_filter_stl(d, p) + 8 + 16 + 2) + 16;   // (+ 2: the state of the steady-state test behind gs)
 }
 size_t svd_sampler_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 16 * SL + 16 * STL + 8) + 16; }
 
 // ---------------------------------------------------------------------------------------
 // SVD filter.  Record t: [m_t (d) | dc_t (d) | uc_t (d x d, column-major)].
 // ---------------------------------------------------------------------------------------
-#ifndef SVD_SETTLE_TOL
-#define SVD_SETTLE_TOL 1e-11
-#endif
 __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restrict__ rec_out) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
@@ -392,13 +389,21 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
   // buffers were used for something else.
   bool warm_r = false, warm_c = false;
   // Steady state.  On a regular stretch without missing observations the Riccati recursion converges: the posterior
-  // factors a measurement update writes equal the ones it overwrites.  `settled` records that for the last update actually
-  // computed (largest change <= SVD_SETTLE_TOL = 1e-11 of the largest entry, for uc and for dc: the factors of a settled stretch are
-  // then within ~1e-10 of the recursion's, three decades inside the 1e-7 to which this path is held); while it holds and the transition is the
-  // same, (ur, dr) ARE the answer, and with the same observation pattern so are (uc, dc): both decompositions are skipped
+  // factors a measurement update writes approach the ones it overwrites.  `settled` records for the last update actually
+  // computed that the factors are within DLM_SETTLE_TOL (relative to their largest entry, for uc and for dc) of their LIMIT:
+  // settle_test (dlm_internal.h) bounds the geometric tail of the step-to-step changes, tested at every computed step -- a
+  // small one-step change alone says nothing when the recursion contracts slowly.  While it holds and the transition is
+  // the same, (ur, dr) ARE the answer, and with the same observation pattern so are (uc, dc): both decompositions are skipped
   // and only the mean moves.  Anything that disturbs the covariance (a missing observation, another dt, a variance
-  // stream) clears it and the full path resumes.
+  // stream) clears it, the test starts over and the full path resumes.
   bool have_r = false, have_c = false, reuse_r = false, settled = false;
+  float* settle = (float*)(L.gs + 16);
+  settle_reset(settle);
+  unsigned nsteady = 0;   // steps that skipped both decompositions (KArgs::counters[0])
+  bool chain = false;     // the last step computed a measurement update (with transition chain_g / chain_dt, pattern chain_mask)
+  int chain_g = -1;
+  double chain_dt = 0.0;
+  unsigned long long chain_mask = 0ull;
   int gprev = -1;
   double dtprev = 0.0;
   unsigned long long mask_prev = 0ull;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
     if (pm == 0) {
       for (int i = lane; i < d; i += 64) { L.m[i] = L.a[i]; L.dc[i] = L.dr[i]; }
       for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = M17(L.ur, k % d, k / d);
-      have_c = false; settled = false;
+      have_c = false; settled = false; chain = false;
     } else {
       // e = y - fm^T a ; tmp(pm x d) = vm fm^T   (vm = sqrtVinv[idx, idx], fm = F[:, idx])
       for (int j = lane; j < pm; j += 64) {
@@ -496,6 +501,7 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
         STK(16 + i, j) = s;                    // vm fm^T, parked in rows 16.. of the stack
       }
       ssync();
+      if (reuse_c) ++nsteady;
       if (!reuse_c) {
       // stack ((pm + d) x d) = [vm fm^T ur ; diag(1/dr)]
       for (int k = lane; k < pm * d; k += 64) {
@@ -533,7 +539,15 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
       }
       for (int i = lane; i < d; i += 64) { const double v = 1.0 / L.sig[i]; mxd = fmax(mxd, fabs(v)); dfd = fmax(dfd, fabs(v - L.dc[i])); L.dc[i] = v; }
       for (int o_ = 32; o_ > 0; o_ >>= 1) { mxu = fmax(mxu, __shfl_xor(mxu, o_)); dfu = fmax(dfu, __shfl_xor(dfu, o_)); mxd = fmax(mxd, __shfl_xor(mxd, o_)); dfd = fmax(dfd, __shfl_xor(dfd, o_)); }
-      settled = dfu <= SVD_SETTLE_TOL * mxu && dfd <= SVD_SETTLE_TOL * mxd;
+      {   // the larger of the two relative changes, in single precision (ratios of maxima)
+        const float xu = (float)dfu * __builtin_amdgcn_rcpf((float)mxu), xd = (float)dfd * __builtin_amdgcn_rcpf((float)mxd);
+        // the update before this one ran one step earlier with the same transition and observation pattern: else start over
+        const int giu = a.g_index ? a.g_index[t] : 0;
+        const bool contiguous = chain && chain_g == giu && chain_dt == dt && chain_mask == mask && dt != 0.0;
+        if (!contiguous) settle_reset(settle);
+        settled = settle_test(settle, fmaxf(xu, xd), 1.f, 1);
+        chain = true; chain_g = giu; chain_dt = dt; chain_mask = mask;
+      }
       have_c = true; mask_prev = mask;
       }
       // tv (pm) = vm^T vm e ; gs (d) = fm tv ; gain e = uc dc^2 uc^T gs
@@ -579,6 +593,7 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
   for (int i = lane; i < d; i += 64) bad |= !isfinite(L.m[i]) || !isfinite(L.dc[i]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
 }
 
 // canonical factor: columns of U (d x d, LDS ld SL) and entries of s reordered so that the

@@ -631,6 +631,10 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
   unsigned char* marks = innov ? (unsigned char*)(innov + (size_t)a.N * T * p) + (size_t)n * (T + 1) : nullptr;
   if (marks && lane == 0) marks[0] = 0;
   bool steady = false;
+  float* settle = (float*)(vec0 + 9 * VL);   // state of the steady-state test (dlm_internal.h: settle_test), in a vector slot this kernel does not use
+  wave_sync();
+  settle_reset(settle);
+  unsigned nsteady = 0;                       // steady steps taken (KArgs::counters[0])
 
   for (int t = 0; t < T; ++t) {
     // opaque copies of the lane coordinates: the compiler would otherwise hoist the few dozen address computations of
@@ -695,6 +699,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
       wave_sync();
       store_record(rfo, mv, t + 1, g, c);
       if (marks && lane == 0) marks[t + 1] = 1;
+      ++nsteady;
       if (++t >= T) break;
       missing_here = false;
 #pragma unroll
@@ -707,6 +712,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
       if (t >= T) break;     // (otherwise: step t, whose observation is in ycur, takes the full path below)
     }
     steady = false;
+    if (!all) settle_reset(settle);             // a missing component disturbs the covariance: the convergence test starts over
     if (marks && lane == 0) marks[t + 1] = 0;
 
     // ---- advance: a = G m, R = G C G^T + W dt (into C's registers), dt == 0: identity
@@ -892,10 +898,11 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * aa + 4 * r + g;
               const double old = bld(rfo, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so);
-              dmax = fmax(dmax, fabs(C[aa][b][r] - old)); cmax = fmax(cmax, fabs(C[aa][b][r]));
+              dmax = fmax(dmax, settle_absdiff(C[aa][b][r], old)); cmax = fmax(cmax, fabs(C[aa][b][r]));
             }
         for (int o_ = 32; o_ > 0; o_ >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o_)); cmax = fmax(cmax, __shfl_xor(cmax, o_)); }
-        if (__builtin_amdgcn_readfirstlane((int)(dmax <= 1e-13 * cmax))) {   // (every lane holds the same maxima: a scalar flag)
+        const double sc = settle_pow2_inverse_of(cmax);
+        if (settle_test(settle, (float)(dmax * sc), (float)(cmax * sc), 4)) {   // the geometric tail of the changes within DLM_SETTLE_TOL max|C| (a scalar flag)
           steady = true;
           wave_sync();
           to_image<IL, PT, DT>(KT, img, g, c);                      // K^T for the steady steps
@@ -907,6 +914,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
     }
   }
   if (a.loglik && lane == 0) a.loglik[n] = ll;
+  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
   bool bad = false;
 #pragma unroll
   for (int aa = 0; aa < DT; ++aa)
@@ -1045,6 +1053,10 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
   double* xv = tv + VL;   double* zv = xv + VL;
   const bool can_steady = KF > 0 && !a.g_index && !a.f_stride && !a.v_tstride && !(a.flags & DLM_OPT_NO_STEADY);
   bool smode = false, psteady = false, inh_next = false;
+  float* settle = (float*)(vec0 + 9 * VL);   // state of the steady-state test (dlm_internal.h: settle_test), in a vector slot this kernel does not use
+  wave_sync();
+  settle_reset(settle);
+  unsigned nsteady = 0;                       // steady steps taken (KArgs::counters[1])
   int mk_cur = can_steady ? marks[T] : 0;
 
   for (int t = T; t >= 0; --t) {
@@ -1140,11 +1152,12 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
 #pragma unroll
       for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) qv[16 * b + c] = qn[b];
       wave_sync();
+      ++nsteady;
       continue;
     }
     }
     smode = false;
-    if (!(inherit && allobs)) psteady = false;
+    if (!(inherit && allobs)) { psteady = false; settle_reset(settle); }
 
     d4 Kg[DT][PT];
     if (any) {
@@ -1393,10 +1406,11 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
             const int i = 16 * aa + 4 * r + g;
             const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rout, (i < d && jd[b]) ? cpart[b] + i * 8 : OOB, so, 1);   // glc
             const double old = __hiloint2double((int)v[1], (int)v[0]);
-            dmax = fmax(dmax, fabs(P[aa][b][r] - old)); pmax = fmax(pmax, fabs(P[aa][b][r]));
+            dmax = fmax(dmax, settle_absdiff(P[aa][b][r], old)); pmax = fmax(pmax, fabs(P[aa][b][r]));
           }
       for (int o_ = 32; o_ > 0; o_ >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o_)); pmax = fmax(pmax, __shfl_xor(pmax, o_)); }
-      psteady = dmax <= 1e-13 * pmax;
+      const double sc = settle_pow2_inverse_of(pmax);
+      psteady = settle_test(settle, (float)(dmax * sc), (float)(pmax * sc), 4);   // the geometric tail of the changes within DLM_SETTLE_TOL max|P|
     }
     if (can_steady && psteady && inherit && allobs && mk) {   // the next step can be a steady one: S_t (stored above) into the image
       wave_sync();
@@ -1425,6 +1439,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
 #pragma unroll
       for (int r = 0; r < 4; ++r) bad |= !isfinite(P[aa][b][r]);
   if (lane < d) bad |= !isfinite(qv[lane]);
+  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[1], (unsigned long long)nsteady);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
@@ -1841,7 +1856,7 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
 // draws it reproduces.  Products are MFMA chains on the tiles (X^T Y, as everywhere in this file), the three products
 // with G gathers through the image, R+^-1 the warm-started Newton-Schulz refinement, the factor of H is taken with lane i
 // holding row i in registers (pivots and multipliers by v_readlane: no LDS round trip on the d dependent pivots).
-// Once the filtered covariance has stopped moving (|C_t - C| <= 1e-13 max|C| against the last step computed in full), J, H
+// Once the filtered covariance has stopped moving (|C_t - C| <= DLM_SETTLE_TOL max|C| against the last step computed in full), J, H
 // and the factor are reused and a step is a gather, two matrix-vector products and the draw.
 // LDS per wave: two images (scratch; the second also keeps the factor L in its lower triangle and the comparison copy of
 // C in its strict upper triangle) and six vectors -- 39 KB at DT = 3: four series per CU.
@@ -2045,7 +2060,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
             const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
             if (i < d && j < d) {
               const double old = (i == j) ? cdv[i] : (i < j ? keep[i * IL + j] : keep[j * IL + i]);
-              moved |= !(fabs(C[aa][b][r] - old) <= 1e-13 * cmaxp);
+              moved |= !(fabs(C[aa][b][r] - old) <= DLM_SETTLE_TOL * cmaxp);   // this step's record against the covariance of the last full step: a bound on the distance itself
             }
           }
       reuse = __ballot(moved) == 0ull;

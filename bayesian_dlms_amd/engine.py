@@ -211,8 +211,8 @@ class Engine:
             if not small:
                 cache = None
             if cache is not None and not (flags & _lib.OPT_ASYNC) and cache["dev"] == be.device:
-                if cache["mkey"] == mkey:
-                    oflags |= _lib.OPT_MODEL_UNCHANGED
+                if cache["mkey"] == mkey:   # compared byte for byte right here: the engine's device checksum of the promise is not needed
+                    oflags |= _lib.OPT_MODEL_UNCHANGED | _lib.OPT_TRUST_MODEL_UNCHANGED
                 blob = cache["blob"] if (cache["host"].size == host.size and np.array_equal(cache["host"], host)) else None
             else:
                 blob = None
@@ -358,6 +358,13 @@ class Engine:
         ms = (ctypes.c_double * 2)()
         self._check(self.lib.dlm_last_timing(self.h, ctypes.byref(ms)))
         return float(ms[0]), float(ms[1])
+
+    def last_counters(self):
+        """(forward steady steps, backward steady steps, series on the shared-covariance path, series on their own
+        recursion) of the last call made with DLM_OPT_COUNT_STEPS."""
+        c = (ctypes.c_uint64 * 4)()
+        self._check(self.lib.dlm_last_counters(self.h, ctypes.byref(c)))
+        return tuple(int(v) for v in c)
 
     def ffbs(self, mat, params, y, *, z=None, seed=0, series_offset=0, flags=0, want_theta=True,
              want_cond=False, want_stats=True, filt=None):

@@ -54,9 +54,19 @@ enum {
   DLM_OPT_FFBS_SIMSMOOTH = 1u << 6,     /* draw with the Durbin-Koopman simulation smoother */
   DLM_OPT_PACKED_SYM = 1u << 7,         /* state records leave PACKED: [mean (d) | lower triangle of the covariance by rows],
                                            dlm_packed_record_doubles(d) doubles per record (see below)              */
+  /* A PROMISE of the caller, not a tuning knob -- results are WRONG if it is broken.  Device-memory calls only: F, G and the
+   * time grid are bit for bit those of this engine's previous model-taking call, so its analysis of their structure is reused
+   * (two stream round trips per call less).  The engine checks what it can without reading device memory (d, p, n_g, f_stride
+   * and the path taken must agree, else it analyses afresh) and, unless DLM_OPT_TRUST_MODEL_UNCHANGED is also set, verifies
+   * the promise with a 64-bit checksum of F, G, g_index and dt computed on the device (one tiny kernel per call; a mismatch
+   * returns DLM_ERR_ARG).  Host-memory calls never need it: the engine compares the tables itself. */
+  DLM_OPT_MODEL_UNCHANGED = 1u << 8,
+  DLM_OPT_COUNT_STEPS = 1u << 9,        /* count the steps that took a short path (dlm_last_counters); costs a 32-byte memset per call */
+  DLM_OPT_TRUST_MODEL_UNCHANGED = 1u << 10, /* with DLM_OPT_MODEL_UNCHANGED: skip the device checksum (callers that stage the tables themselves
+                                         * and compare them on the host, as bayesian_dlms_amd/engine.py does)                     */
+  DLM_OPT_LOGLIK_LITERAL_Q7 = 1u << 11, /* dlm_loglik_batch: KalmanFilter.likelihood as written (KalmanFilter.scala:299-306, what
+                                         * MetropolisHastings.dlm evaluates): the transition density of the filtered means        */
   /* Kernel-selection overrides: measurements and tests only, results do not depend on them.           */
-  DLM_OPT_MODEL_UNCHANGED = 1u << 8,    /* device-memory calls: F, G and the time grid are bit for bit those of this engine's previous call -- its
-                                         * analysis of their structure is reused (a host-memory call compares the tables itself)   */
   DLM_OPT_NO_LANE = 1u << 16,           /* no lane-per-series kernels (d <= 5, p = 1)                                  */
   DLM_OPT_NO_SAMPLER16 = 1u << 17,      /* no register-tile backward sampler: the generic kernel                       */
   DLM_OPT_NO_WAVE = 1u << 18,           /* 16 <= d <= 48: the workgroup-per-series kernels instead of wave-per-series  */
@@ -223,7 +233,16 @@ int dlm_ou_ffbs_batch(dlm_engine* e, int32_t N, int32_t T, const double* times, 
  * i.e. KalmanFilter.conditionalLikelihood (KalmanFilter.scala:138-153) summed over the series (steps with no observed
  * component contribute 0).  It is the filter recursion with one scalar reduction per series and no record output, for
  * the callers that evaluate a bank of parameter sets (MetropolisHastings.scala:126-137, RaoBlackwellFilter.scala:43-57;
- * SURVEY 8f #2): params strides select per-series parameters.  loglik [N]; status [N] as for dlm_filter_batch. */
+ * SURVEY 8f #2): params strides select per-series parameters.  loglik [N]; status [N] as for dlm_filter_batch.
+ *
+ * DLM_OPT_LOGLIK_LITERAL_Q7 selects what the reference's `KalmanFilter.likelihood` (KalmanFilter.scala:299-306) -- the
+ * function MetropolisHastings.dlm calls (MetropolisHastings.scala:134, :205) -- really computes: it filters and then
+ * sums the TRANSITION density of the filtered means (KalmanFilter.logLikelihood, :175-183),
+ *   loglik[n] = sum_{t=1..T} log N(m_t ; g(dt_t) m_{t-1}, W dt_t),     m_0 = the initial state at t0 - 1,
+ * with Breeze's MultivariateGaussian.logPdf (Cholesky of W dt).  Every consecutive pair counts, also across a missing
+ * observation.  W must be positive definite and every dt > 0 (Breeze's cholesky throws otherwise: here loglik[n] = NaN and
+ * DLM_ST_NOT_PD); a W_t stream (w_tstride != 0) is DLM_ERR_UNSUPPORTED (the reference passes the time-invariant p.w).
+ * The call filters into an engine workspace of N (T + 1) (d + d^2) doubles first. */
 int dlm_loglik_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
                      const double* y, const dlm_options* opts, double* loglik, int32_t* status);
 
@@ -241,6 +260,14 @@ int dlm_filter_smooth_batch(dlm_engine *e, const dlm_model_desc *model,
  * dlm_backward_sample_batch, dlm_svd_filter_batch or dlm_svd_ffbs_batch call, from HIP events recorded on the
  * engine's stream around them (a part that did not run reads 0). */
 int dlm_last_timing(dlm_engine *e, double ms[2]);
+
+/* Step counters of the LAST call made with DLM_OPT_COUNT_STEPS (synchronises the engine's stream):
+ *   out[0]  steps of the forward kernel that took its steady-state (mean-only) path, summed over the series
+ *   out[1]  the same for the backward kernel
+ *   out[2]  series served by the shared-covariance kernels
+ *   out[3]  series of the same call that ran their own covariance recursion (a missing observation)
+ * `bench.py` reports out[0..1] / (N T) as `steady_fraction`. */
+int dlm_last_counters(dlm_engine *e, uint64_t out[4]);
 
 /* ---- FFBS + Gibbs sufficient statistics --------------------------------------------
  * Replaces Smoothing.ffbsDlm (Smoothing.scala:173-180) and, when `stats` is given, the

@@ -103,6 +103,16 @@ JNIEXPORT jdoubleArray JNICALL Java_com_github_jonnylaw_dlm_gpu_Native_lastTimin
   if (out) env->SetDoubleArrayRegion(out, 0, 2, ms);
   return out;
 }
+// {forward steady steps, backward steady steps, series on the shared-covariance path, series on their own recursion} of the last
+// call made with DLM_OPT_COUNT_STEPS
+JNIEXPORT jlongArray JNICALL Java_com_github_jonnylaw_dlm_gpu_Native_lastCounters(JNIEnv* env, jobject, jlong h) {
+  uint64_t c[4] = {0, 0, 0, 0};
+  if (throw_if(env, eng(h), dlm_last_counters(eng(h), c))) return nullptr;
+  jlong v[4] = {static_cast<jlong>(c[0]), static_cast<jlong>(c[1]), static_cast<jlong>(c[2]), static_cast<jlong>(c[3])};
+  jlongArray out = env->NewLongArray(4);
+  if (out) env->SetLongArrayRegion(out, 0, 4, v);
+  return out;
+}
 
 // ---- engine-owned device buffers ----------------------------------------------------------------------------------
 // address of a direct java.nio buffer (host mode, and the host side of upload / download)

@@ -43,6 +43,7 @@ final class Native private[gpu] () {
   @native def engineWaitStream(h: Long, stream: Long): Unit
   @native def streamWaitEngine(h: Long, stream: Long): Unit
   @native def lastTiming(h: Long): Array[Double]
+  @native def lastCounters(h: Long): Array[Long]
   @native def address(directBuffer: java.nio.Buffer): Long
   @native def bufferAlloc(h: Long, bytes: Long): Long
   @native def bufferFree(h: Long, dev: Long): Unit
@@ -83,7 +84,10 @@ object Native {
   val StatsOuter = 1 << 4         // GibbsWishart statistics
   val FfbsSimSmooth = 1 << 6      // Durbin-Koopman simulation smoother instead of backward sampling
   val PackedSym = 1 << 7
-  val ModelUnchanged = 1 << 8     // F, G and the time grid are those of this engine's previous call: its structure analysis is reused
+  val ModelUnchanged = 1 << 8     // a PROMISE: F, G and the time grid are those of this engine's previous call (its structure analysis is reused); the engine verifies it with a device checksum and fails the call if it does not hold
+  val CountSteps = 1 << 9         // count the steps that took a short path (Native.lastCounters)
+  val LoglikLiteralQ7 = 1 << 11   // logLikelihood: KalmanFilter.likelihood as written (the transition density of the filtered means, KalmanFilter.scala:299-306)
+  val TrustModelUnchanged = 1 << 10 // with ModelUnchanged: skip the device checksum (only for callers that compared the tables themselves)
   val NoSteady = 1 << 22          // every step recomputes the covariance recursion, also once it has settled (the reference's arithmetic, step for step)
   /** every reference quirk switched on: results are the reference's arithmetic, not the textbook's (SURVEY Q1 / Q2 / Q9) */
   val LiteralReference = SmootherCompatQ1 | SvdRawWQ2 | SvdSamplerQ9

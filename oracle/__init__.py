@@ -121,6 +121,14 @@ def loglik(M, filt, y):
     return float(fn(M.p, M.T, _p(filt["f"]), _p(filt["Q"]), _p(y)))
 
 
+def likelihood_q7(M, filt, W):
+    """KalmanFilter.likelihood (KalmanFilter.scala:299-306): the transition density of the filtered means,
+    sum_t log N(m_t; g(dt_t) m_{t-1}, W dt_t) (KalmanFilter.logLikelihood :175-183) -- what MetropolisHastings.dlm evaluates."""
+    out = ctypes.c_double()
+    lib().oracle_loglik_q7(M.d, M.T, _p(M.G), _pi(M.g_index), _p(M.dt), _p(cm(W)), _p(np.ascontiguousarray(filt["m"])), ctypes.byref(out))
+    return float(out.value)
+
+
 def ar1_filter(y, v, phi, mu, sigma_eta):
     """FilterAr.filterUnivariate: T+1 records of (m, c, a, r)."""
     y = np.ascontiguousarray(y, dtype=np.float64); T = y.size

@@ -484,6 +484,50 @@ double oracle_loglik(int p, int T, const double *f, const double *Q, const doubl
   return ll;
 }
 
+/* KalmanFilter.logLikelihood (KalmanFilter.scala:175-183) as KalmanFilter.likelihood calls it (:299-306) -- the
+ * "likelihood" MetropolisHastings.dlm evaluates (MetropolisHastings.scala:134, :205): over the T+1
+ * filtered means m_0 .. m_T (m_0 = the initial state at t0 - 1, kf.initialiseState),
+ *   sum_{t=1..T} MultivariateGaussian(mod.g(dt_t) * m_{t-1}, w * dt_t).logPdf(m_t).
+ * Breeze's MultivariateGaussian(mean, cov).logPdf(x) = -1/2 |L^-1 (x - mean)|^2 - (n/2 log 2 pi + sum log diag L),
+ * L = cholesky(cov) (lower).  Every consecutive pair counts, also across a missing observation (there m_t = a_t: the
+ * quadratic form is 0).  dt = 0 makes the covariance the zero matrix: Breeze's cholesky throws; here the result is NaN and
+ * the return value 1.  m [T+1][d]; G, g_index, dts as in oracle_kf_filter (mod.g(dt) is the table entry also for dt = 0);
+ * W d x d column-major.  Returns 0, or 1 if some W dt was not positive definite. */
+int oracle_loglik_q7(int d, int T, const double *G, const int *g_index, const double *dts, const double *W,
+                     const double *m, double *out) {
+  double ll = 0.0;
+  int bad = 0;
+  double *cov = (double *)malloc(sizeof(double) * (size_t)d * d);
+  double *L = (double *)malloc(sizeof(double) * (size_t)d * d);
+  double *c = (double *)malloc(sizeof(double) * (size_t)d);
+  double *u = (double *)malloc(sizeof(double) * (size_t)d);
+  for (int t = 0; t < T; ++t) {
+    const double dt = dts ? dts[t] : 1.0;
+    const double *Gt = G + (size_t)(g_index ? g_index[t] : 0) * d * d;
+    const double *x0 = m + (size_t)t * d, *x1 = m + (size_t)(t + 1) * d;
+    for (int i = 0; i < d; ++i) {   /* c = x1 - g(dt) x0 */
+      double v = 0.0;
+      for (int k = 0; k < d; ++k) v += Gt[IDX(i, k, d)] * x0[k];
+      c[i] = x1[i] - v;
+    }
+    for (int i = 0; i < d * d; ++i) cov[i] = W[i] * dt;
+    chol_lower(d, cov, L);
+    double logdet = 0.0, quad = 0.0;
+    for (int i = 0; i < d; ++i) {   /* u = L^-1 c */
+      double v = c[i];
+      for (int l = 0; l < i; ++l) v -= L[IDX(i, l, d)] * u[l];
+      if (!(L[IDX(i, i, d)] > 0.0)) bad = 1;
+      u[i] = v / L[IDX(i, i, d)];
+      quad += u[i] * u[i];
+      logdet += log(L[IDX(i, i, d)]);
+    }
+    ll += -0.5 * quad - (0.5 * d * 1.8378770664093453 + logdet);
+  }
+  free(cov); free(L); free(c); free(u);
+  *out = bad ? NAN : ll;
+  return bad;
+}
+
 /* ---- scalar AR(1) state (FilterAr.scala:15-82) -------------------------------------------------
  * alpha_t = mu + phi (alpha_{t-1} - mu) + eta_t, eta_t ~ N(0, sigma_eta^2);  y_t = alpha_t + eps_t, eps_t ~ N(0, v_t).
  * filterUnivariate (:34-49): m0 = mu, c0 = sigma_eta^2 / (1 - phi^2); stepUni (:17-32).  Outputs have T+1 records. */
