@@ -129,6 +129,15 @@ class KalmanFilter:
         ll = np.asarray(engine.loglik(mat, p, y, flags=flags)["loglik"])
         return ll if batched else float(ll[0])
 
+    @staticmethod
+    def likelihood(mod: Dlm, ys, p, engine: Engine, *, flags: int = 0):
+        """KalmanFilter.likelihood(mod, ys)(p) as the reference writes it (KalmanFilter.scala:299-306) -- the function
+        MetropolisHastings.dlm evaluates (MetropolisHastings.scala:134, :205): filter, then the TRANSITION density of the filtered
+        means, sum_t log N(m_t; g(dt_t) m_{t-1}, W dt_t) (KalmanFilter.logLikelihood, :175-183).  For the
+        prediction-error log-likelihood log p(y | V, W) use log_likelihood."""
+        from . import _lib
+        return KalmanFilter.log_likelihood(mod, ys, p, engine, flags=flags | _lib.OPT_LOGLIK_LITERAL_Q7)
+
 
 def _records_from_states(kf_states: Sequence[Sequence[KfState]], d: int) -> np.ndarray:
     N, T1 = len(kf_states), len(kf_states[0])

@@ -9,6 +9,7 @@
 //   DlmParameters{v, w, m0, c0}, Data{time, observation}                       Dlm.scala:36-39,94
 //   KalmanFilter::filterDlm / filter                                          KalmanFilter.scala:262-294
 //   KalmanFilter::logLikelihood (sum of conditionalLikelihood)                KalmanFilter.scala:138-153
+//   KalmanFilter::likelihood (the literal one MetropolisHastings.dlm calls)    KalmanFilter.scala:175-183, :299-306
 //   Smoothing::backwardsSmoother / filterSmooth / ffbsDlm                      Smoothing.scala:57-64,173-180
 //   SvdFilter::filterDlm, SvdSampler::ffbsDlm                                  SvdFilter.scala:158-161, SvdSampler.scala:79-82
 //   GibbsSampling::sample / sampleSvd, GibbsWishart::sample                    Gibbs.scala:165-180,203-217, GibbsWishart.scala:65-80
@@ -235,6 +236,17 @@ inline std::vector<double> logLikelihood(Engine& e, const Dlm& mod, const std::v
   detail::Tables t = detail::materialise(mod, ys);
   const dlm_model_desc m = detail::modelDesc(t); const dlm_params_desc q = detail::paramsDesc(p);
   const dlm_options o = detail::opts(0, DLM_MEM_HOST);
+  std::vector<double> ll((size_t)t.N);
+  e.check(dlm_loglik_batch(e.get(), &m, &q, t.y.data(), &o, ll.data(), nullptr));
+  return ll;
+}
+// KalmanFilter.likelihood(mod, ys)(p) as the reference writes it (KalmanFilter.scala:299-306; what MetropolisHastings.dlm
+// evaluates, MetropolisHastings.scala:134, :205): the transition density of the filtered means,
+// sum_t log N(m_t; g(dt_t) m_{t-1}, W dt_t) (KalmanFilter.logLikelihood, :175-183) -- NOT the prediction-error likelihood above
+inline std::vector<double> likelihood(Engine& e, const Dlm& mod, const std::vector<std::vector<Data>>& ys, const DlmParameters& p) {
+  detail::Tables t = detail::materialise(mod, ys);
+  const dlm_model_desc m = detail::modelDesc(t); const dlm_params_desc q = detail::paramsDesc(p);
+  const dlm_options o = detail::opts(DLM_OPT_LOGLIK_LITERAL_Q7, DLM_MEM_HOST);
   std::vector<double> ll((size_t)t.N);
   e.check(dlm_loglik_batch(e.get(), &m, &q, t.y.data(), &o, ll.data(), nullptr));
   return ll;
@@ -487,6 +499,10 @@ inline std::vector<double> logLikelihood(const DeviceSeries& ys, const DevicePar
   std::vector<double> out((size_t)ys.N());
   ll.download(out.data(), ll.bytes());
   return out;
+}
+// KalmanFilter.likelihood as written (KalmanFilter.scala:299-306) on device-resident series: the transition density of the filtered means
+inline std::vector<double> likelihood(const DeviceSeries& ys, const DeviceParameters& p, Flags flags = 0) {
+  return logLikelihood(ys, p, flags | DLM_OPT_LOGLIK_LITERAL_Q7);
 }
 }  // namespace KalmanFilter
 

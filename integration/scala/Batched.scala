@@ -308,12 +308,18 @@ final class Batched(device: Int = 0, stagingBytes: Int = 64 << 20) extends AutoC
   }
 
   /** Sum over each series of KalmanFilter.conditionalLikelihood(f_t, Q_t, y_t) (KalmanFilter.scala:138-153). */
-  def logLikelihood(ys: DeviceSeries, p: DeviceParameters): Array[Double] = {
+  def logLikelihood(ys: DeviceSeries, p: DeviceParameters, flags: Int = 0): Array[Double] = {
     val (ll, st) = (alloc(8L * ys.n), alloc(4L * ys.n))
-    nat.loglik(handle, ys.model, p.desc, opts(0), ys.y.ptr, ll.ptr, st.ptr)
+    nat.loglik(handle, ys.model, p.desc, opts(flags), ys.y.ptr, ll.ptr, st.ptr)
     st.free()
     val out = download(ll, 0L, ys.n); ll.free(); out
   }
+
+  /** KalmanFilter.likelihood(mod, ys)(p) as the reference writes it (KalmanFilter.scala:299-306) -- what
+    * MetropolisHastings.dlm evaluates (MetropolisHastings.scala:134, :205): the transition density of the filtered means,
+    * sum_t log N(m_t; g(dt_t) m_(t-1), W dt_t) (KalmanFilter.logLikelihood :175-183).  With one DlmParameters per series
+    * (DeviceParameters built from a Vector) a whole population of proposals is evaluated in one launch. */
+  def likelihood(ys: DeviceSeries, p: DeviceParameters): Array[Double] = logLikelihood(ys, p, Native.LoglikLiteralQ7)
 
   /** Smoothing.ffbsDlm(mod, ys, p) for N series (Smoothing.scala:173-180).  The reference's draws cannot be seeded
     * (SURVEY Q3); here a draw is a pure function of (seed, series index). */

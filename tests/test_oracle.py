@@ -362,6 +362,39 @@ def test_loglik_matches_scipy_and_scalar_closed_form():
     assert oracle.loglik(M, f, y) == pytest.approx(want, rel=1e-12, abs=1e-10)
 
 
+def test_likelihood_q7_on_the_reference_s_filtered_means(golden_dir):
+    """KalmanFilter.likelihood (KalmanFilter.scala:299-306) = KalmanFilter.logLikelihood (:175-183) over the filtered means:
+    sum_t log N(m_t; g(dt) m_{t-1}, W dt).  Pinned by the reference's own output: the filtered means of
+    first_order_dlm_filtered.csv (config C1: w = 3, dt = 1, g = 1) put through scipy's normal density, and -- dense W, d = 3,
+    irregular grid, missing data -- through scipy's multivariate normal."""
+    from scipy.stats import multivariate_normal, norm
+    mat, p, y = _c1(golden_dir)
+    M = _omodel(mat)
+    f = oracle.kf_filter(M, p.v, p.w, p.m0, p.c0, y)
+    _, rows = _read_csv(os.path.join(golden_dir, "first_order_dlm_filtered.csv"))
+    m_ref = np.array([float(r[1]) for r in rows])                      # the reference's m_0 .. m_T
+    want = norm(m_ref[:-1], np.sqrt(3.0)).logpdf(m_ref[1:]).sum()
+    assert oracle.likelihood_q7(M, f, p.w) == pytest.approx(want, rel=1e-12)
+    rng = np.random.default_rng(12)
+    mod = Dlm.polynomial(1) + Dlm.seasonal(24, 1)        # G depends on dt: several tables
+    times = np.cumsum(np.array([1, 2, 1, 0.5, 3] * 6, dtype=np.float64))
+    mat = materialise(mod, times)
+    A = rng.standard_normal((3, 3))
+    p = DlmParameters([[0.7]], A @ A.T + 0.3 * np.eye(3), rng.standard_normal(3), np.eye(3))
+    y = rng.standard_normal((mat.T, 1)).cumsum(axis=0)
+    y[rng.random(y.shape) < 0.2] = np.nan
+    M = _omodel(mat)
+    f = oracle.kf_filter(M, p.v, p.w, p.m0, p.c0, y)
+    assert mat.n_g > 1
+    want = 0.0
+    for t in range(mat.T):
+        G = oracle.from_cm(np.asarray(mat.G)[mat.g_index[t] * 9:(mat.g_index[t] + 1) * 9], 3, 3)
+        want += multivariate_normal(G @ f["m"][t], p.w * mat.dt[t]).logpdf(f["m"][t + 1])
+    assert oracle.likelihood_q7(M, f, p.w) == pytest.approx(want, rel=1e-11)
+    # it is NOT the prediction-error likelihood (SURVEY quirk Q7)
+    assert abs(oracle.likelihood_q7(M, f, p.w) - oracle.loglik(M, f, y)) > 1.0
+
+
 def test_ar1_filter_reproduces_reference_csv(golden_dir):
     """FilterAr.filterUnivariate on examples/data/ar_dlm.csv with SvParameters(0.8, 1.0, 0.3), v = 0.5
     (examples/src/main/scala/dlm/ar.scala:47-61) reproduces ar_dlm_filtered.csv (5001 rows)."""
