@@ -236,8 +236,11 @@ def test_chain_and_data_csv_round_trip(tmp_path, golden_dir):
 
 def test_headline_kernels_keep_their_occupancy(tmp_path):
     """The C2 kernels are tuned to a register budget: the backward kernel of the K = 2 regular instantiation at <= 96 VGPRs (five
-    waves per SIMD) and the forward kernel at <= 96 (five), with no spills.  A change that costs a wave per SIMD costs ~3 % of the
-    headline and shows up nowhere else -- so the build is checked here (device-only assembly of dlm_sparse16.hip, ~10 s)."""
+    waves per SIMD) and the forward kernel at <= 96 (five), with no spills -- except, since round 3, ONE value of the backward kernel
+    (an LDS address of the transposed read) that lives in scratch and is reloaded only in the every-8th-step symmetrisation branch:
+    with the error-bounded steady-state test the allocator needs 98 registers otherwise, and five waves with that reload measured
+    1.5 % faster than four without (profiles/r03_notes.md).  A change that costs a wave per SIMD costs ~3 % of the headline and shows
+    up nowhere else -- so the build is checked here (device-only assembly of dlm_sparse16.hip, ~10 s)."""
     import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -257,5 +260,5 @@ def test_headline_kernels_keep_their_occupancy(tmp_path):
     bwd = [v for k, v in meta.items() if "k_smoother_sp16ILi2ELb0ELb0E" in k]
     fwd = [v for k, v in meta.items() if "k_filter_sp16ILi2ELb0ELb0ELb0E" in k]
     assert len(bwd) == 1 and len(fwd) == 1, sorted(meta)
-    assert bwd[0]["vgpr_count"] <= 96 and bwd[0]["vgpr_spill_count"] == 0, bwd
+    assert bwd[0]["vgpr_count"] <= 96 and bwd[0]["vgpr_spill_count"] <= 1, bwd
     assert fwd[0]["vgpr_count"] <= 96 and fwd[0]["vgpr_spill_count"] == 0, fwd
