@@ -35,6 +35,18 @@ def build_variant(name, defines):
     return out
 
 
+def build_tu_variant(name, src, defines):
+    """Experimental build in which only ONE translation unit gets extra -D flags (the other objects come from the regular
+    build) -> bayesian_dlms_amd/libdlm_engine_<name>.so.  Select it with DLM_ENGINE_LIB."""
+    build()
+    out = os.path.join(HERE, f"libdlm_engine_{name}.so")
+    o = os.path.join(HERE, "build", f"{name}_{src.replace('.hip', '.o')}")
+    subprocess.check_call([HIPCC] + FILE_FLAGS.get(src, FLAGS) + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, src), "-o", o])
+    objs = [o if s == src else os.path.join(HERE, "build", s.replace(".hip", ".o")) for s in SOURCES]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrccl"])
+    return out
+
+
 def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, "dlm_internal.h"), os.path.join(HERE, "..", "include", "dlm_engine.h")]
     objs = []

@@ -54,6 +54,14 @@ struct dlm_engine {
     std::vector<double> g_host, f_host;         // host-mode calls: the tables analysed
   } an;
   bool an_touched = true;
+  // shared-covariance path: the tables of the covariance-only run, one byte per series (route), and a second
+  // stream + events so that the backward covariance run overlaps the forward mean kernel
+  double* covws = nullptr;
+  size_t covws_bytes = 0;
+  unsigned char* route = nullptr;
+  size_t route_bytes = 0;
+  hipStream_t cov_stream = nullptr;
+  hipEvent_t cov_ev[2] = {nullptr, nullptr};
   // DLM_OPT_COUNT_STEPS: [4] device counters the kernels add to (KArgs::counters), read by dlm_last_counters
   unsigned long long* counters = nullptr;
   // DLM_OPT_MODEL_UNCHANGED is verified on the device: model_sum[0] = checksum of (F, G, g_index, dt) at the last fresh
@@ -370,7 +378,8 @@ int ensure_fws(dlm_engine* e, size_t need) {
 }
 
 int ensure_side(dlm_engine* e, const KArgs& k) {
-  const size_t need = sizeof(double) * 2 * (size_t)k.N * ((size_t)k.T + 1);
+  // (e / Q, 1 / Q) per record for the per-series kernels, and behind them one double per record (e / Q) for the shared-covariance kernels
+  const size_t need = sizeof(double) * 3 * (size_t)k.N * ((size_t)k.T + 1);
   if (need > e->side_bytes) {
     if (e->side) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->side)); e->side = nullptr; e->side_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->side, need));
@@ -405,6 +414,79 @@ int packed_path(dlm_engine* e, KArgs& k) {
   k.flags |= DLM_OPT_NO_LANE;
   if (!(fast_shape_ok(k) && e->sparse_k > 0) || (k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1))
     return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_PACKED_SYM needs the structured d <= 15, p = 1 path (time-invariant F, <= 4 nonzeros per row and column of G) without DLM_OPT_FORCE_GENERIC / DLM_OPT_SMOOTHER_COMPAT_Q1; use dense records otherwise");
+  return DLM_OK;
+}
+
+// Shared covariance sequence (dlm_sparse16.hip): structured d <= 15, p = 1 path on a regular grid with V, W, C0
+// shared by the batch.  One wave runs the covariance recursions into tables, every series its mean recursions against them; a
+// series with a missing observation is marked by the forward mean kernel and served by the per-series kernels launched behind.
+bool use_shared_cov(const dlm_engine* e, const KArgs& k) {
+  return fast_shape_ok(k) && e->sparse_k > 0 && !dlm::lane_supported(k) && dlm::shared_cov_eligible(k);
+}
+int ensure_xplus_bytes(dlm_engine* e, size_t need) {
+  if (need > e->xplus_bytes) {
+    if (e->xplus) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->xplus, need));
+    e->xplus_bytes = need;
+  }
+  return DLM_OK;
+}
+int ensure_shared(dlm_engine* e, const KArgs& k, dlm::CovTabs& tb, bool with_backward) {
+  const size_t need = sizeof(double) * dlm::covtabs_doubles(k.d, k.T);
+  if (need > e->covws_bytes) {
+    if (e->covws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->covws)); e->covws = nullptr; e->covws_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->covws, need));
+    e->covws_bytes = need;
+  }
+  if ((size_t)k.N > e->route_bytes) {
+    if (e->route) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->route)); e->route = nullptr; e->route_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->route, (size_t)k.N));
+    e->route_bytes = (size_t)k.N;
+  }
+  int rc = ensure_side(e, k);
+  if (rc) return rc;
+  if (!e->cov_stream) {
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->cov_stream, hipStreamNonBlocking));
+    for (auto& ev : e->cov_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  dlm::covtabs_carve(e->covws, k.d, k.T, tb);
+  tb.eq = e->side + 2 * (size_t)k.N * ((size_t)k.T + 1);
+  tb.mc = tb.sc = nullptr;
+  if (with_backward) {   // compact means of the mean-only kernels: 512 bytes per step and group of four series, filtered then smoothed
+    const size_t one = 64 * (size_t)((k.N + 3) / 4) * ((size_t)k.T + 1);
+    int rc2 = ensure_xplus_bytes(e, sizeof(double) * one);
+    if (rc2) return rc2;
+    tb.mc = e->xplus;
+  }
+  return DLM_OK;
+}
+// forward half: covariance-only run, mean kernel, then the per-series kernel for the series the mean kernel routed away.
+// with_backward: the backward covariance run starts on the engine's second stream as soon as the forward tables exist and
+// overlaps the forward mean kernel (it needs nothing from the data).
+int run_shared_filter(dlm_engine* e, KArgs& k, dlm::CovTabs& tb, bool with_backward) {
+  int rc = ensure_shared(e, k, tb, with_backward);
+  if (rc) return rc;
+  k.route = e->route; k.route_take = 0;
+  e->variant = "sparse16";   // (the same kernel family; dlm_last_counters[2] tells the series served by the shared-covariance kernels)
+  HIP_TRY(e, dlm::launch_sparse16_cov_filter(k, e->sparse_k, e->sp_dev, tb, e->stream));
+  if (with_backward) {
+    HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
+    HIP_TRY(e, dlm::launch_sparse16_cov_smoother(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
+    HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
+  }
+  HIP_TRY(e, dlm::launch_sparse16_mean_filter(k, e->sparse_k, e->sp_dev, tb, e->stream));
+  KArgs kg = k;
+  kg.route_take = 1;
+  HIP_TRY(e, dlm::launch_sparse16_filter(kg, e->sparse_k, e->sp_dev, with_backward ? e->side : nullptr, nullptr, e->stream));
+  return DLM_OK;
+}
+int run_shared_smoother(dlm_engine* e, KArgs& k, const dlm::CovTabs& tb) {
+  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));   // the S_t table
+  HIP_TRY(e, dlm::launch_sparse16_mean_smoother(k, e->sparse_k, e->sp_dev, tb, e->stream));
+  KArgs kg = k;
+  kg.route_take = 1;
+  HIP_TRY(e, dlm::launch_sparse16_smoother(kg, e->sparse_k, e->sp_dev, e->side, e->stream));
   return DLM_OK;
 }
 
@@ -516,6 +598,10 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->fws) (void)hipFree(e->fws);
   if (e->spb_dev) (void)hipFree(e->spb_dev);
   if (e->spf_dev) (void)hipFree(e->spf_dev);
+  if (e->covws) (void)hipFree(e->covws);
+  if (e->route) (void)hipFree(e->route);
+  for (auto& ev : e->cov_ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->cov_stream) (void)hipStreamDestroy(e->cov_stream);
   if (e->counters) (void)hipFree(e->counters);
   if (e->model_sum) (void)hipFree(e->model_sum);
   if (e->model_bad) (void)hipHostFree(e->model_bad);
@@ -699,6 +785,11 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
     if ((rc = packed_path(e, k))) return rc;
     k.packed = 1;
   }
+  if (use_shared_cov(e, k)) {
+    dlm::CovTabs tb;
+    if ((rc = run_shared_filter(e, k, tb, false))) return rc;
+    return st.finish(opts->flags & DLM_OPT_ASYNC);
+  }
   if ((rc = run_filter(e, k, false))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }
@@ -876,6 +967,15 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
     k.filt = e->fws;
   }
   if ((rc = mark(e, 0))) return rc;
+  if (filt && fast_smoother_ok(e, k) && use_shared_cov(e, k)) {
+    dlm::CovTabs tb;
+    if ((rc = run_shared_filter(e, k, tb, true))) return rc;
+    if ((rc = mark(e, 1))) return rc;
+    k.filt_in = k.filt;
+    if ((rc = run_shared_smoother(e, k, tb))) return rc;
+    if ((rc = mark(e, 2))) return rc;
+    return st.finish(opts->flags & DLM_OPT_ASYNC);
+  }
   if ((rc = run_filter(e, k, fused_fast))) return rc;
   if ((rc = mark(e, 1))) return rc;
   k.filt_in = k.filt;

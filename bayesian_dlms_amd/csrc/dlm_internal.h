@@ -35,6 +35,11 @@ struct KArgs {
   int spf_k;           // largest nonzero count per column / row of F (1..4)
   unsigned flags;
   unsigned long long seed, series_offset;
+  // Shared-covariance path (dlm_sparse16.hip): route[n] != 0 marks a series with a missing observation.  The
+  // mean-only kernels set it and skip such a series; the per-series kernels launched behind them with route_take = 1 serve
+  // exactly those series (and leave at once for the others).  nullptr: every series is served (the ordinary calls).
+  unsigned char* route;
+  int route_take;
   unsigned long long* counters;   // engine-owned [4], zeroed per call (nullable): steady (short) steps taken by the forward [0] / backward [1] kernel,
                                   // series served by the shared-covariance kernels [2], series sent to their own full recursion [3]
 };
@@ -79,6 +84,29 @@ hipError_t launch_small_mv_sampler(const KArgs& a, hipStream_t s);   // the same
 hipError_t launch_sparse16_rts(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s);
 hipError_t launch_small_mv_rts(const KArgs& a, hipStream_t s);
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s);
+// ---- shared covariance sequence: with parameters shared by the batch and no missing observation C_t, R_t, K_t,
+// Q_t, P_t and S_t do not depend on the data.  ONE wave runs the covariance recursions (the per-series kernels' own code on a
+// series of zeros: the same arithmetic, bit for bit) into L2-resident tables, and every series runs only its mean recursions
+// against them.  A series that meets a missing observation is marked in KArgs::route and served by the per-series kernels.
+struct CovTabs {
+  double* ftab;   // [T+1] rows of frow bytes: [filtered record of the covariance-only run (mean slots 0): C_t | 16 doubles: R_t F (full
+                  //   step) or K_t (steady step) per component, [15] = +-1/Q_t (negative: steady step)]
+  double* btab;   // [T+1] rows of brow bytes: [smoothed record of the covariance-only run: S_t | 16 doubles: K_t = C_t F / V per
+                  //   component, [15] = 1 where the step was a steady one | C_t record]
+  double* cside;  // [T+1][2]  side records of the covariance-only forward run (0, +-1/Q_t), read by its backward run
+  double* eq;     // [N][T+1]  per series: e_t / Q_t, forward -> backward
+  double* mc;     // fused call: the filtered means once more, compact -- [ceil(N / 4)][T+1][4][16] (512 bytes per wave and step) --
+                  //   for the backward kernel (a sequential stream instead of 112 bytes out of every 1456-byte record); nullptr: dlm_filter_batch
+  double* sc;     // (unused: the smoothed means of the record-writer experiment, profiles/r03_notes.md)
+  int frow, brow;
+};
+size_t covtabs_doubles(int d, int T);   // doubles of the table block (everything but eq)
+void covtabs_carve(double* base, int d, int T, CovTabs& t);
+bool shared_cov_eligible(const KArgs& a);   // regular grid, time-invariant F / V / W, V, W, C0 shared by the batch, dense records, no prior / forecast records
+hipError_t launch_sparse16_cov_filter(const KArgs& a, int K, const SparseT* rows_dev, const CovTabs& tabs, hipStream_t s);
+hipError_t launch_sparse16_cov_smoother(const KArgs& a, int K, const SparseT* cols_dev, const CovTabs& tabs, hipStream_t s);
+hipError_t launch_sparse16_mean_filter(const KArgs& a, int K, const SparseT* rows_dev, const CovTabs& tabs, hipStream_t s);
+hipError_t launch_sparse16_mean_smoother(const KArgs& a, int K, const SparseT* cols_dev, const CovTabs& tabs, hipStream_t s);
 
 // ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------
 // Nonzeros of the rows (`rows`) and of the columns (`cols`) of a d x d G with at most 4 per row and column (every

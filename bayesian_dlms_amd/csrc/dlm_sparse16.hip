@@ -339,13 +339,19 @@ __device__ void wave_chol(double* img, int d, int g, int c) {
 // instantiation keeps none of that.
 // LL: also accumulate the prediction-error log-likelihood (its own instantiation: the expansion of log() in the loop
 // would cost the plain filter two waves per SIMD of occupancy).
-template <int K, bool SIM, bool IRR, bool LL>
+// COV: the covariance-only run of the shared-covariance path -- this very code on ONE series of zeros with a zero
+// prior mean (the covariance entries of the augmented tile never see the mean: bit for bit the C_t, K_t, Q_t of every
+// series of a batch with shared parameters and no missing observation); it also leaves the vector of the mean update,
+// R_t F (full step) or K_t (steady step), in kftab [T+1][16] for the mean-only kernel.
+template <int K, bool SIM, bool IRR, bool LL, bool COV = false>
 __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __restrict__ sp, double* __restrict__ side,
-                                            double* __restrict__ xplus, double* lds /* 4 WAVE_LDS (+ 4 IMG with SIM) doubles */) {
+                                            double* __restrict__ xplus, double* lds /* 4 WAVE_LDS (+ 4 IMG with SIM) doubles */,
+                                            double* __restrict__ kftab = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
   if (n >= a.N) return;
+  if (!COV && a.route && (a.route[n] != 0) != (a.route_take != 0)) return;   // shared-covariance call: only the series routed here
   double* imgA = lds + wave * WAVE_LDS;
   double* imgB = imgA + IMG;
   double* vRF = imgB + IMG;      // R F  (one 16-vector is spare)
@@ -360,10 +366,10 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
   const double* C0 = a.C0 + (size_t)n * a.c0_stride;
   const double* m0 = a.m0 + (size_t)n * a.m0_stride;
   double V = a.V[(size_t)n * a.v_stride];   // V_0; reloaded every step when time-varying (IRR instantiation)
-  const double* y = a.y + (size_t)n * T;
+  const double* y = COV ? nullptr : a.y + (size_t)n * T;
   // likelihood-only calls pass no record buffer: a zero-sized resource drops every store
   const bool packed = SIM || a.packed;                // records go to an engine-internal workspace: packed (see below)
-  const int recb = packed ? packed_rec_bytes(d) : rec * 8;
+  const int recb = COV ? rec * 8 + 128 : (packed ? packed_rec_bytes(d) : rec * 8);   // record stride (COV: a table row is the record followed by the 16 doubles of kftab)
   char* bout = a.filt ? (char*)a.filt + (size_t)n * (T + 1) * recb : nullptr;
   const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, a.filt ? (size_t)(T + 1) * recb : 0);
   double ll = 0.0;   // sum_t log N(y_t; f_t, Q_t) (KalmanFilter.conditionalLikelihood, KalmanFilter.scala:138-153)
@@ -402,7 +408,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
                      : (ok ? (d + i * d + c) * 8 : (vr[r] && col15 ? i * 8 : OOB));
     w[r] = ok ? W[i * d + c] : 0.0;
     cc[r] = ok ? C0[i * d + c] : 0.0;
-    if (!SIM) {                                  // SIM: y* is filtered from a zero prior mean
+    if (!SIM && !COV) {                          // SIM: y* is filtered from a zero prior mean
       if (vr[r] && col15) cc[r] = m0[i];
       if (i == 15 && vc) cc[r] = m0[c];
     }
@@ -466,7 +472,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
   double Kst = 0.0, rq_st = 0.0, Q_st = 0.0, lq_st = 0.0;
   double ychunk = 0.0;
   for (int t = 0; t < T; ++t) {
-    if ((t & 63) == 0) {
+    if (!COV && (t & 63) == 0) {
       ychunk = (t + lane < T) ? y[t + lane] : 0.0;
       // consume the load inside the branch: otherwise the wait for it lands on the common path as
       // vmcnt(0), which every step would also wait for the record stores of the step before
@@ -528,6 +534,8 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
       const double f = uniform_from_lane(row_sum(Fc * ac), 0);
       const double e = yt - f, erq = e * rq_st;
       const double mn = fma(Kst, e, ac);                                   // m = a + K e
+      if (COV && g == 0) ((double*)((char*)kftab + (size_t)(t + 1) * recb))[c] = vc ? Kst : (c == 15 ? -rq_st : 0.0);   // [15]: 1 / Q negated = "steady step"
+
       wave_sync();                                                         // the reads of vRF above precede its rewrite
       vRF[c] = mn;
       wave_sync();
@@ -603,6 +611,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
       //   = R - RF_i * (RF_j / Q) * (2 - Q * (1/Q))   -- the same expression, factored
       //   column 15: a + RF e / Q = m ;  row 15 (lanes g == 3 of register 3): a[c] + K[c] e
       const double e = yt - f, rq = fast_rcp(Q), erq = e * rq;
+      if (COV && g == 0) ((double*)((char*)kftab + (size_t)(t + 1) * recb))[c] = vc ? rfc : (c == 15 ? rq : 0.0);   // R_t F (the mean-only kernel's m = a + (R F)(e / Q)); [15]: 1 / Q
       const double Kc = (col15 ? 0.0 : rfc) * rq;
       const double ngam = col15 ? erq : -Kc * fma(-Q, rq, 2.0);
       const bool check = may_settle && bpri == nullptr && (t & 3) == 3;
@@ -634,7 +643,10 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
     wave_sync();   // the images are rewritten at the top of the next step
   }
   if (LL && a.loglik && lane == 0) a.loglik[n] = ll;
-  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
+  if (!COV && a.counters && lane == 0) {
+    if (nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
+    if (a.route) atomicAdd(&a.counters[3], 1ull);          // a series of a shared-covariance call that ran its own recursion
+  }
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(cc[r]);
@@ -648,6 +660,13 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS + (SIM ? 4 * IMG : 0)];
   filter_body<K, SIM, IRR, LL>(a, sp, side, xplus, lds);
 }
+// the covariance-only run: one wave (a: N = 1, filt = the C_t table)
+template <int K>
+__global__ __launch_bounds__(64) void k_cov_filter_sp16(KArgs a, const SparseT* __restrict__ sp, double* __restrict__ side,
+                                                        double* __restrict__ kftab) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
+  filter_body<K, false, false, false, true>(a, sp, side, nullptr, lds, kftab);
+}
 
 // ---------------------------------------------------------------------------------------
 // backward pass: MFMA for P C and C (P C); gathers for G^T M G
@@ -658,15 +677,18 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
 // extraction from the product, and mean and covariance are read and stored by the same 4 instructions.
 // ---------------------------------------------------------------------------------------
 constexpr int SM_LDS = 2 * IMG + 3 * 16 + 2;   // backward pass: two images + three 16-vectors + the state of the steady-state test per wave
-template <int K, bool IRR, bool PIPE = false>
+// COV: the covariance-only run of the shared-covariance path -- this code on the C_t table (means zero): S_t, bit for bit that of
+// every series of the batch; K_t = C_t F / V and the kind of each step (steady: 1) go to kbtab [T+1][16] for the mean-only kernel.
+template <int K, bool IRR, bool PIPE = false, bool COV = false>
 __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __restrict__ sp, const double* __restrict__ side,
-                                              double* lds /* 4 SM_LDS doubles */, char* ring_all) {
+                                              double* lds /* 4 SM_LDS doubles */, char* ring_all, double* __restrict__ kbtab = nullptr) {
   // ring_all: two-slot ring per wave for the LDS-DMA prefetch; a slot is a raw record followed by one
   // zero double, which the padded lanes read.  Record t lives in slot t & 1 and is requested two steps ahead.
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it scalar
   const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
   if (n >= a.N) return;
+  if (!COV && a.route && (a.route[n] != 0) != (a.route_take != 0)) return;   // shared-covariance call: only the series routed here
   double* imgA = lds + wave * SM_LDS;
   double* imgB = imgA + IMG;
   double* vK = imgB + IMG;       // K_t
@@ -681,9 +703,12 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   const bool pout = (a.packed & 2) != 0;                          // smoothed records (output): packed with DLM_OPT_PACKED_SYM, dense otherwise
   const int recb = pout ? packed_rec_bytes(d) : rec * 8;
   const int rinb = (a.packed & 1) ? packed_rec_bytes(d) : rec * 8; // filtered records (input): packed when engine-internal or DLM_OPT_PACKED_SYM
-  const char* bin = (const char*)a.filt_in + (size_t)n * (T + 1) * rinb;
-  char* bout = (char*)a.smooth + (size_t)n * (T + 1) * recb;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * recb);
+  // COV: the input is the forward table (rows of rinb + 128 bytes), the output the backward table, whose rows are
+  // [S_t record | kbtab (16 doubles) | C_t record]
+  const int rins = COV ? rinb + 128 : rinb, recs = COV ? 2 * recb + 128 : recb;   // strides
+  const char* bin = (const char*)a.filt_in + (size_t)n * (T + 1) * rins;
+  char* bout = (char*)a.smooth + (size_t)n * (T + 1) * recs;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, (size_t)(T + 1) * recs);
   const double* sd = side + (size_t)n * (T + 1) * 2;
 
   int idx[K];
@@ -727,7 +752,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   const int slotb = rinb + 16;
   char* ring = ring_all + wave * 2 * slotb;
   const unsigned ring_lds = lds_addr_of(ring);
-  const i4 rdma = rsrc_words(bin, (unsigned)((size_t)(T + 1) * rinb));
+  const i4 rdma = rsrc_words(bin, (unsigned)((size_t)(T + 1) * rins));
   const int n16 = rinb / 16;                          // d (d + 1) is even (and packed records are padded): whole 16 B pieces
   const int n16m = (d * 8 + 15) / 16;                 // the mean alone (it leads the record in both layouts)
   if (lane < 2) *(double*)(ring + lane * slotb + rinb) = 0.0;
@@ -737,9 +762,9 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   double ceq = sd[2 * T], ciq = sd[2 * T + 1];
   double neq, niq;
   { const int t1 = T > 0 ? T - 1 : 0; neq = sd[2 * t1]; niq = sd[2 * t1 + 1]; }
-  dma_record(rdma, ring_lds + (T & 1) * slotb, T * rinb, lane, n16);
+  dma_record(rdma, ring_lds + (T & 1) * slotb, T * rins, lane, n16);
   { const int t1 = T > 0 ? T - 1 : 0;
-    dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * rinb, lane, (!IRR && uniform_from_lane(ciq, 0) < 0.0) ? n16m : n16); }
+    dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * rins, lane, (!IRR && uniform_from_lane(ciq, 0) < 0.0) ? n16m : n16); }
   vQ[c] = 0.0;
   d4 out = {0.0, 0.0, 0.0, 0.0};                     // the record stored last (assigned in every step before its store)
   d4 cc = {0.0, 0.0, 0.0, 0.0};
@@ -798,7 +823,8 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     if (!IRR && psteady && same_next && observed) {
       ++nsteady;
       was_steady = true;
-      { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rinb, lane, mean_only ? n16m : n16); }
+      if (COV && g == 0) ((double*)(bout + (size_t)t * recs + recb))[c] = col15 ? 1.0 : vK[c];   // K_t (that of the step before) and the mark "steady step"
+      { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rins, lane, mean_only ? n16m : n16); }
       d4 nqr;
       {
         const unsigned bq = lds_addr_of(vQ + g);             // -q_t, published by the last step's closing wave_sync
@@ -842,9 +868,10 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       vK[c] = (observed && vc) ? sum_g(ks) * (IRR ? rV : imgB[16]) : 0.0;
     }
     wave_sync();                                             // also publishes vQ of the last step
+    if (COV && g == 0) ((double*)(bout + (size_t)t * recs + recb))[c] = col15 ? 0.0 : vK[c];
     // the slot just read is free again: request record t-2 into it (always issued, so that the operation
     // count behind every request is the same; below record 0 it re-reads record 0, which nobody uses)
-    { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rinb, lane, mean_only ? n16m : n16); }
+    { const int t2 = t > 1 ? t - 2 : 0; dma_record(rdma, ring_lds + (t & 1) * slotb, t2 * rins, lane, mean_only ? n16m : n16); }
     d4 kr, nqr;
     {
       const unsigned bk = lds_addr_of(vK + g), bq = lds_addr_of(vQ + g);
@@ -969,9 +996,13 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     }
     }
     same_next = same_c;
-    const int so = t * recb;
+    const int so = t * recs;
 #pragma unroll
     for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], so, out[r]);
+    if (COV) {   // C_t behind S_t and the K row: one table row serves a whole backward step of the mean-only kernel
+#pragma unroll
+      for (int r = 0; r < 4; ++r) buf_store(rout, bout, offA[r], so + recb + 128, cc[r]);
+    }
     STAMP(5)
   }
 #ifdef DLM_STAMP
@@ -979,7 +1010,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     for (int k = 0; k < 8; ++k) a.status[1 + k] = (int)(seg[k] / (unsigned long long)(T + 1));
 #endif
   vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
-  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[1], (unsigned long long)nsteady);
+  if (!COV && a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[1], (unsigned long long)nsteady);
   // P and q carry any non-finite value down to record 0: test the last output
   bool bad = false;
 #pragma unroll
@@ -994,6 +1025,14 @@ __global__ __launch_bounds__(256, PIPE ? 2 : (K <= 2 ? SM_WAVES_K2 : SM_WAVES)) 
   __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
   extern __shared__ __attribute__((aligned(16))) char ring_all[];
   smoother_body<K, IRR, PIPE>(a, sp, side, lds, ring_all);
+}
+// the covariance-only run: one wave alone on its SIMD (the variant whose output-product MFMAs are spread over the recursion)
+template <int K>
+__global__ __launch_bounds__(64) void k_cov_smoother_sp16(KArgs a, const SparseT* __restrict__ sp, const double* __restrict__ side,
+                                                          double* __restrict__ kbtab) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
+  extern __shared__ __attribute__((aligned(16))) char ring_all[];
+  smoother_body<K, false, true, true>(a, sp, side, lds, ring_all, kbtab);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1176,6 +1215,470 @@ __global__ __launch_bounds__(256, FI_WAVES) void k_simsmooth_sp16(KArgs a, const
 }
 
 // ---------------------------------------------------------------------------------------
+// Shared covariance sequence.
+//
+// With V, W and C0 shared by the batch and no missing observation, C_t, R_t, K_t, Q_t (KalmanFilter.scala:64-107) and the
+// smoother's P_t, S_t (Smoothing.scala:31-47, information form above) do not depend on the data: the reference recomputes them
+// for every series because it has no batch.  Here ONE wave runs the two covariance recursions -- k_cov_filter_sp16 /
+// k_cov_smoother_sp16: the per-series kernels' own code on a series of zeros -- into tables that stay in L2, and every series runs
+// only the mean recursions against them (k_mean_filter_sp16 / k_mean_smoother_sp16).  The arithmetic of every output element is
+// that of the per-series kernels, operation for operation (the same FMA chains, the same reduction orders, the MFMA for the
+// smoothed mean of a full step), including which steps they take in their steady-state form: the results are bit for bit
+// those of k_filter_sp16 / k_smoother_sp16 (tests/test_shared_cov_gpu.py).  A series that meets a missing observation is
+// marked in KArgs::route by the forward kernel and served by the per-series kernels launched behind.
+//
+// What a series-step costs is then its records: the state record is the table's C_t (S_t) with the mean patched into its
+// first d doubles, written as 16-byte pieces -- two store instructions per record.
+// ---------------------------------------------------------------------------------------
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2 buf_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  d2 o = {__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
+  return o;
+}
+__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, int voff, int soff, d2 x) {
+  const u4 v = {(unsigned)__double2loint(x[0]), (unsigned)__double2hiint(x[0]), (unsigned)__double2loint(x[1]), (unsigned)__double2hiint(x[1])};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
+
+// n16 <= 256 pieces of 16 bytes from byte offset soff of the buffer to LDS byte address lds_addr (see dma_record)
+__device__ __forceinline__ void dma_pieces(const i4& rs, unsigned lds_addr, int soff, int lane, int n16) {
+  const int voff = lane * 16;
+  lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  if (lane < n16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if (lane + 64 < n16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if (lane + 128 < n16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if (lane + 192 < n16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ d2 lds_read128(unsigned addr) {
+  d2 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+// the reads above are not counted by the compiler: these waits also tie the loaded registers to the wait, so that no use of
+// them can be scheduled ahead of it
+__device__ __forceinline__ void lds_wait(d2& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void lds_wait(d2& a, d2& b, d2& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory"); }
+__device__ __forceinline__ void lds_wait(d2& a, d2& b, double& c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory"); }
+__device__ __forceinline__ void lds_wait(d4& a, d4& b, d2& c, d2& e, double& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e), "+v"(f)::"memory");
+}
+
+// ---- four series per wave ------------------------------------------------------------------------------------------
+// A mean recursion is a d-vector: sixteen lanes.  Lane 16 j + c of a wave holds component c of series j (j = 0..3) of the wave's
+// four consecutive series; the row-wise DPP reductions and the gathers through LDS advance four series with the instructions of
+// one, one table row (LDS-DMA, two steps ahead) serves all four, and their four records leave as 16-byte pieces, six store
+// instructions for 4 x d (d + 1) / 2 pieces.
+__device__ __forceinline__ double row_lane0(double v, int lane) {   // every lane of a 16-lane row gets the value of the row's lane 0
+  const int a = (lane & 48) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_pick(double v, int lane, int src) {   // ... of the row's lane src (0..15, wave-uniform)
+  const int a = ((lane & 48) + src) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int MEAN4_LDS = 6 * 64;   // per wave: six vectors of 4 x 16 doubles
+constexpr int MEAN_AHEAD = 8;       // backward: the filtered means are requested this many steps ahead (512-byte slots)
+template <int NP>
+__device__ __forceinline__ void lds_wait_pieces(d2 (&pc)[NP]) {
+  if constexpr (NP == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3])::"memory");
+  else if constexpr (NP == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]), "+v"(pc[4]), "+v"(pc[5])::"memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]), "+v"(pc[4]), "+v"(pc[5]), "+v"(pc[6]), "+v"(pc[7])::"memory");
+}
+
+// Forward.  Table row r (tb.ftab, tb.frow bytes) = [C_r record | R_r F or K_r (16 doubles; [15] = +-1/Q_r)].
+// NP: store instructions per step = 64-lane groups of 16-byte pieces covering the four records (4, 6 or 8 for d <= 10, 13, 15)
+// REC: the filtered records are written here (dlm_filter_batch).  In the fused call (REC = false) only the means leave, compact --
+// tb.mc, 512 bytes per step and wave: [group of four series][T+1][4][16] -- and the backward kernel writes BOTH record streams
+// (it holds C_t anyway): the two passes' worth of stores in flight behind one wave, and no scattered re-read of the means.
+template <int K, int NP, int MODE>   // MODE 0: compact means only, 1: records only (dlm_filter_batch), 2: records and compact means (fused call)
+__global__ __launch_bounds__(256) void k_mean_filter_sp16(KArgs a, const SparseT* __restrict__ sp, CovTabs tb) {
+  constexpr bool REC = MODE != 0, CMP = MODE != 1;
+  constexpr int NS = (REC ? NP : 0) + (CMP ? 1 : 0);   // store instructions per step
+  __shared__ __attribute__((aligned(16))) double lds[4 * MEAN4_LDS];
+  extern __shared__ __attribute__((aligned(16))) char ring_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = 4 * (blockIdx.x * (int)(blockDim.x >> 6) + wave);   // first of this wave's four series
+  if (n0 >= a.N) return;
+  const int j = lane >> 4, c = lane & 15;
+  const int nser = a.N - n0 < 4 ? a.N - n0 : 4;
+  const bool have = j < nser;                       // this row has a series
+  const int n = have ? n0 + j : n0;                 // (a row without one shadows the first: loads stay in bounds, stores are dropped)
+  double* vM = lds + wave * MEAN4_LDS;   // m_col [4][16]
+  double* vW = vM + 64;                  // m_row
+  double* vA = vW + 64;                  // a_col (full steps)
+  double* vH = vA + 64;                  // the first 16 doubles of each series' record
+  const int d = a.d, T = a.T, rec = d + d * d, recb = rec * 8, frow = recb + 128;
+  const bool vc = c < d;
+  int idx[K];
+  double val[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { idx[s] = 16 * j + sp[0].idx[c][s]; val[s] = sp[0].val[c][s]; }
+  const double V = a.V[0];
+  const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+  const double* y = a.y + (size_t)n * T;
+  const size_t sbytes = (size_t)(T + 1) * recb;                      // one series' records
+  char* bout = REC ? (char*)a.filt + (size_t)n0 * sbytes : nullptr;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(bout, REC ? (size_t)nser * sbytes : 0);
+  const __amdgpu_buffer_rsrc_t rcmp = make_rsrc(CMP ? (char*)(tb.mc + (size_t)(n0 / 4) * (T + 1) * 64) : nullptr, CMP ? (size_t)(T + 1) * 512 : 0);
+  const int offmc = have ? lane * 8 : OOB;           // this lane's double of the wave's 512 compact bytes of a step
+  double* eqn = tb.eq + (size_t)n * (T + 1);
+  const double Fc = vc ? a.F[c] : 0.0;
+  double F4[4];                                      // F[(c & 3) + 4 k]: the full step's forecast sums rows 4 k + g' in this order
+#pragma unroll
+  for (int k = 0; k < 4; ++k) F4[k] = ((c & 3) + 4 * k < d) ? a.F[(c & 3) + 4 * k] : 0.0;
+  // the four records as 16-byte pieces: piece q = 64 k + lane is piece q % npc of series q / npc
+  const int npc = rec / 2;
+  unsigned psrc[NP];       // LDS byte offset of the piece inside a slot; bit 31: it lies in the record's first 16 doubles (taken from vH)
+  int pdst[NP], pser[NP];   // byte offset in the output, series
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int q = 64 * k + lane, sj = q / npc, pp = q - sj * npc;
+    pser[k] = sj;
+    pdst[k] = sj < nser ? (int)((size_t)sj * sbytes) + pp * 16 : OOB;
+    psrc[k] = pp < 8 ? (0x80000000u | (unsigned)((16 * (sj & 3) + 2 * pp) * 8)) : (unsigned)(pp * 16);
+  }
+  const unsigned vH_lds = lds_addr_of(vH);
+  char* ring = ring_all + wave * 2 * frow;
+  const unsigned ring_lds = lds_addr_of(ring);
+  const unsigned pkf = recb + c * 8, ptd = c * 8;   // K row entry, table double c (the record's first 16 doubles beyond the mean)
+  const i4 rtab = rsrc_words(tb.ftab, (unsigned)((size_t)(T + 1) * frow));
+  const int nrow = frow / 16;
+  dma_pieces(rtab, ring_lds, 0, lane, nrow);                    // row 0 -> slot 0
+  dma_pieces(rtab, ring_lds + frow, frow, lane, nrow);          // row 1 -> slot 1
+  // k_filter_sp16 carries the mean twice, as column 15 and as row 15 of its augmented tile, and a full step updates the two
+  // copies with differently associated products (m_col = a + (R F)(e / Q), m_row = a + (R F / Q) e) from each other's advance:
+  // a_col = G m_row, a_row = G m_col.  The record holds m_col.  Both are followed here (a steady step sets them equal).
+  double mcol = vc ? m0[c] : 0.0, mrow = mcol;
+  int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+  unsigned nsteady = 0;
+  bool dead = !have;                                 // row-uniform: the series met a missing observation (or there is none)
+  unsigned deadmask = (unsigned)(0xf << nser) & 0xf; // the same for all four rows, wave-uniform
+  vM[lane] = mcol; vW[lane] = mrow;
+  // observations: lane 16 j + c holds y_j[64 b + 16 k + c] in yk[k], refreshed every 64 steps
+  double yk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) yk[k] = (16 * k + c < T) ? y[16 * k + c] : 0.0;
+  asm volatile("" ::"v"(yk[0]), "v"(yk[1]), "v"(yk[2]), "v"(yk[3]));
+  double ek[4] = {__builtin_nan(""), 0.0, 0.0, 0.0};   // e / Q of records 64 b + 16 k + c (record 0: NaN), stored every 64 records
+  wave_sync();
+  vm_wait<1>();                                                 // row 0 (only the requests for row 1 may still be on their way)
+
+  auto store = [&](const d2 (&pc)[NP], int so) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) buf_store2(rout, ((deadmask >> pser[k]) & 1u) ? OOB : pdst[k], so, pc[k]);
+  };
+  if constexpr (REC) {   // record 0: [m0 | C0]
+    d2 pc[NP];
+    {
+      double td = lds_read64<0>(ring_lds + ptd);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(td)::"memory");
+      vH[lane] = vc ? mcol : td;
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < NP; ++k) pc[k] = lds_read128((psrc[k] & 0x80000000u) ? vH_lds + (psrc[k] & 0x7fffffffu) : ring_lds + psrc[k]);
+      lds_wait_pieces<NP>(pc);
+    }
+    dma_pieces(rtab, ring_lds, (T >= 2 ? 2 : T) * frow, lane, nrow);   // row 2 -> slot 0
+    store(pc, 0);
+  } else dma_pieces(rtab, ring_lds, (T >= 2 ? 2 : T) * frow, lane, nrow);   // row 2 -> slot 0
+  if constexpr (CMP) buf_store(rcmp, nullptr, offmc, 0, vc ? mcol : 0.0);
+  for (int t = 0; t < T; ++t) {
+    if (t > 0 && (t & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) yk[k] = (t + 16 * k + c < T) ? y[t + 16 * k + c] : 0.0;
+      asm volatile("" ::"v"(yk[0]), "v"(yk[1]), "v"(yk[2]), "v"(yk[3]));     // consume the loads inside the branch (see k_filter_sp16)
+    }
+    const int kk = (t >> 4) & 3;
+    const double yt = row_pick(kk == 0 ? yk[0] : kk == 1 ? yk[1] : kk == 2 ? yk[2] : yk[3], lane, t & 15);
+    if (!dead && !(yt == yt)) {   // a missing observation: this series' covariances are its own -- the per-series kernels take it (all of it)
+      dead = true;
+      if (c == 0) a.route[n] = 1;
+    }
+    deadmask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) deadmask |= (__builtin_amdgcn_readlane((int)dead, 16 * q) & 1) << q;
+    if (deadmask == 0xfu) break;
+    // Operations issued after the request for row t + 1: the NP stores of record t - 1, the request for row t + 2 (>= 1
+    // instruction), the NP stores of record t.  In the first step only the request for row 2 and the stores of record 0.
+    if (t == 0) vm_wait<NS + 1>(); else vm_wait<2 * NS + 1>();
+    const unsigned slot = ring_lds + ((t + 1) & 1) * frow;
+    double kfc = lds_read64<0>(slot + pkf);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kfc)::"memory");
+    const double rqs = uniform_from_lane(kfc, 15);        // +-1/Q_t rides in the row's last slot; negative: the step is a steady one
+    const double rq = fabs(rqs);
+    double ac = vW[idx[0]] * val[0];
+#pragma unroll
+    for (int s = 1; s < K; ++s) ac = fma(vW[idx[s]], val[s], ac);          // a_col = G m_row
+    double e, erq;
+    if (rqs < 0.0) {                                                       // steady step of k_filter_sp16: f by the row sum, m = a + K e
+      nsteady += 4 - __builtin_popcount(deadmask);
+      const double f = row_lane0(row_sum(Fc * ac), lane);
+      e = yt - f; erq = e * rq;
+      mcol = fma(kfc, e, ac);
+      mrow = mcol;
+    } else {                                                               // full step: f = (R F)[15] in ITS summation order
+      double ar = vM[idx[0]] * val[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) ar = fma(vM[idx[s]], val[s], ar);        // a_row = G m_col
+      vA[lane] = ac;
+      wave_sync();
+      double pf = 0.0;                                                     // rows g', g' + 4, g' + 8, g' + 12 (g' = c & 3) as one FMA chain ...
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pf = fma(vA[16 * j + (c & 3) + 4 * k], F4[k], pf);
+      pf = pf + quad_perm<0xB1>(pf);                                       // ... then (p0 + p1) + (p2 + p3), as the cross-row sum of k_filter_sp16 adds them
+      const double f = pf + quad_perm<0x4E>(pf);
+      e = yt - f; erq = e * rq;
+      mcol = fma(kfc, erq, ac);                                            // m_col = a_col + (R F)(e / Q)
+      mrow = fma(kfc * rq, e, ar);                                         // m_row = a_row + K e,  K = (R F) / Q
+    }
+    {   // e / Q of record t + 1 into its place of the 64-record chunk
+      const int k1 = ((t + 1) >> 4) & 3;
+      const bool mine = c == ((t + 1) & 15);
+      ek[0] = (mine && k1 == 0) ? erq : ek[0]; ek[1] = (mine && k1 == 1) ? erq : ek[1];
+      ek[2] = (mine && k1 == 2) ? erq : ek[2]; ek[3] = (mine && k1 == 3) ? erq : ek[3];
+      if (((t + 1) & 63) == 63 || t + 1 == T) {
+        const int base = (t + 1) & ~63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (!dead && base + 16 * k + c <= t + 1) eqn[base + 16 * k + c] = ek[k];
+      }
+    }
+    wave_sync();                                                           // the reads of vM, vW (and vA) precede their rewrite
+    vM[lane] = vc ? mcol : 0.0; vW[lane] = vc ? mrow : 0.0;
+    wave_sync();
+    if constexpr (REC) {
+      d2 pc[NP];
+      {
+        double td = lds_read64<0>(slot + ptd);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(td)::"memory");
+        vH[lane] = vc ? mcol : td;
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < NP; ++k) pc[k] = lds_read128((psrc[k] & 0x80000000u) ? vH_lds + (psrc[k] & 0x7fffffffu) : slot + psrc[k]);
+        lds_wait_pieces<NP>(pc);
+      }
+      { const int tn = t + 3 <= T ? t + 3 : T; dma_pieces(rtab, slot, tn * frow, lane, nrow); }   // the slot is free again: row t + 3
+      store(pc, (t + 1) * recb);
+    } else { const int tn = t + 3 <= T ? t + 3 : T; dma_pieces(rtab, slot, tn * frow, lane, nrow); }
+    if constexpr (CMP) buf_store(rcmp, nullptr, dead ? OOB : offmc, (t + 1) * 512, vc ? mcol : 0.0);
+  }
+  vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
+  if (have && !dead && c == 0) a.route[n] = 0;
+  if (a.counters && lane == 0) { atomicAdd(&a.counters[2], (unsigned long long)(4 - __builtin_popcount(deadmask))); if (nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady); }
+  const unsigned long long badl = __ballot(!dead && vc && !isfinite(mcol));
+  if (have && !dead && c == 0) {
+    const int sj = st | (((badl >> (16 * j)) & 0xffffull) ? DLM_ST_NONFINITE : 0);
+    if (a.status && sj) atomicOr(&a.status[n], sj);
+  }
+}
+
+// Backward.  Of table row t (tb.btab, tb.brow bytes: [S_t record | K_t (16 doubles; [15] = 1: steady step) | C_t record]) the K row
+// and C_t travel two steps ahead into a two-slot ring (they come from L2); the four series' filtered means m_t -- the forward
+// kernel's compact 512 bytes per step, from HBM -- MEAN_AHEAD steps ahead into a ring of their own.  Only the smoothed MEANS
+//
+// REC: the smoothed records are written here (the whole row travels, S_t leaves as 16-byte pieces with s_t patched in).  (REC = false
+// -- only the smoothed means leave, compact, for a separate fully parallel record-writer kernel -- was built and measured: the
+// writer reached 3.3 TB/s, no better than the stores of this kernel; profiles/r03_notes.md.)
+template <int K, int NP, bool REC>
+__global__ __launch_bounds__(256) void k_mean_smoother_sp16(KArgs a, const SparseT* __restrict__ sp, CovTabs tb) {
+  constexpr int NS = REC ? NP : 1;   // store instructions per step
+  __shared__ __attribute__((aligned(16))) double lds[4 * MEAN4_LDS];
+  extern __shared__ __attribute__((aligned(16))) char ring_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = 4 * (blockIdx.x * (int)(blockDim.x >> 6) + wave);
+  if (n0 >= a.N) return;
+  const int j = lane >> 4, c = lane & 15, g = j;
+  const int nser = a.N - n0 < 4 ? a.N - n0 : 4;
+  const bool have = j < nser;
+  const int n = have ? n0 + j : n0;
+  const bool dead = !have || a.route[n] != 0;       // a series with a missing observation: k_smoother_sp16 serves it
+  unsigned deadmask = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) deadmask |= (__builtin_amdgcn_readlane((int)dead, 16 * q) & 1) << q;
+  if (deadmask == 0xfu) return;
+  double* vQ = lds + wave * MEAN4_LDS;   // -q_t [4][16]
+  double* vR = vQ + 64;                  // r
+  double* vX = vR + 64;                  // C q products on their way from the column lanes to the series rows
+  double* vH = vX + 64;                  // REC: the first 16 doubles of each series' smoothed record
+  const int d = a.d, T = a.T, rec = d + d * d, recb = rec * 8, brow = 2 * recb + 128;
+  const int skip = REC ? 0 : recb;                  // bytes of a table row that do not travel (S_t when only the means leave)
+  const int part = brow - skip, slotb = part + 16;
+  const bool vc = c < d;
+  int idx[K];
+  double val[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { idx[s] = 16 * j + sp[1].idx[c][s]; val[s] = sp[1].val[c][s]; }
+  const double V = a.V[0];
+  const char* bin = (const char*)(tb.mc + (size_t)(n0 / 4) * (T + 1) * 64);    // the wave's compact filtered means: 512 bytes per step
+  const size_t sbytes = (size_t)(T + 1) * recb;
+  const __amdgpu_buffer_rsrc_t rout = REC ? make_rsrc((char*)a.smooth + (size_t)n0 * sbytes, (size_t)nser * sbytes)
+                                          : make_rsrc(tb.sc + (size_t)(n0 / 4) * (T + 1) * 64, (size_t)(T + 1) * 512);
+  const int offsc = dead ? OOB : lane * 8;
+  const int npc = rec / 2;
+  unsigned psrc[NP];
+  int pdst[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int q = 64 * k + lane, sj = q / npc, pp = q - sj * npc;
+    pdst[k] = (sj < nser && !((deadmask >> (sj & 3)) & 1u)) ? (int)((size_t)sj * sbytes) + pp * 16 : OOB;
+    psrc[k] = pp < 8 ? (0x80000000u | (unsigned)((16 * (sj & 3) + 2 * pp) * 8)) : (unsigned)(pp * 16);
+  }
+  const unsigned vH_lds = lds_addr_of(vH);
+  const double* eqn = tb.eq + (size_t)n * (T + 1);
+  const double Fc = vc ? a.F[c] : 0.0;
+  char* ring = ring_all + wave * (2 * slotb + MEAN_AHEAD * 512);
+  const unsigned ring_lds = lds_addr_of(ring), mring_lds = ring_lds + 2 * slotb;   // table slots, then the slots of the means
+  const unsigned pzero = part;                      // the zero double behind the slot's data (what the padded lanes read)
+  const unsigned pkb = recb - skip + c * 8, pmean = lane * 8, ptd = c * 8;     // a slot holds [(S_t record) | K row | C_t record]
+  unsigned pC[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int i = 4 * r + g; pC[r] = (i < d && vc) ? (unsigned)(recb - skip + 128 + (d + i * d + c) * 8) : pzero; }   // C_t[4r+g][c]
+  const i4 rtab = rsrc_words((const char*)tb.btab + skip, (unsigned)((size_t)(T + 1) * brow - skip));
+  const i4 rmean = rsrc_words(bin, (unsigned)((size_t)(T + 1) * 512));
+  const int nrow = part / 16;
+  const int mvoff = lane * 16;
+  const bool mact = lane < 32;
+  auto dma_means = [&](unsigned lds_addr, int soff) {
+    lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    if (mact) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(mvoff), "s"(rmean), "s"(soff) : "memory");
+  };
+  int st = (V > 0.0) ? 0 : DLM_ST_NOT_PD;
+  unsigned nsteady = 0;
+  double qcol = 0.0;
+  vQ[lane] = 0.0;
+  if (lane < 2) *(double*)(ring + lane * slotb + part) = 0.0;
+  wave_sync();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    // the means of steps T .. T - MEAN_AHEAD + 1 first (the oldest requests), then the table rows T and T - 1
+    for (int k = 0; k < MEAN_AHEAD; ++k) { const int tk = T - k > 0 ? T - k : 0; dma_means(mring_lds + ((T - k) & (MEAN_AHEAD - 1)) * 512, tk * 512); }
+    const int t1 = T > 0 ? T - 1 : 0;
+    dma_pieces(rtab, ring_lds + (T & 1) * slotb, T * brow, lane, nrow);
+    dma_pieces(rtab, ring_lds + (t1 & 1) * slotb, t1 * brow, lane, nrow);
+  }
+  double ek[4] = {0.0, 0.0, 0.0, 0.0};   // e / Q of records 64 b + 16 k + c of this row's series
+  double sm = 0.0;
+  for (int t = T; t >= 0; --t) {
+    if (t == T || (t & 63) == 63) {
+      const int base = t & ~63;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ek[k] = (base + 16 * k + c <= T) ? eqn[base + 16 * k + c] : 0.0;
+      asm volatile("" ::"v"(ek[0]), "v"(ek[1]), "v"(ek[2]), "v"(ek[3]));
+    }
+    const int kk = (t >> 4) & 3;
+    const double eq = row_pick(kk == 0 ? ek[0] : kk == 1 ? ek[1] : kk == 2 ? ek[2] : ek[3], lane, t & 15);
+    // Operations issued after the request for table row t: the means request and the store of step t + 2, the two requests of
+    // step t + 1 (>= 2 instructions) and its store.  The first two steps have fewer operations behind them.  The means of step t
+    // were requested MEAN_AHEAD steps ago: older than row t, complete with it.
+    if (t == T) vm_wait<1>(); else if (t == T - 1) vm_wait<NS + 2>(); else vm_wait<2 * NS + 3>();
+    const unsigned slot = ring_lds + (t & 1) * slotb, mslot = mring_lds + (t & (MEAN_AHEAD - 1)) * 512;
+    d4 cc;
+    cc[0] = lds_read64<0>(slot + pC[0]); cc[1] = lds_read64<0>(slot + pC[1]); cc[2] = lds_read64<0>(slot + pC[2]); cc[3] = lds_read64<0>(slot + pC[3]);
+    double mr = lds_read64<0>(mslot + pmean), kb = lds_read64<0>(slot + pkb), td = REC ? lds_read64<0>(slot + ptd) : 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cc), "+v"(mr), "+v"(kb), "+v"(td)::"memory");
+    if constexpr (!REC) {   // the slots are free again: table row t - 2, means t - MEAN_AHEAD (always issued: the operation count behind every request stays the same)
+      const int t2 = t > 1 ? t - 2 : 0, tm = t > MEAN_AHEAD ? t - MEAN_AHEAD : 0;
+      dma_pieces(rtab, slot, t2 * brow, lane, nrow);
+      dma_means(mslot, tm * 512);
+    }
+    const bool steady = uniform_from_lane(kb, 15) != 0.0;    // the step k_smoother_sp16 takes in its steady form
+    if (steady) {
+      // s_t = m_t + C_t q_t by column sums on the symmetric C_t (k_smoother_sp16's steady step), once per series
+      nsteady += 4 - __builtin_popcount(deadmask);
+      double pick = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double ncq = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ncq = fma(cc[r], vQ[16 * q + 4 * r + g], ncq);
+        ncq = sum_g(ncq);
+        pick = (j == q) ? ncq : pick;
+      }
+      sm = mr - pick;
+    } else {
+      // full step: the columns [ -q_0 | -q_1 | -q_2 | -q_3 ] of C_t [ . ] on the matrix pipe, as column 15 of [S | s] = [C | m] - C [P C | -q]
+      d4 b2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b2[r] = (c < 4) ? vQ[16 * c + 4 * r + g] : 0.0;
+      const d4 x2 = mmT(cc, b2);
+      wave_sync();                                           // (the reads of vX of the step before are done)
+      if (c < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vX[16 * c + 4 * r + g] = x2[r];
+      }
+      wave_sync();
+      sm = mr - vX[lane];
+    }
+    if (t > 0) {   // q_{t-1} = G^T [ q_t + F (e_t / Q_t - K_t . q_t) ]
+      const double kq = row_lane0(row_sum(kb * qcol), lane);
+      wave_sync();                                           // the reads of vQ above precede its rewrite below; vR's of the step before too
+      vR[lane] = fma(Fc, eq - kq, qcol);
+      wave_sync();
+      qcol = vR[idx[0]] * val[0];
+#pragma unroll
+      for (int s = 1; s < K; ++s) qcol = fma(vR[idx[s]], val[s], qcol);
+    } else wave_sync();
+    vQ[lane] = -qcol;
+    if constexpr (REC) {   // the four records: S_t of the table with s_t in the first d doubles
+      vH[lane] = vc ? sm : td;
+      wave_sync();
+      d2 pc[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) pc[k] = lds_read128((psrc[k] & 0x80000000u) ? vH_lds + (psrc[k] & 0x7fffffffu) : slot + psrc[k]);
+      lds_wait_pieces<NP>(pc);
+      {
+        const int t2 = t > 1 ? t - 2 : 0, tm = t > MEAN_AHEAD ? t - MEAN_AHEAD : 0;
+        dma_pieces(rtab, slot, t2 * brow, lane, nrow);
+        dma_means(mslot, tm * 512);
+      }
+      const int so = t * recb;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) buf_store2(rout, pdst[k], so, pc[k]);
+    } else {
+      wave_sync();
+      buf_store(rout, nullptr, offsc, t * 512, vc ? sm : 0.0);
+    }
+  }
+  vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
+  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[1], (unsigned long long)nsteady);
+  const unsigned long long badl = __ballot(!dead && vc && !isfinite(sm));
+  if (!dead && c == 0) {
+    const int sj = st | (((badl >> (16 * j)) & 0xffffull) ? DLM_ST_NONFINITE : 0);
+    if (a.status && sj) atomicOr(&a.status[n], sj);
+  }
+}
+
+size_t covtabs_doubles(int d, int T) { return (size_t)(T + 1) * (3 * (size_t)(d + d * d) + 16 + 16 + 2) + 64; }
+void covtabs_carve(double* base, int d, int T, CovTabs& t) {
+  const size_t rec = (size_t)(d + d * d), n1 = (size_t)T + 1;
+  t.frow = (int)(rec * 8 + 128); t.brow = (int)(2 * rec * 8 + 128);
+  t.ftab = base; t.btab = t.ftab + n1 * (rec + 16); t.cside = t.btab + n1 * (2 * rec + 16);
+}
+bool shared_cov_eligible(const KArgs& a) {
+  return a.d <= 15 && a.p == 1 && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !a.v_stride && !a.w_stride &&
+         !a.c0_stride && !a.packed && !a.prior && !a.fq && !a.loglik && a.filt && (a.flags & DLM_OPT_SHARED_COV) && !(a.flags & DLM_OPT_FORCE_GENERIC) &&
+         4 * ((size_t)a.T + 1) * (size_t)(a.d + a.d * a.d) * 8 < ((size_t)1 << 31);   // four series' records under one buffer resource
+}
+
+// ---------------------------------------------------------------------------------------
 // host side: structure detection and launch
 // ---------------------------------------------------------------------------------------
 // Nonzeros of the rows of G (`rows`, forward pass) and of the columns of G (`cols`, backward
@@ -1266,6 +1769,54 @@ hipError_t launch_sparse16_simsmooth(const KArgs& a, int K, const SparseT* tabs_
   }
   return hipErrorInvalidValue;
 }
+
+// ---- shared-covariance launches: the covariance-only runs take `a` with N = 1 and the tables as their record buffers ----------
+static KArgs cov_args(const KArgs& a, const CovTabs& tb) {
+  KArgs k = a;
+  k.N = 1; k.y = nullptr; k.status = nullptr; k.route = nullptr; k.counters = nullptr; k.loglik = nullptr; k.prior = nullptr; k.fq = nullptr;
+  k.filt = tb.ftab; k.filt_in = tb.ftab; k.smooth = tb.btab; k.packed = 0; k.m0_stride = 0;
+  return k;
+}
+template <int K>
+static hipError_t launch_cf(const KArgs& a, const SparseT* sp, const CovTabs& tb, hipStream_t s) {
+  hipLaunchKernelGGL((k_cov_filter_sp16<K>), dim3(1), dim3(64), 0, s, cov_args(a, tb), sp, tb.cside, tb.ftab + (a.d + a.d * a.d));
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_cs(const KArgs& a, const SparseT* sp, const CovTabs& tb, hipStream_t s) {
+  const size_t ring = 2 * ((size_t)(a.d + a.d * a.d) * 8 + 16);
+  hipLaunchKernelGGL((k_cov_smoother_sp16<K>), dim3(1), dim3(64), ring, s, cov_args(a, tb), sp, (const double*)tb.cside, tb.btab);
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_mf(const KArgs& a, const SparseT* sp, const CovTabs& tb, hipStream_t s) {
+  const int wpb = a.N < 8192 ? 1 : 4, nw = (a.N + 3) / 4;   // four series per wave
+  const dim3 grid((nw + wpb - 1) / wpb), blk(64 * wpb);
+  const size_t ring = (size_t)wpb * 2 * tb.frow;
+#define DLM_MF(MODE) { if (a.d <= 10) hipLaunchKernelGGL((k_mean_filter_sp16<K, 4, MODE>), grid, blk, ring, s, a, sp, tb); \
+                      else if (a.d <= 13) hipLaunchKernelGGL((k_mean_filter_sp16<K, 6, MODE>), grid, blk, ring, s, a, sp, tb); \
+                      else hipLaunchKernelGGL((k_mean_filter_sp16<K, 8, MODE>), grid, blk, ring, s, a, sp, tb); }
+  if (tb.mc) DLM_MF(2)                   // fused call: records, and compact means for the backward kernel
+  else DLM_MF(1)                         // dlm_filter_batch: records only
+#undef DLM_MF
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_ms(const KArgs& a, const SparseT* sp, const CovTabs& tb, hipStream_t s) {
+  const int wpb = a.N < 8192 ? 1 : 4, nw = (a.N + 3) / 4;
+  const dim3 grid((nw + wpb - 1) / wpb), blk(64 * wpb);
+  const size_t ring = (size_t)wpb * (2 * ((size_t)tb.brow + 16) + MEAN_AHEAD * 512);
+  if (a.d <= 10) hipLaunchKernelGGL((k_mean_smoother_sp16<K, 4, true>), grid, blk, ring, s, a, sp, tb);
+  else if (a.d <= 13) hipLaunchKernelGGL((k_mean_smoother_sp16<K, 6, true>), grid, blk, ring, s, a, sp, tb);
+  else hipLaunchKernelGGL((k_mean_smoother_sp16<K, 8, true>), grid, blk, ring, s, a, sp, tb);
+  return hipGetLastError();
+}
+#define DLM_K_SWITCH(fn, ...) switch (K) { case 1: return fn<1>(__VA_ARGS__); case 2: return fn<2>(__VA_ARGS__); case 3: return fn<3>(__VA_ARGS__); case 4: return fn<4>(__VA_ARGS__); } return hipErrorInvalidValue;
+hipError_t launch_sparse16_cov_filter(const KArgs& a, int K, const SparseT* rows_dev, const CovTabs& tabs, hipStream_t s) { DLM_K_SWITCH(launch_cf, a, rows_dev, tabs, s) }
+hipError_t launch_sparse16_cov_smoother(const KArgs& a, int K, const SparseT* cols_dev, const CovTabs& tabs, hipStream_t s) { DLM_K_SWITCH(launch_cs, a, cols_dev, tabs, s) }
+hipError_t launch_sparse16_mean_filter(const KArgs& a, int K, const SparseT* rows_dev, const CovTabs& tabs, hipStream_t s) { DLM_K_SWITCH(launch_mf, a, rows_dev, tabs, s) }
+hipError_t launch_sparse16_mean_smoother(const KArgs& a, int K, const SparseT* cols_dev, const CovTabs& tabs, hipStream_t s) { DLM_K_SWITCH(launch_ms, a, cols_dev, tabs, s) }
+#undef DLM_K_SWITCH
 
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s) {
   switch (K) {

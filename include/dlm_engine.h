@@ -74,7 +74,11 @@ enum {
   DLM_OPT_NO_SPARSE_F = 1u << 20,       /* treat F as dense                                                            */
   DLM_OPT_NO_SMALL_BATCH = 1u << 21,    /* d <= 15: the throughput kernels also for batches that leave SIMDs idle      */
   DLM_OPT_NO_STEADY = 1u << 22,         /* d <= 15: every step recomputes the covariance recursion, also once it has settled */
-  DLM_OPT_NO_PIPE = 1u << 23            /* d <= 15, small batches: the output product's MFMAs in one block (as at full occupancy) */
+  DLM_OPT_NO_PIPE = 1u << 23,           /* d <= 15, small batches: the output product's MFMAs in one block (as at full occupancy) */
+  DLM_OPT_SHARED_COV = 1u << 24         /* d <= 15, p = 1, regular grid, V, W, C0 shared by the batch: ONE wave runs the covariance recursions, every series
+                                           only its mean recursions against their tables; a series with a missing observation runs its own recursion
+                                           as always.  Bit for bit the results of the default kernels (tests/test_shared_cov_gpu.py) -- and, measured,
+                                           no faster than them: opt-in (profiles/r03_notes.md) */
 };
 
 /* per-series status bits */

@@ -21,7 +21,11 @@ class _Eng:
     """The engine on one of its two kernel families for 16 <= d <= 48: "workgroup" (DLM_OPT_NO_WAVE: the workgroup-per-series
     kernels, which production takes for up to 256 series of a model that is not time-invariant) or "per-wave"
     (DLM_OPT_FORCE_WAVE: the wave-per-series kernels, which production takes otherwise).  Every test of this module runs under
-    both; test_dispatch_rule_of_the_multivariate_kernels checks which one production picks."""
+    both; test_dispatch_rule_of_the_multivariate_kernels checks which one production picks.
+
+    Since round 3 the "per-wave" run also turns on the opt-in shared-covariance kernels (DLM_OPT_SHARED_COV) for d <= 15, so that
+    every test of this module exercises them where they are eligible; tests/test_shared_cov_gpu.py compares them with the default
+    kernels bit for bit."""
 
     def __init__(self, engine, rule):
         self._e, self.rule, self._d = engine, rule, 0
@@ -37,6 +41,8 @@ class _Eng:
                 kw["flags"] = kw.get("flags", 0) | _lib.OPT_FORCE_WAVE
             elif mat.d >= 16 and not (kw.get("flags", 0) & _lib.OPT_FORCE_WAVE):
                 kw["flags"] = kw.get("flags", 0) | _lib.OPT_NO_WAVE
+            if self.rule == "per-wave" and mat.d <= 15:
+                kw["flags"] = kw.get("flags", 0) | _lib.OPT_SHARED_COV
             return attr(mat, *a, **kw)
         return call
 
