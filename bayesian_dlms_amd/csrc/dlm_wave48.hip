@@ -29,6 +29,15 @@
 
 namespace dlm {
 namespace w48 {
+// The convergence test of the steady-state shortcut (dlm_internal.h: settle_test) as a REAL call: these kernels live at the
+// 512-register limit, and inlined the few dozen instructions of the test changed the allocator's choices for the whole kernel
+// (k_smoother_w48<3, 2, 2, 1>: 6 -> 296 spilled registers, C4 18.7 -> 23.2 ms, 64 -> 121 ms without the shortcut).
+__device__ __attribute__((noinline)) bool settle_eval(float* st, double dmax, double smax, bool reset) {
+  if (reset) settle_reset(st);
+  const double sc = settle_pow2_inverse_of(smax);
+  return settle_test(st, (float)(dmax * sc), (float)(smax * sc), 4);
+}
+
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -635,6 +644,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
   wave_sync();
   settle_reset(settle);
   unsigned nsteady = 0;                       // steady steps taken (KArgs::counters[0])
+  bool sreset = false;                        // the convergence test starts over at its next evaluation
 
   for (int t = 0; t < T; ++t) {
     // opaque copies of the lane coordinates: the compiler would otherwise hoist the few dozen address computations of
@@ -712,7 +722,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
       if (t >= T) break;     // (otherwise: step t, whose observation is in ycur, takes the full path below)
     }
     steady = false;
-    if (!all) settle_reset(settle);             // a missing component disturbs the covariance: the convergence test starts over
+    if (!all) sreset = true;                    // a missing component disturbs the covariance: the convergence test starts over
     if (marks && lane == 0) marks[t + 1] = 0;
 
     // ---- advance: a = G m, R = G C G^T + W dt (into C's registers), dt == 0: identity
@@ -901,8 +911,9 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
               dmax = fmax(dmax, settle_absdiff(C[aa][b][r], old)); cmax = fmax(cmax, fabs(C[aa][b][r]));
             }
         for (int o_ = 32; o_ > 0; o_ >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o_)); cmax = fmax(cmax, __shfl_xor(cmax, o_)); }
-        const double sc = settle_pow2_inverse_of(cmax);
-        if (settle_test(settle, (float)(dmax * sc), (float)(cmax * sc), 4)) {   // the geometric tail of the changes within DLM_SETTLE_TOL max|C| (a scalar flag)
+        const bool settled = settle_eval(settle, dmax, cmax, sreset);   // the geometric tail of the changes within DLM_SETTLE_TOL max|C| (a scalar flag)
+        sreset = false;
+        if (settled) {
           steady = true;
           wave_sync();
           to_image<IL, PT, DT>(KT, img, g, c);                      // K^T for the steady steps
@@ -1057,6 +1068,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
   wave_sync();
   settle_reset(settle);
   unsigned nsteady = 0;                       // steady steps taken (KArgs::counters[1])
+  bool sreset = false;                        // the convergence test starts over at its next evaluation
   int mk_cur = can_steady ? marks[T] : 0;
 
   for (int t = T; t >= 0; --t) {
@@ -1157,7 +1169,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
     }
     }
     smode = false;
-    if (!(inherit && allobs)) { psteady = false; settle_reset(settle); }
+    if (!(inherit && allobs)) { psteady = false; sreset = true; }
 
     d4 Kg[DT][PT];
     if (any) {
@@ -1409,8 +1421,8 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
             dmax = fmax(dmax, settle_absdiff(P[aa][b][r], old)); pmax = fmax(pmax, fabs(P[aa][b][r]));
           }
       for (int o_ = 32; o_ > 0; o_ >>= 1) { dmax = fmax(dmax, __shfl_xor(dmax, o_)); pmax = fmax(pmax, __shfl_xor(pmax, o_)); }
-      const double sc = settle_pow2_inverse_of(pmax);
-      psteady = settle_test(settle, (float)(dmax * sc), (float)(pmax * sc), 4);   // the geometric tail of the changes within DLM_SETTLE_TOL max|P|
+      psteady = settle_eval(settle, dmax, pmax, sreset);   // the geometric tail of the changes within DLM_SETTLE_TOL max|P|
+      sreset = false;
     }
     if (can_steady && psteady && inherit && allobs && mk) {   // the next step can be a steady one: S_t (stored above) into the image
       wave_sync();

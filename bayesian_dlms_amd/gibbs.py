@@ -94,6 +94,7 @@ class GibbsState:
     p: object
     theta: Optional[np.ndarray]
     stats: np.ndarray
+    status: Optional[object] = None     # per-series status flags of this iteration's FFBS call (DLM_ST_*), as the engine returned them
 
 
 def _params_list(p, N):
@@ -218,4 +219,4 @@ def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, p
                     w = np.diag(draw_w_diag(prior_w, body[k], tcount[k], r))
                 new.append(DlmParameters(v, w, old[k].m0, old[k].c0))
             params = new
-        yield GibbsState(params, (out["theta"] if on_device else np.asarray(out["theta"])) if keep_theta else None, stats)
+        yield GibbsState(params, (out["theta"] if on_device else np.asarray(out["theta"])) if keep_theta else None, stats, out.get("status"))

@@ -273,3 +273,8 @@ def filter_smooth_batch(N, M, V, W, m0, C0, y, want_out=True):
     bad = lib().oracle_filter_smooth_batch(N, d, p, T, _p(M.F), _p(M.G), _p(V), _p(W), _p(m0), _p(C0),
                                            _p(y), _p(filt), _p(sm))
     return filt, sm, bad
+
+
+def set_threads(n=0):
+    """OpenMP threads of filter_smooth_batch (0: leave as is); returns the number in force."""
+    return int(lib().oracle_set_threads(int(n)))
