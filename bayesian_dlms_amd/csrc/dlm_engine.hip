@@ -423,6 +423,14 @@ int packed_path(dlm_engine* e, KArgs& k) {
 bool use_shared_cov(const dlm_engine* e, const KArgs& k) {
   return fast_shape_ok(k) && e->sparse_k > 0 && !dlm::lane_supported(k) && dlm::shared_cov_eligible(k);
 }
+int ensure_route(dlm_engine* e, size_t N) {
+  if (N > e->route_bytes) {
+    if (e->route) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->route)); e->route = nullptr; e->route_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->route, N));
+    e->route_bytes = N;
+  }
+  return DLM_OK;
+}
 int ensure_xplus_bytes(dlm_engine* e, size_t need) {
   if (need > e->xplus_bytes) {
     if (e->xplus) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
@@ -438,12 +446,9 @@ int ensure_shared(dlm_engine* e, const KArgs& k, dlm::CovTabs& tb, bool with_bac
     HIP_TRY(e, hipMalloc((void**)&e->covws, need));
     e->covws_bytes = need;
   }
-  if ((size_t)k.N > e->route_bytes) {
-    if (e->route) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->route)); e->route = nullptr; e->route_bytes = 0; }
-    HIP_TRY(e, hipMalloc((void**)&e->route, (size_t)k.N));
-    e->route_bytes = (size_t)k.N;
-  }
-  int rc = ensure_side(e, k);
+  int rc = ensure_route(e, (size_t)k.N);
+  if (rc) return rc;
+  rc = ensure_side(e, k);
   if (rc) return rc;
   if (!e->cov_stream) {
     HIP_TRY(e, hipStreamCreateWithFlags(&e->cov_stream, hipStreamNonBlocking));
@@ -1106,7 +1111,18 @@ int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
   e->variant = "svd-jacobi";
   if ((rc = want_counters(e, k))) return rc;
   if ((rc = mark(e, 0))) return rc;
-  HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
+  if (dlm::svd_shared_eligible(k)) {
+    // parameters shared by the batch: the decompositions once per call (one wave), a mean-only kernel per series; a series with a
+    // missing observation runs k_svd_filter as always
+    if ((rc = ensure_route(e, (size_t)k.N))) return rc;
+    const size_t need = sizeof(double) * dlm::svd_shared_ws_doubles(k);
+    if (need > e->covws_bytes) {
+      if (e->covws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->covws)); e->covws = nullptr; e->covws_bytes = 0; }
+      HIP_TRY(e, hipMalloc((void**)&e->covws, need));
+      e->covws_bytes = need;
+    }
+    HIP_TRY(e, dlm::launch_svd_filter_shared(k, rec_dev, e->covws, e->route, e->stream));
+  } else HIP_TRY(e, dlm::launch_svd_filter(k, rec_dev, e->stream));
   if ((rc = mark(e, 1)) || (rc = mark(e, 2))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }

@@ -141,6 +141,10 @@ hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, 
 size_t svd_filter_lds_bytes(int d, int p);
 hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s);
 hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s);
+// shared factors (parameters shared by the batch, no missing observation): the decompositions once per call, a mean-only kernel per series
+bool svd_shared_eligible(const KArgs& a);
+size_t svd_shared_ws_doubles(const KArgs& a);
+hipError_t launch_svd_filter_shared(const KArgs& a, double* svd_rec, double* ws, unsigned char* route, hipStream_t s);
 
 // ---- one lane per series for d <= 3, p = 1 (dlm_lane.hip): filter (+ prior / forecast records, log-likelihood), RTS smoother
 bool lane_supported(const KArgs& a);

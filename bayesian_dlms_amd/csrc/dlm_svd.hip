@@ -355,10 +355,13 @@ size_t svd_sampler_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 1
 // ---------------------------------------------------------------------------------------
 // SVD filter.  Record t: [m_t (d) | dc_t (d) | uc_t (d x d, column-major)].
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restrict__ rec_out) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
+// rec_stride (doubles, 0: 2 d + d^2) / aux: the covariance-only run of the shared-factor path (k_svd_mean_filter below) writes its
+// records as padded table rows and leaves sqrt(V)^-1[0][0] in aux[0].
+__global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restrict__ rec_out, int rec_stride, double* __restrict__ aux) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
-  const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = 2 * d + dd;
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = rec_stride ? rec_stride : 2 * d + dd;
+  if (a.route && (a.route[n] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
   SvdLds L = carve_filter(sm, d, p);
   double* stack = L.stack;
   const int stl = svd_filter_stl(d, p);
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
     ssync();
   } else if (sqrt_svd(lane, d, W, false, L.Wadv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
   if (sqrt_svd(lane, p, V, true, L.sVinv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (aux && lane == 0) aux[0] = M17(L.sVinv, 0, 0);
   // initialiseState (SvdFilter.scala:83-95): svd(C0) -> dc0 = sqrt(sigma), uc0 = V
   for (int k = lane; k < dd; k += 64) STK(k % d, k / d) = C0[k];
   ssync();
@@ -593,7 +597,185 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
   for (int i = lane; i < d; i += 64) bad |= !isfinite(L.m[i]) || !isfinite(L.dc[i]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
-  if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
+  if (a.counters && lane == 0) {
+    if (nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
+    if (a.route) atomicAdd(&a.counters[3], 1ull);          // a series of a shared-factor call that ran its own decompositions
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Shared factors.  With V, W, C0 shared by the batch and no missing observation the factors (uc_t, dc_t) of the SVD filter do
+// not depend on the data: the two decompositions per step -- all of this filter's cost -- are done ONCE per call, by k_svd_filter
+// itself on a series of zeros (one wave: its records are the table), and every series runs only
+//   a = G m,  e = y - F^T a,  m = a + uc dc^2 uc^T F (sqrt(V)^-1)^2 e          (SvdFilter.scala:58-66)
+// with the operations and their order exactly those of k_svd_filter: the records are bit for bit its own.  A series with a
+// missing observation is marked in KArgs::route and served by k_svd_filter (p = 1, regular grid, time-invariant model).
+// One wave per series; table row t + 1 ([0 | dc | uc], padded to a multiple of 16 bytes) travels two steps ahead into an LDS ring.
+// ---------------------------------------------------------------------------------------
+typedef int i4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void svd_dma_row(const i4s& rs, unsigned lds_addr, int soff, int lane, int n16) {
+  const int voff = lane * 16;
+  lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  if (lane < n16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if (lane + 64 < n16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if (lane + 128 < n16)   // (d = 16: 144 pieces)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__global__ __launch_bounds__(256) void k_svd_mean_filter(KArgs a, const double* __restrict__ tab, int tstride, const double* __restrict__ aux,
+                                                         const int* __restrict__ cov_status, double* __restrict__ rec_out) {
+  extern __shared__ __attribute__((aligned(16))) char ring_all[];
+  __shared__ __attribute__((aligned(16))) double lds[4 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+  if (n >= a.N) return;
+  const int d = a.d, T = a.T, dd = d * d, srec = 2 * d + dd, rowb = tstride * 8;
+  double* vM = lds + wave * 64;   // m
+  double* vA = vM + 16;           // a
+  double* vG = vA + 16;           // gs, then yv
+  const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+  const double* y = a.y + (size_t)n * T;
+  double* out = rec_out + (size_t)n * (T + 1) * srec;
+  const int OOBo = 0x7ffffff0;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)(T + 1) * srec * 8), 0x00020000);
+  // G and F in registers: lane i holds row i of G and F[i] (d <= 16)
+  double Gi[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Gi[k] = (lane < d && k < d) ? a.G[lane + k * d] : 0.0;
+  const double s00 = aux[0];
+  const double vv = fma(s00, s00, 0.0);               // (vm^T vm)[0][0]
+  const double Fl = lane < d ? a.F[lane] : 0.0;
+  double* vF = vG + 16;                               // F
+  if (lane < 16) vF[lane] = Fl;
+  char* ring = ring_all + wave * 2 * (rowb + 16);
+  const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+  const unsigned long long ta = (unsigned long long)tab;
+  const i4s rtab = {__builtin_amdgcn_readfirstlane((int)(unsigned)ta), __builtin_amdgcn_readfirstlane((int)(unsigned)((ta >> 32) & 0xffffu)),
+                    __builtin_amdgcn_readfirstlane((int)((size_t)(T + 1) * rowb)), 0x00020000};
+  const int n16 = rowb / 16;
+  int offp[5];          // this lane's doubles of a record: lane, lane + 64, ... (2 d + d^2 <= 288)
+#pragma unroll
+  for (int k = 0; k < 5; ++k) offp[k] = (lane + 64 * k < srec) ? (lane + 64 * k) * 8 : OOBo;
+  svd_dma_row(rtab, ring_lds, 0, lane, n16);
+  svd_dma_row(rtab, ring_lds + rowb + 16, rowb, lane, n16);
+  double mi = lane < d ? m0[lane] : 0.0;
+  if (lane < 16) vM[lane] = mi;
+  double ychunk = (lane < T) ? y[lane] : 0.0;
+  asm volatile("" ::"v"(ychunk));
+  ssync();
+  asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // row 0
+  {   // record 0: [m0 | dc0 | uc0]
+    const double* row = (const double*)ring;
+    double v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = (lane + 64 * k < srec) ? row[lane + 64 * k] : 0.0;
+    v[0] = lane < d ? mi : v[0];
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
+    svd_dma_row(rtab, ring_lds, (T >= 2 ? 2 : T) * rowb, lane, n16);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const unsigned lo = (unsigned)__double2loint(v[k]), hi = (unsigned)__double2hiint(v[k]);
+      const unsigned __attribute__((ext_vector_type(2))) w = {lo, hi};
+      __builtin_amdgcn_raw_buffer_store_b64(w, rout, offp[k], 0, 0);
+    }
+  }
+  for (int t = 0; t < T; ++t) {
+    if (t > 0 && (t & 63) == 0) {
+      ychunk = (t + lane < T) ? y[t + lane] : 0.0;
+      asm volatile("" ::"v"(ychunk));
+    }
+    const double yt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ychunk), t & 63), __builtin_amdgcn_readlane(__double2loint(ychunk), t & 63));
+    if (!(yt == yt)) {   // a missing observation: the factors of this series are its own -- k_svd_filter takes it
+      if (lane == 0) a.route[n] = 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+    // operations issued after the request for row t + 1: the 5 stores of record t - 1, the request for row t + 2 (>= 1), the 5 stores of record t
+    if (t == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    const double* row = (const double*)(ring + ((t + 1) & 1) * (rowb + 16));
+    // a = G m
+    double ai = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < d) ai = fma(Gi[k], vM[k], ai);
+    if (lane < 16) vA[lane] = lane < d ? ai : 0.0;
+    ssync();
+    double fs = 0.0;
+    for (int k = 0; k < d; ++k) fs = fma(vF[k], vA[k], fs);
+    const double e = yt - fs;
+    const double tv = fma(vv, e, 0.0);
+    if (lane < 16) vG[lane] = lane < d ? fma(Fl, tv, 0.0) : 0.0;              // gs = F tv
+    ssync();
+    double yv = 0.0;
+    if (lane < d) {
+      double s_ = 0.0;
+      for (int l = 0; l < d; ++l) s_ = fma(row[2 * d + l + lane * d], vG[l], s_);   // uc[l][i]
+      const double dci = row[d + lane];
+      yv = dci * dci * s_;
+    }
+    ssync();
+    if (lane < 16) vG[lane] = lane < d ? yv : 0.0;
+    ssync();
+    if (lane < d) {
+      double s_ = ai;
+      for (int l = 0; l < d; ++l) s_ = fma(row[2 * d + lane + l * d], vG[l], s_);   // uc[i][l]
+      mi = s_;
+    }
+    ssync();
+    if (lane < 16) vM[lane] = lane < d ? mi : 0.0;
+    ssync();
+    double v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = (lane + 64 * k < srec) ? row[lane + 64 * k] : 0.0;
+    v[0] = lane < d ? mi : v[0];
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
+    { const int tn = t + 3 <= T ? t + 3 : T; svd_dma_row(rtab, ring_lds + ((t + 1) & 1) * (rowb + 16), tn * rowb, lane, n16); }
+    const int so = (t + 1) * srec * 8;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const unsigned lo = (unsigned)__double2loint(v[k]), hi = (unsigned)__double2hiint(v[k]);
+      const unsigned __attribute__((ext_vector_type(2))) w = {lo, hi};
+      __builtin_amdgcn_raw_buffer_store_b64(w, rout, offp[k], so, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) a.route[n] = 0;
+  if (a.counters && lane == 0) atomicAdd(&a.counters[2], 1ull);
+  int st = cov_status[0];
+  if (__ballot(lane < d && !isfinite(mi)) != 0ull) st |= DLM_ST_NONFINITE;
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+bool svd_shared_eligible(const KArgs& a) {
+  return a.d <= 16 && a.p == 1 && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !a.v_stride && !a.w_stride && !a.c0_stride &&
+         !(a.flags & (DLM_OPT_SVD_PER_SERIES | DLM_OPT_FORCE_GENERIC));
+}
+size_t svd_shared_ws_doubles(const KArgs& a) { return (size_t)(a.T + 1) * (size_t)((2 * a.d + a.d * a.d + 1) & ~1) + (size_t)a.T + 64; }
+// ws: svd_shared_ws_doubles(a) doubles; route: [N] bytes
+hipError_t launch_svd_filter_shared(const KArgs& a, double* svd_rec, double* ws, unsigned char* route, hipStream_t s) {
+  const int d = a.d, srec = 2 * d + d * d, tstride = (srec + 1) & ~1;
+  double* tab = ws;
+  double* zeros = tab + (size_t)(a.T + 1) * tstride;      // [T] zero observations, then: aux, the covariance-only run's status
+  double* aux = zeros + a.T;
+  int* cst = (int*)(aux + 8);
+  hipError_t err = hipMemsetAsync(zeros, 0, sizeof(double) * ((size_t)a.T + 16), s);
+  if (err != hipSuccess) return err;
+  KArgs kc = a;
+  kc.N = 1; kc.y = zeros; kc.m0 = zeros; kc.m0_stride = 0; kc.status = cst; kc.counters = nullptr; kc.route = nullptr;
+  hipLaunchKernelGGL(k_svd_filter, dim3(1), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kc, tab, tstride, aux);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  KArgs km = a;
+  km.route = route; km.route_take = 0;
+  const int wpb = 4;
+  hipLaunchKernelGGL(k_svd_mean_filter, dim3((a.N + wpb - 1) / wpb), dim3(64 * wpb), (size_t)wpb * 2 * (tstride * 8 + 16), s, km, (const double*)tab, tstride,
+                     (const double*)aux, (const int*)cst, svd_rec);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  KArgs kg = a;
+  kg.route = route; kg.route_take = 1;
+  hipLaunchKernelGGL(k_svd_filter, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kg, svd_rec, 0, (double*)nullptr);
+  return hipGetLastError();
 }
 
 // canonical factor: columns of U (d x d, LDS ld SL) and entries of s reordered so that the
@@ -774,7 +956,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
 
 hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s) {
   if (a.d > 16 || a.p > 16) return hipErrorNotSupported;
-  hipLaunchKernelGGL(k_svd_filter, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec);
+  hipLaunchKernelGGL(k_svd_filter, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec, 0, (double*)nullptr);
   return hipGetLastError();
 }
 

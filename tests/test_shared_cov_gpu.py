@@ -177,3 +177,64 @@ def test_device_resident_call_and_what_falls_back(eng):
     mi = materialise(Dlm.polynomial(1) + Dlm.seasonal(24, 6), np.cumsum(np.array([1.0, 2.0, 1.0] * 40)))
     out = eng.filter_smooth(mi, p, y, flags=_lib.OPT_SHARED_COV | _lib.OPT_COUNT_STEPS)   # an irregular grid: per-series kernels (for now)
     assert eng.last_counters()[2] == 0 and np.all(out["status"] == 0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# SVD filter: shared factors (on by default where the batch shares V, W, C0; DLM_OPT_SVD_PER_SERIES turns it off)
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,N", [(600, 9), (1, 3), (2, 5), (65, 4), (130, 70)])
+def test_svd_filter_shared_factors_bit_for_bit(eng, T, N):
+    """The decompositions of the SVD filter once per call (k_svd_filter on a series of zeros) and a mean-only kernel per series:
+    the records [m | dc | uc] bit for bit those of k_svd_filter run per series (SvdFilter.scala:38-95, :183-202), series with a
+    missing observation routed to it; the covariance U D^2 U^T against the oracle's Kalman filter (1e-7, the path's tolerance)."""
+    mat, p = c2(T)
+    rng = np.random.default_rng(100 + T)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    if N > 3:
+        y[1, T // 2, 0] = np.nan
+        y[3, 0, 0] = np.nan
+    sh = eng.svd_filter(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
+    cnt = eng.last_counters()
+    ps = eng.svd_filter(mat, p, y, flags=_lib.OPT_SVD_PER_SERIES | _lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2:] == (0, 0)
+    ngap = 2 if N > 3 else 0
+    assert cnt[2] == N - ngap and cnt[3] == ngap, cnt
+    assert np.array_equal(sh["svd"], ps["svd"], equal_nan=True)
+    assert np.array_equal(sh["status"], ps["status"]) and np.all(sh["status"] == 0)
+    n = N - 1
+    kf = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n])
+    rec = sh["svd"][n]
+    m, dc, U = rec[:, :13], rec[:, 13:26], rec[:, 26:].reshape(-1, 13, 13).transpose(0, 2, 1)
+    C = np.einsum("tij,tj,tkj->tik", U, dc * dc, U)
+    Co = kf["C"].reshape(T + 1, 13, 13).transpose(0, 2, 1)
+    assert (np.abs(C - Co) / np.abs(Co).max(axis=(1, 2), keepdims=True)).max() <= 1e-7
+    assert np.abs(m - kf["m"]).max() <= 1e-7 * max(1.0, np.abs(kf["m"]).max())
+
+
+def test_svd_shared_factors_other_shapes_and_fallbacks(eng):
+    rng = np.random.default_rng(7)
+    for d in (2, 7, 16):
+        T = 90
+        Gm = 0.8 * np.eye(d) + 0.15 * np.eye(d, k=1)
+        Fv = rng.standard_normal((d, 1))
+        mat = materialise(Dlm(lambda t: Fv, lambda dt: Gm), np.arange(1, T + 1, dtype=np.float64))
+        A = rng.standard_normal((d, d))
+        p = DlmParameters([[0.9]], A @ A.T / d + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d) * 2)
+        y = rng.standard_normal((6, T, 1)).cumsum(axis=1)
+        sh = eng.svd_filter(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
+        assert eng.last_counters()[2] == 6
+        ps = eng.svd_filter(mat, p, y, flags=_lib.OPT_SVD_PER_SERIES)
+        assert np.array_equal(sh["svd"], ps["svd"])
+    # per-series parameters, or the literal raw-W quirk with shared ones: the first falls back, the second shares
+    mat, p = c2(50)
+    y = rng.standard_normal((4, 50, 1))
+    eng.svd_filter(mat, [p] * 4, y, flags=_lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2] == 0
+    a = eng.svd_filter(mat, p, y, flags=_lib.OPT_SVD_RAW_W_Q2 | _lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2] == 4
+    b = eng.svd_filter(mat, p, y, flags=_lib.OPT_SVD_RAW_W_Q2 | _lib.OPT_SVD_PER_SERIES)
+    assert np.array_equal(a["svd"], b["svd"])
+    # the FFBS entry point (its forward half is the per-series kernel: unchanged)
+    z = rng.standard_normal((4, 51, 13))
+    f1 = eng.svd_ffbs(mat, p, y, z=z)
+    assert np.all(np.isfinite(f1["theta"]))
