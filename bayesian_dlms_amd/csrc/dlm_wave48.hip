@@ -2302,8 +2302,8 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
 // The per-wave kernels take the structured-G models; a dense G stays on dlm_tiled.hip.
 // One wave per series needs more series than the chip has SIMDs to pay off: up to one series per CU (N <= 256) the
 // workgroup-per-series kernels of dlm_tiled.hip finish a step sooner (10.8 against 13 us at d = 40, p = 20).
-// DLM_NO_WAVE48 in the environment sends everything to dlm_tiled.hip, DLM_FORCE_WAVE48 lifts the batch-size rule (A/B
-// measurements and the parity tests of the two paths).
+// dlm_options.flags: DLM_OPT_NO_WAVE sends everything to dlm_tiled.hip, DLM_OPT_FORCE_WAVE lifts the batch-size rule (A/B
+// measurements and the parity tests of the two paths; the library reads no environment variables).
 // Multivariate models below the tiled range (d <= 15, 2 <= p <= 32) run on the same kernels with one tile per dimension:
 // their only alternative is the generic LDS kernel, so the batch-size rule does not apply to them.
 bool wave48_small_shape(const KArgs& a) {

@@ -120,7 +120,9 @@ class Engine {
   dlm_engine* e_ = nullptr;
 };
 
-// An engine-owned device allocation (dlm_buffer_alloc); freed with the object.
+// An engine-owned device allocation (dlm_buffer_alloc); freed with the object.  LIFETIME: the Engine must outlive its DeviceBuffers
+// (and everything built on them: DeviceSeries, DeviceParameters, DeviceRecords) -- dlm_engine_destroy releases every buffer still
+// allocated, after which this destructor would hand a dangling handle to dlm_buffer_free.  Declare the Engine first (destroyed last).
 class DeviceBuffer {
  public:
   DeviceBuffer(Engine& e, size_t bytes) : e_(&e), bytes_(bytes) { e.check(dlm_buffer_alloc(e.get(), bytes, &p_)); }
@@ -534,9 +536,16 @@ inline void filterSmoothInto(const DeviceSeries& ys, const DeviceParameters& p, 
 // Smoothing.backwardsSmoother on filter records already on the device
 inline DeviceRecords backwardsSmoother(const DeviceSeries& ys, const DeviceParameters& p, const DeviceRecords& kfStates, Flags flags = 0) {
   Engine& e = ys.engine();
-  DeviceRecords sm(ys, kfStates.packed());
+  // dlm_smooth_batch takes DENSE records (packed ones are read by the fused call only): packed input is expanded first
+  if (kfStates.packed()) {
+    DeviceRecords dense(ys, false);
+    const dlm_options ou = detail::opts(0, DLM_MEM_DEVICE);
+    e.check(dlm_unpack_records(e.get(), ys.d(), (int64_t)ys.N() * (ys.T() + 1), kfStates.ptr(), &ou, dense.ptr()));
+    return backwardsSmoother(ys, p, dense, flags);
+  }
+  DeviceRecords sm(ys, false);
   const dlm_model_desc m = ys.modelDesc(); const dlm_params_desc q = p.desc();
-  const dlm_options o = detail::opts(flags | (kfStates.packed() ? DLM_OPT_PACKED_SYM : 0), DLM_MEM_DEVICE);
+  const dlm_options o = detail::opts(flags & ~(Flags)DLM_OPT_PACKED_SYM, DLM_MEM_DEVICE);
   e.check(dlm_smooth_batch(e.get(), &m, &q, kfStates.ptr(), &o, sm.ptr(), nullptr));
   return sm;
 }

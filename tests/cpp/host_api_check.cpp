@@ -79,6 +79,17 @@ int main(int argc, char** argv) {
     const double got = KalmanFilter::logLikelihood(eng, Dlm::polynomial(1), {ys}, p)[0];
     std::printf("first_order_dlm: log-likelihood %.10f (from the golden forecasts %.10f)\n", got, want);
     expect(std::fabs(got - want) < 1e-8 * std::fabs(want), "log-likelihood from the reference's forecasts");
+    // KalmanFilter.likelihood as written (KalmanFilter.scala:299-306 -> logLikelihood :175-183; what MetropolisHastings.dlm calls):
+    // the transition density of the filtered means, here from the means the reference itself wrote (w = 3, dt = 1, g = 1)
+    double wantq7 = 0.0;
+    for (size_t t = 1; t < 1001; ++t) {
+      const double c = fr[t][1] - fr[t - 1][1];
+      wantq7 += -0.5 * c * c / 3.0 - 0.5 * std::log(2.0 * M_PI * 3.0);
+    }
+    const double gotq7 = KalmanFilter::likelihood(eng, Dlm::polynomial(1), {ys}, p)[0];
+    std::printf("first_order_dlm: KalmanFilter.likelihood (literal) %.10f (from the golden filtered means %.10f)\n", gotq7, wantq7);
+    expect(std::fabs(gotq7 - wantq7) < 1e-9 * std::fabs(wantq7), "literal KalmanFilter.likelihood from the reference's filtered means");
+    expect(std::fabs(gotq7 - got) > 1.0, "the literal likelihood is not the prediction-error one (SURVEY quirk Q7)");
   }
   {  // 3. seasonal d = 13 batch + FFBS shape
     Dlm mod = Dlm::polynomial(1).compose(Dlm::seasonal(24, 6));
@@ -119,6 +130,17 @@ int main(int argc, char** argv) {
     expect(one.time == 500.0 && one.mt[0] == sm[500].mt[0], "single-record fetch");
     const double ll = KalmanFilter::logLikelihood(dys, dp)[0], llh = KalmanFilter::logLikelihood(eng, Dlm::polynomial(1), {ys}, p)[0];
     expect(ll == llh, "device-resident log-likelihood equals the host-mode one");
+    expect(KalmanFilter::likelihood(dys, dp)[0] == KalmanFilter::likelihood(eng, Dlm::polynomial(1), {ys}, p)[0], "device-resident literal likelihood equals the host-mode one");
+    // backwardsSmoother on PACKED filter records (dlm_smooth_batch takes dense ones: the wrapper expands them)
+    DeviceRecords pk = KalmanFilter::filter(dys, dp, nullptr, DLM_OPT_PACKED_SYM);
+    DeviceRecords de = KalmanFilter::filter(dys, dp);
+    if (pk.packed()) {
+      auto s1 = Smoothing::backwardsSmoother(dys, dp, pk).series(0), s2 = Smoothing::backwardsSmoother(dys, dp, de).series(0);
+      double dmax = 0;
+      for (size_t t = 0; t < 1001; ++t) dmax = std::max(dmax, std::fabs(s1[t].mt[0] - s2[t].mt[0]) + std::fabs(s1[t].ct(0, 0) - s2[t].ct(0, 0)));
+      std::printf("backwardsSmoother from packed records vs dense ones (another forward kernel wrote them): max diff %.3g\n", dmax);
+      expect(dmax < 1e-11, "backwardsSmoother accepts packed filter records");
+    }
   }
   {  // 5. C2-sized batch, device-resident
     uint64_t freeb = 0, total = 0;
