@@ -60,6 +60,8 @@ struct dlm_engine {
   size_t covws_bytes = 0;
   unsigned char* route = nullptr;
   size_t route_bytes = 0;
+  void* sampws = nullptr;       // shared factors of the backward sampler: table, the zero series' records, flags
+  size_t sampws_bytes = 0;
   hipStream_t cov_stream = nullptr;
   hipEvent_t cov_ev[2] = {nullptr, nullptr};
   // DLM_OPT_COUNT_STEPS: [4] device counters the kernels add to (KArgs::counters), read by dlm_last_counters
@@ -439,6 +441,31 @@ int ensure_xplus_bytes(dlm_engine* e, size_t need) {
   }
   return DLM_OK;
 }
+int ensure_cov_stream(dlm_engine* e) {
+  if (!e->cov_stream) {
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->cov_stream, hipStreamNonBlocking));
+    for (auto& ev : e->cov_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  return DLM_OK;
+}
+// Shared factors of the reference-form backward sampler (dlm_sampler16.hip): the tables are made on the second
+// stream -- a filter and a sampler run of ONE wave on a series of zeros -- while the batch is filtered on the first.
+int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb) {
+  const size_t need = dlm::sampler_shared_ws_bytes(k);
+  if (need > e->sampws_bytes) {
+    if (e->sampws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->sampws)); e->sampws = nullptr; e->sampws_bytes = 0; }
+    HIP_TRY(e, hipMalloc(&e->sampws, need));
+    e->sampws_bytes = need;
+  }
+  int rc = ensure_route(e, (size_t)k.N);
+  if (rc || (rc = ensure_cov_stream(e))) return rc;
+  dlm::sampler_shared_carve(e->sampws, k, tb);
+  HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));               // the model and the tables of G are staged
+  HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
+  HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
+  HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
+  return DLM_OK;
+}
 int ensure_shared(dlm_engine* e, const KArgs& k, dlm::CovTabs& tb, bool with_backward) {
   const size_t need = sizeof(double) * dlm::covtabs_doubles(k.d, k.T);
   if (need > e->covws_bytes) {
@@ -450,10 +477,7 @@ int ensure_shared(dlm_engine* e, const KArgs& k, dlm::CovTabs& tb, bool with_bac
   if (rc) return rc;
   rc = ensure_side(e, k);
   if (rc) return rc;
-  if (!e->cov_stream) {
-    HIP_TRY(e, hipStreamCreateWithFlags(&e->cov_stream, hipStreamNonBlocking));
-    for (auto& ev : e->cov_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  }
+  if ((rc = ensure_cov_stream(e))) return rc;
   dlm::covtabs_carve(e->covws, k.d, k.T, tb);
   tb.eq = e->side + 2 * (size_t)k.N * ((size_t)k.T + 1);
   tb.mc = tb.sc = nullptr;
@@ -605,6 +629,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->spf_dev) (void)hipFree(e->spf_dev);
   if (e->covws) (void)hipFree(e->covws);
   if (e->route) (void)hipFree(e->route);
+  if (e->sampws) (void)hipFree(e->sampws);
   for (auto& ev : e->cov_ev) if (ev) (void)hipEventDestroy(ev);
   if (e->cov_stream) (void)hipStreamDestroy(e->cov_stream);
   if (e->counters) (void)hipFree(e->counters);
@@ -1004,6 +1029,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
   const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
+  bool shared_factors = false;
+  dlm::SampTabs stb{};
   // a V_t stream is a scalar per step on the structured d <= 15, p = 1 path (the Student-t DLM, StudentTGibbs.scala:100-136)
   // and goes through; W_t streams and V_t elsewhere would need a factorisation per step
   if (simflag && (params->w_tstride || (params->v_tstride && !(model->p == 1 && model->d <= 15))))
@@ -1048,6 +1075,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
     if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need a fast path (structured d <= 15 or 16 <= d <= 48)");
+    shared_factors = !simflag && !use_lane(k) && fast_shape_ok(k) && e->sparse_k > 0 && dlm::sampler_shared_eligible(k);
+    if (shared_factors && (rc = start_sampler_tables(e, k, stb))) return rc;
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }
@@ -1057,6 +1086,15 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if (use_lane(k)) {
     e->variant = "lane-sampler";
     HIP_TRY(e, dlm::launch_lane_sampler(k, e->stream));
+    return done();
+  }
+  if (shared_factors) {
+    // V, W, C0 shared by the batch on a regular grid: J_t, H_t and the factors once per call (the table of the second stream), the
+    // series draw against it; a series with a missing observation computes its own as always
+    e->variant = "sparse16-sampler-shared";
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));
+    k.route = e->route;
+    HIP_TRY(e, dlm::launch_sampler_shared_draw(k, e->sparse_k, e->sp_dev, stb, e->stream));
     return done();
   }
   if (fast_shape_ok(k) && e->sparse_k > 0 && !(k.flags & DLM_OPT_NO_SAMPLER16)) {

@@ -108,6 +108,25 @@ hipError_t launch_sparse16_cov_smoother(const KArgs& a, int K, const SparseT* co
 hipError_t launch_sparse16_mean_filter(const KArgs& a, int K, const SparseT* rows_dev, const CovTabs& tabs, hipStream_t s);
 hipError_t launch_sparse16_mean_smoother(const KArgs& a, int K, const SparseT* cols_dev, const CovTabs& tabs, hipStream_t s);
 
+// ---- shared factors of the reference-form backward sampler, dlm_sampler16.hip: J_t, H_t and chol(H_t) depend on
+// the filtered covariances alone.  With parameters shared by the batch ONE wave runs k_sampler_sp16 on the records of a series of
+// zeros into a table; every series without a missing observation draws with the mean-only kernel (four series per wave), the
+// others with k_sampler_sp16 as always.  Draw for draw the per-series kernel's results, bit for bit.
+struct SampTabs {
+  double* rows;          // [T+1] rows of 16 x 34 doubles: per component c [ J_t^T[.][c] (16) | L_t[c][.] (16) | pad (2) ]
+  double* zrec;          // [T+1][d + d^2] filter records of the series of zeros
+  double* zeros;         // max(T, 16) zeros: its observations and initial mean
+  unsigned char* need;   // [T+1] 1: row t was written (a full step); 0: the factors of the last row above it
+  int* status;           // status of the zero series' two kernels, for every series served by the tables
+};
+bool sampler_shared_eligible(const KArgs& a);
+size_t sampler_shared_ws_bytes(const KArgs& a);
+void sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
+// the tables: filter on zeros, then the sampler with its export on (both one wave; stream s)
+hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
+// a.route [N] is filled here (series with a missing observation), the mean-only kernel draws for the others, k_sampler_sp16 for these
+hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
+
 // ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------
 // Nonzeros of the rows (`rows`) and of the columns (`cols`) of a d x d G with at most 4 per row and column (every
 // model the reference can build): the congruences G C G^T and G^T M G are then two gather passes instead of two

@@ -173,10 +173,22 @@ __device__ __forceinline__ double chol_draw(const double (&row)[15], int d, int 
   return th;
 }
 
+// Shared factors.  J_t, H_t and the factor of H_t depend on the filtered COVARIANCES alone: when the batch shares
+// V, W, C0 on a regular grid they are those of every series without a missing observation.  One wave then runs k_sampler_sp16
+// on the records of a series of zeros with EXP set and leaves, per step that computed them, a table row; every series draws
+// with k_mean_sampler_sp16 below -- four series per wave, the mean recursion and the draw only.
+//   row t (SF_ROW doubles): per component c < d  [ J_t^T[0..15][c] | L_t[c][0..14], 0 | 2 pad ]      need[t] = 1
+//   a step the producer took in its steady form leaves no row (need[t] = 0): the factors are those of the last row above it.
+constexpr int SF_ENT = 34;                 // 272 bytes per component: sixteen lanes' 16-byte LDS reads fall into distinct banks
+constexpr int SF_ROW = 16 * SF_ENT;
+constexpr int SF_SLOT = 4096;              // LDS bytes of a ring slot (15 * 272 = 4080 at most travel)
+constexpr int SF_AHEAD = 8;                // the filtered means are requested this many steps ahead
+
 // Tab: SparseT (the d <= 15, p = 1 tables) or SparseBig (the tables of the multivariate paths); any p <= 64 -- the
 // observations only enter the statistics.
-template <int K, class Tab>
-__global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __restrict__ sp) {   // two waves per SIMD: the step is a long dependent chain
+template <int K, class Tab, bool EXP = false>
+__global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __restrict__ sp, SampTabs tb) {   // two waves per SIMD: the step is a long dependent chain
+  if (!EXP && a.route && (a.route[blockIdx.x] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16 + 64];
   double* img = lds;       double* inv = lds + IMG;
   double* mv = inv + IMG;  double* thv = mv + 16;   double* uv = thv + 16;   double* zv = uv + 16;
@@ -233,6 +245,19 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     const double v = chol_draw(rows, d, lane, hcol, vc ? zc : 0.0);
     return (vc && g == 0) ? v : 0.0;
   };
+  auto export_row = [&](int t, const d4* JT, const double (&rows)[15]) {
+    double* row = tb.rows + (size_t)t * SF_ROW + c * SF_ENT;
+    if (vc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) row[4 * r + g] = JT ? (*JT)[r] : 0.0;
+      if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) row[16 + k] = (lane >= k && k < d) ? rows[k] : 0.0;   // as chol_draw takes them
+        row[31] = 0.0;
+      }
+    }
+    if (lane == 0) tb.need[t] = 1;
+  };
   auto factor = [&](const d4& H, double (&rows)[15]) {
     to_img(H, img, g, c);
     wave_sync();
@@ -250,6 +275,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     const double zc = vc ? (zin ? zin[(size_t)T * d + c] : philox_normal(a.seed, series, (unsigned)T, (unsigned)c)) : 0.0;
     double rows[15];
     factor(C, rows);
+    if constexpr (EXP) export_row(T, nullptr, rows);
     const double th = emit(T, mc, C, zc, rows);
     if (g == 0) thv[c] = th;
     if (thout && g == 0 && vc) thout[(size_t)T * d + c] = th;
@@ -342,6 +368,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
       if (g == 0) uv[c] = vc ? thv[c] - a1 : 0.0;
       wave_sync();
       hcol = mc + matTvec(JT, uv, g);
+      if constexpr (EXP) { if (lane == 0) tb.need[t] = 0; }
     } else {
     to_img(C, img, g, c);
     wave_sync();
@@ -440,6 +467,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
       for (int r = 0; r < 4; ++r) H[r] = (4 * r + g == c) ? H[r] : (H[r] + Ht[r]) / 2.0;
     }
     factor(H, Ls);
+    if constexpr (EXP) export_row(t, &JT, Ls);
     Cp = C; JTs = JT; Hs = H; have = true; gprev = gi; dtprev = dt;
     {
       double mx = fmax(fmax(fabs(C[0]), fabs(C[1])), fmax(fabs(C[2]), fabs(C[3])));
@@ -481,6 +509,263 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     } else if (g == 0 && vc) so[2 * p + c] = ssd;
   }
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+  if (!EXP && a.route && a.counters && lane == 0) atomicAdd(&a.counters[3], 1ull);   // a series of a shared-factor call that computed its own
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The draw against the shared factors: four series per wave (lane 16 j + c = component c of series j of the wave's four
+// consecutive series).  Per step only what depends on the data is left --
+//     a+ = G m_t,  h = m_t + J_t (theta_{t+1} - a+),  theta_t = h + L_t z_t,  the Gibbs sums
+// -- in the operations of k_sampler_sp16, one for one: the same FMA chains (matTvec's four partial chains and their
+// (0 + 1) + (2 + 3) sum, chol_draw's chain over the pivots, the gathers of G in table order), the same normals.  The factors
+// live in registers (column c of J^T, row c of L) and are replaced when the table has a row for the step (SampTabs::need);
+// rows travel two steps ahead by LDS DMA from L2, the four series' filtered means SF_AHEAD steps ahead from their records.
+// All vector-memory traffic of the loop is issued by hand and waited for by count (vm_wait), see dlm_sparse16.hip.
+// NR: DMA instructions per table row = ceil(17 d / 64).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i4 rsrc_words(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  i4 r = {__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu)),
+          __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+template <int OFF>
+__device__ __forceinline__ double lds_read64(unsigned addr) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ d2 lds_read128(unsigned addr) {
+  d2 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// 16 bytes per lane from byte offset voff + soff of the buffer to LDS address lds_addr + 16 lane (+ 1024 per further instruction)
+template <int NR>
+__device__ __forceinline__ void dma_row(const i4& rs, unsigned lds_addr, int soff, int lane, int n16) {
+  const int voff = lane * 16;
+  lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  // NR = ceil(n16 / 64): every instruction has lanes to serve, so the count of operations in flight is NR whatever the exec mask
+  if (lane < n16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if constexpr (NR > 1) if (lane + 64 < n16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if constexpr (NR > 2) if (lane + 128 < n16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  if constexpr (NR > 3) if (lane + 192 < n16) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ double mul_rn(double x, double y) {   // a product that is rounded before it is used (never contracted into the addition behind it)
+#pragma clang fp contract(off)
+  return x * y;
+}
+__device__ __forceinline__ double row_pick(double v, int lane, int src) {   // the value of lane src (0..15, wave-uniform) of this lane's 16-lane row
+  const int a_ = ((lane & 48) + src) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(a_, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(a_, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <int K, int NR>
+__global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const SparseT* __restrict__ sp, SampTabs tb) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * 64 + 4 * 64 + 2 * (SF_SLOT / 8) + SF_AHEAD * 64];
+  const int lane = threadIdx.x, j = lane >> 4, c = lane & 15;
+  const int n0 = 4 * blockIdx.x;
+  if (n0 >= a.N) return;
+  const int nser = a.N - n0 < 4 ? a.N - n0 : 4;
+  const bool have = j < nser;
+  const int n = have ? n0 + j : n0;                 // (a row without a series shadows the first: loads stay in bounds, nothing is stored)
+  const bool dead = !have || a.route[n] != 0;       // a series with a missing observation: k_sampler_sp16 serves it
+  if (__ballot(!dead) == 0ull) return;
+  double* vU = lds;            // theta_{t+1} - a+   [4][16]
+  double* vT = vU + 64;        // theta_t
+  double* vZ = vT + 64;        // the normals of four steps, [t & 3][4][16]
+  char* ring = (char*)(vZ + 4 * 64);               // two table slots, then the slots of the means
+  const int d = a.d, T = a.T, rec = d + d * d, recb = rec * 8;
+  const bool vc = c < d;
+  int idx[K];
+  double val[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { idx[s] = (16 * j + sp[0].idx[c][s]) * 8; val[s] = vc ? sp[0].val[c][s] : 0.0; }
+  const size_t sbytes = (size_t)(T + 1) * recb;
+  const i4 rmean = rsrc_words((const char*)a.filt_in + (size_t)n0 * sbytes, (unsigned)((size_t)nser * sbytes));
+  const i4 rtab = rsrc_words(tb.rows, (unsigned)((size_t)(T + 1) * SF_ROW * 8));
+  const int mvoff = (lane < 32 && (lane >> 3) < nser) ? (int)((size_t)(lane >> 3) * sbytes) + (lane & 7) * 16 : OOB;   // 16 doubles from the head of each record
+  const unsigned ring_lds = lds_addr_of(ring), mring_lds = ring_lds + 2 * SF_SLOT;
+  const unsigned vT_lds = lds_addr_of(vT);
+  const int n16 = d * (SF_ENT / 2);                  // 16-byte pieces of a row that travel
+  auto dma_means = [&](unsigned lds_addr, int soff) {
+    lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    if (lane < 32)   // 4 x 8 pieces; the other lanes' LDS destinations lie beyond the slot
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(mvoff), "s"(rmean), "s"(soff) : "memory");
+  };
+  double* thout = a.theta ? a.theta + (size_t)n0 * (T + 1) * d : nullptr;
+  const __amdgpu_buffer_rsrc_t rth = mk_rsrc(thout, thout ? (size_t)nser * (T + 1) * d * 8 : 0);
+  const int offth = (!dead && vc && thout) ? (int)((size_t)j * (T + 1) * d * 8) + c * 8 : OOB;
+  const double* y = (a.stats && a.y) ? a.y + (size_t)n * T : nullptr;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * d : nullptr;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  const double Fc = vc ? a.F[c] : 0.0;
+  const unsigned char* need = tb.need;
+
+  // the normals of steps tb_ and tb_ - 1: one Philox block and one Box-Muller pair give two components
+  auto normals2 = [&](int tb_) {
+    const int te = tb_ - (c & 1);
+    if (te >= 0) {
+      double ze, zo;
+      philox_normal2(a.seed, series, (unsigned)te, (unsigned)(c >> 1), ze, zo);
+      double* zr = vZ + (te & 3) * 64 + 16 * j + (c & ~1);
+      zr[0] = ze; zr[1] = zo;
+    }
+  };
+  double Jc[16], Lr[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { Jc[k] = 0.0; Lr[k] = 0.0; }
+  auto read8 = [&](unsigned base, double (&dst)[16]) {
+    d2 q[8];
+    q[0] = lds_read128<0>(base); q[1] = lds_read128<16>(base); q[2] = lds_read128<32>(base); q[3] = lds_read128<48>(base);
+    q[4] = lds_read128<64>(base); q[5] = lds_read128<80>(base); q[6] = lds_read128<96>(base); q[7] = lds_read128<112>(base);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])::"memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dst[2 * k] = vc ? q[k][0] : 0.0; dst[2 * k + 1] = vc ? q[k][1] : 0.0; }
+  };
+  auto read_row = [&](unsigned slot, bool withJ) {
+    const unsigned base = slot + (vc ? c : 0) * (SF_ENT * 8);
+    if (withJ) read8(base, Jc);
+    read8(base + 128, Lr);
+  };
+  // theta = h + L z over the pivots, as chol_draw
+  auto draw = [&](double hcol, const double* zk) {
+    double th = hcol;
+#pragma unroll
+    for (int k = 0; k < 15; ++k)
+      if (k < d) th = fma(Lr[k], zk[16 * j + k], th);
+    return vc ? th : 0.0;
+  };
+
+  // requests: the means of steps T .. T - SF_AHEAD + 1 (the oldest), then the table rows T and T - 1
+  for (int k = 0; k < SF_AHEAD; ++k) { const int tk = T - k > 0 ? T - k : 0; dma_means(mring_lds + ((T - k) & (SF_AHEAD - 1)) * 512, tk * recb); }
+  dma_row<NR>(rtab, ring_lds + (T & 1) * SF_SLOT, T * (SF_ROW * 8), lane, n16);
+  dma_row<NR>(rtab, ring_lds + ((T - 1) & 1) * SF_SLOT, (T > 0 ? T - 1 : 0) * (SF_ROW * 8), lane, n16);
+  // need[t], need[t - 1], need[t - 2] as the loop goes down: bit (s & 63) of the mask of s's block of 64 steps
+  unsigned long long nmask = 0;
+  auto need_of = [&](int s_) -> bool {
+    if (s_ < 0) return false;
+    if (s_ == T || (s_ & 63) == 63) { const int b = (s_ & ~63) + lane; nmask = __ballot(b <= T && need[b] != 0); }
+    return ((nmask >> (s_ & 63)) & 1ull) != 0;
+  };
+  bool nd0 = need_of(T), nd1 = need_of(T - 1), nd2 = need_of(T - 2);
+  (void)nd0;
+  double thc;
+  {   // theta_T = m_T + chol(C_T) z_T
+    if (zin) vZ[(T & 3) * 64 + lane] = vc ? zin[(size_t)T * d + c] : 0.0;
+    else vZ[(T & 3) * 64 + lane] = vc ? philox_normal(a.seed, series, (unsigned)T, (unsigned)c) : 0.0;
+    if (!zin) { normals2(T - 1); }
+    vm_wait<0>();
+    wave_sync();
+    const unsigned slot = ring_lds + (T & 1) * SF_SLOT, mslot = mring_lds + (T & (SF_AHEAD - 1)) * 512;
+    double mr = lds_read64<0>(mslot + lane * 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr)::"memory");
+    read_row(slot, false);
+    thc = draw(vc ? mr : 0.0, vZ + (T & 3) * 64);
+    wave_sync();
+    dma_means(mslot, (T > SF_AHEAD ? T - SF_AHEAD : 0) * recb);
+    if (nd2) dma_row<NR>(rtab, slot, (T - 2) * (SF_ROW * 8), lane, n16);
+    bst(rth, offth, T * d * 8, thc);
+  }
+  double ssd = 0.0, ssy = 0.0;
+  int nob = 0;
+  double yk[2] = {0.0, 0.0};             // the observations of this row's series, 32 steps at a time
+  for (int t = T - 1; t >= 0; --t) {
+    nd0 = nd1; nd1 = nd2; nd2 = need_of(t - 2);
+    if (zin) { vZ[(t & 3) * 64 + lane] = vc ? zin[(size_t)t * d + c] : 0.0; wave_sync(); }
+    if (y) {   // observation residual of theta_{t+1} (Gibbs.scala:29-39), as k_sampler_sp16
+      if (t == T - 1 || (t & 31) == 31) {
+        const int base = t & ~31;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) yk[k] = (base + 16 * k + c < T) ? y[base + 16 * k + c] : 0.0;
+        asm volatile("" ::"v"(yk[0]), "v"(yk[1]));
+      }
+      const double yv = row_pick(((t >> 4) & 1) ? yk[1] : yk[0], lane, t & 15);
+      double part = vc ? mul_rn(Fc, thc) : 0.0;
+      for (int o_ = 8; o_ > 0; o_ >>= 1) part += __shfl_xor(part, o_);
+      if (c == 0 && yv == yv) { ssy += (yv - part) * (yv - part); nob += 1; }
+    }
+    // Operations younger than the request for row t (issued two steps up, behind that step's request for the means): that step's
+    // store, then the step above this one: means, row t - 1 (when it exists), store.  Without a row for this step the means
+    // of step t are what is waited for: requested SF_AHEAD steps up, at least 2 SF_AHEAD - 1 operations ago.
+    if (nd0) { if (nd1) vm_wait<3 + NR>(); else vm_wait<3>(); } else vm_wait<2 * SF_AHEAD - 1>();
+    const unsigned slot = ring_lds + (t & 1) * SF_SLOT, mslot = mring_lds + (t & (SF_AHEAD - 1)) * 512;
+    double mr = lds_read64<0>(mslot + lane * 8);
+    double mg[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) mg[s] = lds_read64<0>(mslot + idx[s]);
+    if constexpr (K == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(mg[0])::"memory");
+    else if constexpr (K == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(mg[0]), "+v"(mg[1])::"memory");
+    else if constexpr (K == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(mg[0]), "+v"(mg[1]), "+v"(mg[2])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(mg[0]), "+v"(mg[1]), "+v"(mg[2]), "+v"(mg[3])::"memory");
+    if (nd0) read_row(slot, true);
+    dma_means(mslot, (t > SF_AHEAD ? t - SF_AHEAD : 0) * recb);
+    if (nd2) dma_row<NR>(rtab, slot, (t - 2) * (SF_ROW * 8), lane, n16);
+    const double mc = vc ? mr : 0.0;
+    double a1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < K; ++s) a1 = fma(vc ? mg[s] : 0.0, val[s], a1);
+    vU[lane] = vc ? thc - a1 : 0.0;
+    wave_sync();
+    double ch[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ch[g] = fma(Jc[4 * r + g], vU[16 * j + 4 * r + g], ch[g]);
+    const double hcol = mc + ((ch[0] + ch[1]) + (ch[2] + ch[3]));
+    const double th = draw(hcol, vZ + (t & 3) * 64);
+    if (a.stats) {   // system residual theta_{t+1} - G theta_t
+      vT[lane] = th;
+      wave_sync();
+      double gth = 0.0;
+#pragma unroll
+      for (int s = 0; s < K; ++s) gth = fma(vT[idx[s] >> 3], val[s], gth);
+      const double df = vc ? thc - gth : 0.0;
+      ssd += mul_rn(df, df);
+    }
+    wave_sync();
+    thc = th;
+    bst(rth, offth, t * d * 8, th);
+    if (!zin && ((T - 1 - t) & 1) == 1) normals2(t - 1);   // the normals of steps t - 1 and t - 2
+  }
+  vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
+  (void)vT_lds;
+  const int stz = tb.status[0];
+  const unsigned long long badl = __ballot(!dead && vc && !isfinite(thc));
+  if (!dead) {
+    if (a.stats) {
+      const int L = stats_len(d, 1, a.flags);
+      double* so = a.stats + (size_t)n * L;
+      if (c == 0) { so[0] = ssy; so[1] = (double)nob; so[L - 1] = (double)T; }
+      if (vc) so[2 + c] = ssd;
+    }
+    if (c == 0) {
+      const int sj = stz | (((badl >> (16 * j)) & 0xffffull) ? DLM_ST_NONFINITE : 0);
+      if (a.status && sj) atomicOr(&a.status[n], sj);
+    }
+  }
+  const unsigned long long live = __ballot(!dead && c == 0);
+  if (a.counters && lane == 0) atomicAdd(&a.counters[2], (unsigned long long)__builtin_popcountll(live));
+}
+
+// route[n] = 1: the series has a missing observation
+__global__ __launch_bounds__(256) void k_mark_gaps(const double* __restrict__ y, int N, int T, unsigned char* __restrict__ route) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const double* yn = y + (size_t)n * T;
+  bool gap = false;
+  for (int t = lane; t < T; t += 64) { const double v = yn[t]; gap |= !(v == v); }
+  const bool any = __ballot(gap) != 0ull;
+  if (lane == 0) route[n] = any ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -685,10 +970,10 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
 template <class Tab>
 static hipError_t launch_sampler_t(const KArgs& a, int K, const Tab* tabs_dev, hipStream_t s) {
   switch (K) {
-    case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 3: hipLaunchKernelGGL((s16::k_sampler_sp16<3, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 4: hipLaunchKernelGGL((s16::k_sampler_sp16<4, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, SampTabs{}); break;
+    case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, SampTabs{}); break;
+    case 3: hipLaunchKernelGGL((s16::k_sampler_sp16<3, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, SampTabs{}); break;
+    case 4: hipLaunchKernelGGL((s16::k_sampler_sp16<4, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, SampTabs{}); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -706,6 +991,84 @@ static hipError_t launch_rts_t(const KArgs& a, int K, const Tab* tabs_dev, hipSt
   }
   return hipGetLastError();
 }
+// ---- shared factors ------------------------------------------------------------------------------------------------------------
+#ifndef DLM_SAMPLER_SHARED_MIN
+#define DLM_SAMPLER_SHARED_MIN 2560   // series from which the table pays: below, every series' own wave is resident at once and takes as long as the table's
+#endif
+bool sampler_shared_eligible(const KArgs& a) {
+  const size_t rec = (size_t)a.d + (size_t)a.d * a.d;
+  return a.d <= 15 && a.p == 1 && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !a.v_stride && !a.w_stride && !a.c0_stride &&
+         !a.cond && !a.packed && a.filt && (!a.stats || a.y) && a.T >= 1 && a.T <= 400000 &&
+         !(a.flags & (DLM_OPT_STATS_OUTER | DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16 | DLM_OPT_SAMPLER_PER_SERIES)) &&
+         (a.N >= DLM_SAMPLER_SHARED_MIN || (a.flags & DLM_OPT_NO_SMALL_BATCH)) &&
+         4 * ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);   // four series' records under one buffer resource
+}
+static size_t up64(size_t x) { return (x + 63) & ~(size_t)63; }
+size_t sampler_shared_ws_bytes(const KArgs& a) {
+  const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d;
+  return up64(n1 * s16::SF_ROW * 8) + up64(n1 * rec * 8) + up64((size_t)(a.T > 16 ? a.T : 16) * 8) + up64(n1) + 64;
+}
+void sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb) {
+  const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d;
+  char* p = (char*)ws;
+  tb.rows = (double*)p;  p += up64(n1 * s16::SF_ROW * 8);
+  tb.zrec = (double*)p;  p += up64(n1 * rec * 8);
+  tb.zeros = (double*)p; p += up64((size_t)(a.T > 16 ? a.T : 16) * 8);
+  tb.need = (unsigned char*)p; p += up64(n1);
+  tb.status = (int*)p;
+}
+hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s) {
+  hipError_t err = hipMemsetAsync(tb.zeros, 0, (size_t)(a.T > 16 ? a.T : 16) * 8, s);
+  if (err != hipSuccess) return err;
+  if ((err = hipMemsetAsync(tb.status, 0, sizeof(int), s)) != hipSuccess) return err;
+  KArgs kf = a;   // the filter on a series of zeros: the covariances of every series without a missing observation, bit for bit
+  kf.N = 1; kf.y = tb.zeros; kf.m0 = tb.zeros; kf.m0_stride = 0; kf.filt = tb.zrec; kf.status = tb.status; kf.stats = nullptr; kf.loglik = nullptr;
+  kf.prior = nullptr; kf.fq = nullptr; kf.route = nullptr; kf.counters = nullptr; kf.theta = nullptr; kf.z = nullptr; kf.series_offset = 0;
+  if ((err = launch_sparse16_filter(kf, K, tabs_dev, nullptr, nullptr, s)) != hipSuccess) return err;
+  KArgs kp = kf;
+  kp.y = nullptr; kp.filt_in = tb.zrec;
+  switch (K) {
+    case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 3: hipLaunchKernelGGL((s16::k_sampler_sp16<3, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 4: hipLaunchKernelGGL((s16::k_sampler_sp16<4, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_mean_sampler(const KArgs& a, const SparseT* sp, const SampTabs& tb, hipStream_t s) {
+  const dim3 grid((a.N + 3) / 4), blk(64);
+  const int nr = (17 * a.d + 63) / 64;
+  switch (nr) {
+    case 1: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 1>), grid, blk, 0, s, a, sp, tb); break;
+    case 2: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 2>), grid, blk, 0, s, a, sp, tb); break;
+    case 3: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 3>), grid, blk, 0, s, a, sp, tb); break;
+    default: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 4>), grid, blk, 0, s, a, sp, tb); break;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s) {
+  if (!a.route) return hipErrorInvalidValue;
+  hipError_t err;
+  if (a.y) hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, a.route);
+  else if ((err = hipMemsetAsync(a.route, 0, (size_t)a.N, s)) != hipSuccess) return err;
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  KArgs km = a;
+  km.route_take = 0;
+  switch (K) {
+    case 1: err = launch_mean_sampler<1>(km, tabs_dev, tb, s); break;
+    case 2: err = launch_mean_sampler<2>(km, tabs_dev, tb, s); break;
+    case 3: err = launch_mean_sampler<3>(km, tabs_dev, tb, s); break;
+    case 4: err = launch_mean_sampler<4>(km, tabs_dev, tb, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (err != hipSuccess) return err;
+  KArgs kg = a;   // the series with a missing observation: their own factors
+  kg.route_take = 1;
+  return launch_sampler_t(kg, K, tabs_dev, s);
+}
+
 // RTS smoother from filter records alone (a.filt_in -> a.smooth), textbook or literal Q1: structured d <= 15
 hipError_t launch_sparse16_rts(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s) { return launch_rts_t(a, K, tabs_dev, s); }
 hipError_t launch_small_mv_rts(const KArgs& a, hipStream_t s) { return launch_rts_t(a, a.spb_k, a.spb, s); }

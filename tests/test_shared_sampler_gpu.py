@@ -1,0 +1,169 @@
+"""Shared factors of the reference-form backward sampler ("next round" 7).
+
+Smoothing.sampleDlm / backSampleStep (Smoothing.scala:74-122): J_t = C_t G^T R_{t+1}^-1, H_t and its factor depend on the filtered
+COVARIANCES alone.  With V, W, C0 shared by the batch on a regular grid (the pooled Gibbs samplers, GibbsSampling.sample,
+Gibbs.scala:134-180) the engine computes them ONCE per call -- k_sampler_sp16 itself on the filter records of a series of zeros,
+one wave -- and every series without a missing observation draws against that table with a mean-only kernel (four series per
+wave): a+ = G m_t, h = m_t + J_t (theta_{t+1} - a+), theta_t = h + L_t z_t and the Gibbs sums, in the per-series kernel's
+operations one for one.  The bar is therefore EQUALITY OF BITS with the per-series kernel (DLM_OPT_SAMPLER_PER_SERIES) on whole
+outputs -- draws, statistics, status -- plus the usual tolerance against the oracle with injected normals."""
+import numpy as np
+import pytest
+
+import oracle
+from bayesian_dlms_amd import _lib
+from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
+
+pytestmark = pytest.mark.gpu
+
+W_C2 = np.array([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4])
+SMALL = _lib.OPT_NO_SMALL_BATCH          # the table also for batches below the size from which it pays
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bayesian_dlms_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def omodel(mat):
+    return oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+
+
+def c2(T):
+    mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    return mat, DlmParameters([[1.0]], np.diag(W_C2), np.zeros(13), np.eye(13))
+
+
+def both(eng, mat, p, y, flags=0, **kw):
+    sh = eng.ffbs(mat, p, y, flags=flags | SMALL | _lib.OPT_COUNT_STEPS, **kw)
+    cnt = eng.last_counters()
+    assert eng.last_variant == "sparse16-sampler-shared"
+    ps = eng.ffbs(mat, p, y, flags=flags | SMALL | _lib.OPT_SAMPLER_PER_SERIES | _lib.OPT_COUNT_STEPS, **kw)
+    assert eng.last_variant == "sparse16-sampler"
+    assert eng.last_counters()[2:] == (0, 0)
+    return sh, ps, cnt
+
+
+def same(sh, ps):
+    for k in ("theta", "stats", "filt", "status"):
+        if sh[k] is not None:
+            assert np.array_equal(sh[k], ps[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("T,N", [(1000, 37), (1, 5), (2, 3), (3, 4), (40, 9), (63, 4), (64, 4), (65, 4), (129, 300)])
+def test_draw_for_draw_the_per_series_kernel(eng, T, N):
+    mat, p = c2(T)
+    rng = np.random.default_rng(T + N)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    sh, ps, cnt = both(eng, mat, p, y, seed=11 + T, series_offset=5)
+    assert cnt[2] == N and cnt[3] == 0, cnt
+    same(sh, ps)
+    assert np.all(sh["status"] == 0)
+    assert np.isfinite(sh["theta"]).all() and np.isfinite(sh["stats"]).all()
+
+
+def test_injected_normals_against_the_oracle(eng):
+    """Smoothing.sampleDlm with the engine's canonical factor: the draws from injected normals against the oracle's sampler."""
+    T, N = 200, 6
+    mat, p = c2(T)
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    z = rng.standard_normal((N, T + 1, 13))
+    sh, ps, cnt = both(eng, mat, p, y, z=z)
+    assert cnt[2] == N
+    same(sh, ps)
+    n = 4
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n])
+    o = oracle.backward_sample(omodel(mat), p.w, f, z[n], factor="chol")
+    np.testing.assert_allclose(sh["theta"][n], o["theta"], rtol=1e-7, atol=1e-8)
+
+
+def test_series_with_missing_observations_compute_their_own_factors(eng):
+    T, N = 300, 64
+    mat, p = c2(T)
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    y[1, 0, 0] = np.nan
+    y[5, T - 1, 0] = np.nan
+    y[17, 100:110, 0] = np.nan
+    y[40, :, 0] = np.nan
+    y[63, 64, 0] = np.nan
+    sh, ps, cnt = both(eng, mat, p, y, seed=4)
+    assert cnt[2] == N - 5 and cnt[3] == 5, cnt
+    same(sh, ps)
+    assert np.all(sh["status"] == 0)
+
+
+@pytest.mark.parametrize("knz", [1, 3, 4])
+def test_every_sparsity_instantiation(eng, knz):
+    rng = np.random.default_rng(80 + knz)
+    d, T = 8, 400
+    Gm = np.zeros((d, d))
+    coef = {1: [0.9], 3: [0.6, 0.25, -0.2], 4: [0.5, 0.3, -0.2, 0.15]}[knz]
+    for i in range(d):
+        for s_, cf in enumerate(coef):
+            Gm[i, (i + s_) % d] = cf
+    Fv = np.array([1.0, 0.0, 1.0, 0.5, 0.0, 1.0, 0.0, -0.5]).reshape(-1, 1)
+    mat = materialise(Dlm(lambda t: Fv, lambda dt: Gm), np.arange(1, T + 1, dtype=np.float64))
+    p = DlmParameters([[0.7]], np.diag(rng.uniform(0.1, 0.5, d)), rng.standard_normal(d), np.eye(d))
+    y = rng.standard_normal((9, T, 1))
+    y[1, 200:203, 0] = np.nan
+    sh, ps, cnt = both(eng, mat, p, y, seed=knz)
+    assert cnt[2] == 8 and cnt[3] == 1
+    same(sh, ps)
+
+
+@pytest.mark.parametrize("d", [2, 3, 4, 6, 7, 11, 12, 14, 15])
+def test_other_state_dimensions(eng, d):
+    """Table rows of 17 d sixteen-byte pieces: one to four DMA instructions per row."""
+    rng = np.random.default_rng(d)
+    T = 150
+    Gm = 0.8 * np.eye(d) + 0.15 * np.eye(d, k=1)
+    Fv = rng.standard_normal((d, 1))
+    mat = materialise(Dlm(lambda t: Fv, lambda dt: Gm), np.arange(1, T + 1, dtype=np.float64))
+    A = rng.standard_normal((d, d))
+    p = DlmParameters([[0.9]], A @ A.T / d + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d) * 2)
+    y = rng.standard_normal((7, T, 1)).cumsum(axis=1)
+    sh, ps, cnt = both(eng, mat, p, y, flags=_lib.OPT_NO_LANE, seed=d)
+    assert cnt[2] == 7
+    same(sh, ps)
+
+
+def test_without_statistics_without_draws_and_what_falls_back(eng):
+    T, N = 120, 50
+    mat, p = c2(T)
+    rng = np.random.default_rng(9)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1)
+    sh, ps, _ = both(eng, mat, p, y, want_stats=False)
+    same(sh, ps)
+    sh, ps, _ = both(eng, mat, p, y, want_theta=False)
+    same(sh, ps)
+    eng.ffbs(mat, p, y, flags=_lib.OPT_COUNT_STEPS)                      # a small batch: every series its own wave, all resident at once
+    assert eng.last_variant == "sparse16-sampler" and eng.last_counters()[2] == 0
+    eng.ffbs(mat, p, y, flags=SMALL | _lib.OPT_COUNT_STEPS, want_cond=True)      # conditional-moment records: H_t is not in the table
+    assert eng.last_variant == "sparse16-sampler"
+    plist = [DlmParameters(p.v * (1 + 0.1 * n), p.w, p.m0, p.c0) for n in range(N)]
+    eng.ffbs(mat, plist, y, flags=SMALL | _lib.OPT_COUNT_STEPS)             # per-series V: per-series covariances
+    assert eng.last_variant == "sparse16-sampler"
+    mi = materialise(Dlm.polynomial(1) + Dlm.seasonal(24, 6), np.cumsum(np.array([1.0, 2.0, 1.0] * 40)))
+    out = eng.ffbs(mi, p, y, flags=SMALL)                                   # an irregular grid
+    assert eng.last_variant == "sparse16-sampler" and np.all(out["status"] == 0)
+
+
+def test_device_resident_large_batch_is_shared_by_default(eng):
+    import torch
+    T, N = 60, 2600
+    mat, p = c2(T)
+    rng = np.random.default_rng(10)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1)
+    y[77, 30, 0] = np.nan
+    yd = torch.as_tensor(y, device="cuda:0")
+    dev = eng.ffbs(mat, p, yd, seed=3, flags=_lib.OPT_COUNT_STEPS)
+    assert eng.last_variant == "sparse16-sampler-shared" and eng.last_counters()[2:] == (N - 1, 1)
+    ref = eng.ffbs(mat, p, y, seed=3, flags=_lib.OPT_SAMPLER_PER_SERIES)
+    assert np.array_equal(dev["theta"].cpu().numpy(), ref["theta"], equal_nan=True)
+    assert np.array_equal(dev["stats"].cpu().numpy(), ref["stats"], equal_nan=True)
