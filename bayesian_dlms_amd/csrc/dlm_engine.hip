@@ -443,7 +443,9 @@ int ensure_xplus_bytes(dlm_engine* e, size_t need) {
 }
 int ensure_cov_stream(dlm_engine* e) {
   if (!e->cov_stream) {
-    HIP_TRY(e, hipStreamCreateWithFlags(&e->cov_stream, hipStreamNonBlocking));
+    int lo = 0, hi = 0;   // the few waves of the table kernels go first: they run beside a kernel that fills the device
+    HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(e, hipStreamCreateWithPriority(&e->cov_stream, hipStreamNonBlocking, hi));
     for (auto& ev : e->cov_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   return DLM_OK;

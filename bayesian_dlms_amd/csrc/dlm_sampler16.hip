@@ -183,6 +183,7 @@ constexpr int SF_ENT = 34;                 // 272 bytes per component: sixteen l
 constexpr int SF_ROW = 16 * SF_ENT;
 constexpr int SF_SLOT = 4096;              // LDS bytes of a ring slot (15 * 272 = 4080 at most travel)
 constexpr int SF_AHEAD = 8;                // the filtered means are requested this many steps ahead
+constexpr int SF_STRETCH = 32;             // steps t with t % SF_STRETCH == SF_STRETCH - 1 start from scratch (k_sampler_sp16, every series)
 
 // Tab: SparseT (the d <= 15, p = 1 tables) or SparseBig (the tables of the multivariate paths); any p <= 64 -- the
 // observations only enter the statistics.
@@ -193,8 +194,12 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   double* img = lds;       double* inv = lds + IMG;
   double* mv = inv + IMG;  double* thv = mv + 16;   double* uv = thv + 16;   double* zv = uv + 16;
   double* hv = zv + 16;    double* dfv = hv + 16;   double* zq = mv + 8 * 16;   // zq: 64 normals, four records x 16 components
-  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  // EXP: the series is the one series of zeros and workgroup b makes the rows of the steps of stretch b (a stretch starts from
+  // scratch, see SF_STRETCH)
+  const int n = EXP ? 0 : blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  const int t_lo = EXP ? (int)blockIdx.x * SF_STRETCH : 0;
+  const int t_hi = EXP ? ((t_lo + SF_STRETCH < T ? t_lo + SF_STRETCH : T) - 1) : T - 1;
   const bool vc = c < d;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
   for (int i = lane; i < 8 * 16; i += 64) mv[i] = 0.0;
@@ -267,12 +272,12 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     wave_sync();
   };
 
-  {   // theta_T ~ N(m_T, C_T)
+  if (!EXP || t_hi == T - 1) {   // theta_T ~ N(m_T, C_T)
     d4 C;
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[r] = bld(rin, offC[r], T * recb);
     const double mc = bld(rin, vc ? c * 8 : OOB, T * recb);
-    const double zc = vc ? (zin ? zin[(size_t)T * d + c] : philox_normal(a.seed, series, (unsigned)T, (unsigned)c)) : 0.0;
+    const double zc = (vc && !EXP) ? (zin ? zin[(size_t)T * d + c] : philox_normal(a.seed, series, (unsigned)T, (unsigned)c)) : 0.0;
     double rows[15];
     factor(C, rows);
     if constexpr (EXP) export_row(T, nullptr, rows);
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   d4 nC;
   double nm;
   {
-    const int tp = T > 0 ? T - 1 : 0;
+    const int tp = t_hi > 0 ? t_hi : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
     nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
@@ -300,10 +305,13 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   const bool f1 = p == 1 && !a.f_stride;
   const double Fl1 = (f1 && lane < d) ? a.F[lane] : 0.0;
   double ych = 0.0;
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = t_hi; t >= t_lo; --t) {
+    // Every SF_STRETCH steps the recursion starts from scratch -- a full step, its inverse not refined from the one before: what a
+    // step computes then depends on nothing above its stretch, and the stretches of a shared-factor table are made side by side.
+    if ((t & (SF_STRETCH - 1)) == SF_STRETCH - 1) { have = false; warm = false; }
     // the normals of records t, t-1, t-2, t-3 (16 components each) are drawn together, one per lane, every fourth step:
     // the generator is the same few hundred instructions whether 13 lanes or 64 need a value
-    if (!zin && ((T - 1 - t) & 3) == 0) {
+    if (!EXP && !zin && ((T - 1 - t) & 3) == 0) {
       const int tr = t - g;
       zq[lane] = (vc && tr >= 0) ? philox_normal(a.seed, series, (unsigned)tr, (unsigned)c) : 0.0;
       wave_sync();
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
       for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
       nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
     }
-    const double zc = vc ? (zin ? zin[(size_t)t * d + c] : zq[16 * ((T - 1 - t) & 3) + c]) : 0.0;
+    const double zc = (vc && !EXP) ? (zin ? zin[(size_t)t * d + c] : zq[16 * ((T - 1 - t) & 3) + c]) : 0.0;
     if (a.w_tstride) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wt[r] = va[r] ? (W0 + (size_t)t * a.w_tstride)[4 * r + g + c * d] : 0.0;
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     if (thout && g == 0 && vc) thout[(size_t)t * d + c] = th;
     wave_sync();
   }
-  if (__ballot(vc && !isfinite(thv[c])) != 0ull) st |= DLM_ST_NONFINITE;
+  if (!EXP && __ballot(vc && !isfinite(thv[c])) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.stats) {
     const int L = stats_len(d, p, a.flags);
     double* so = a.stats + (size_t)n * L;
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
     q[4] = lds_read128<64>(base); q[5] = lds_read128<80>(base); q[6] = lds_read128<96>(base); q[7] = lds_read128<112>(base);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])::"memory");
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { dst[2 * k] = vc ? q[k][0] : 0.0; dst[2 * k + 1] = vc ? q[k][1] : 0.0; }
+    for (int k = 0; k < 8; ++k) { dst[2 * k] = q[k][0]; dst[2 * k + 1] = q[k][1]; }   // (a lane beyond d holds component 0's: finite, and what it computes is never used)
   };
   auto read_row = [&](unsigned slot, bool withJ) {
     const unsigned base = slot + (vc ? c : 0) * (SF_ENT * 8);
@@ -641,8 +649,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
   auto draw = [&](double hcol, const double* zk) {
     double th = hcol;
 #pragma unroll
-    for (int k = 0; k < 15; ++k)
-      if (k < d) th = fma(Lr[k], zk[16 * j + k], th);
+    for (int k = 0; k < 15; ++k) th = fma(Lr[k], zk[16 * j + k], th);   // L[c][k] = 0 for k > c and for k >= d: those terms add nothing
     return vc ? th : 0.0;
   };
 
@@ -993,7 +1000,7 @@ static hipError_t launch_rts_t(const KArgs& a, int K, const Tab* tabs_dev, hipSt
 }
 // ---- shared factors ------------------------------------------------------------------------------------------------------------
 #ifndef DLM_SAMPLER_SHARED_MIN
-#define DLM_SAMPLER_SHARED_MIN 2560   // series from which the table pays: below, every series' own wave is resident at once and takes as long as the table's
+#define DLM_SAMPLER_SHARED_MIN 1   // (measured, tools/sweep_c3.sh: the table pays at every batch size -- its stretches are made side by side, a series' own wave makes them one after the other)
 #endif
 bool sampler_shared_eligible(const KArgs& a) {
   const size_t rec = (size_t)a.d + (size_t)a.d * a.d;
@@ -1027,11 +1034,12 @@ hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* ta
   if ((err = launch_sparse16_filter(kf, K, tabs_dev, nullptr, nullptr, s)) != hipSuccess) return err;
   KArgs kp = kf;
   kp.y = nullptr; kp.filt_in = tb.zrec;
+  const dim3 grid((a.T + s16::SF_STRETCH - 1) / s16::SF_STRETCH);   // one wave per stretch
   switch (K) {
-    case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
-    case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
-    case 3: hipLaunchKernelGGL((s16::k_sampler_sp16<3, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
-    case 4: hipLaunchKernelGGL((s16::k_sampler_sp16<4, SparseT, true>), dim3(1), dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 3: hipLaunchKernelGGL((s16::k_sampler_sp16<3, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 4: hipLaunchKernelGGL((s16::k_sampler_sp16<4, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

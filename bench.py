@@ -356,14 +356,16 @@ def run_one(args, ctx):
                 return c
         comm_world = world
         sim = args.sampler == "simsmooth"
+        extra = flags
+        ffbs = (lambda *a_, flags=0, **k_: eng.ffbs(*a_, flags=flags | extra, **k_)) if extra else None   # --flags: A/B runs of the FFBS call
         if cfg == "c3":
             chain = GibbsSampling.sample(mod, InverseGamma(5.0, 4.0), InverseGamma(17.0, 4.0), p, mat.times, y, eng,
                                          n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
-                                         allreduce=allreduce, simulation_smoother=sim)   # priors: SeasonalModel.scala:127
+                                         allreduce=allreduce, simulation_smoother=sim, ffbs=ffbs)   # priors: SeasonalModel.scala:127
         else:
             chain = GibbsWishart.sample(mod, InverseGamma(5.0, 4.0), InverseWishart(d + 2.0, np.eye(d)), p, mat.times, y, eng,
                                         n_iter=steps + warmup, seed=7, pooled=True, series_offset=lo,
-                                        allreduce=allreduce, simulation_smoother=sim)
+                                        allreduce=allreduce, simulation_smoother=sim, ffbs=ffbs)
         last = {}
 
         def step():

@@ -176,7 +176,7 @@ def test_c3_full_size_ffbs_properties(eng):
 
 def test_c3_full_size_reference_form_sampler(eng):
     """BASELINE configs[2] with the reference's backward sampler (Smoothing.sampleDlm, the default of dlm_ffbs_batch): 10 000
-    series x T = 1000 on the register-tile kernel with its steady-state reuse of J, H and the factor.  The same seed reproduces the
+    series x T = 1000 on the shared-factor path (the table of one wave per stretch, the mean-only draw kernel).  The same seed reproduces the
     draw, a shard with series_offset draws the same states, a few series equal the generic kernel's draws (the reference's
     operation sequence in LDS) at full length, and the statistics are those of the states."""
     import torch
@@ -185,8 +185,11 @@ def test_c3_full_size_reference_form_sampler(eng):
     mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
     y = torch.as_tensor(simulate(mat, p, 10000, seed=78), device="cuda")
     a = eng.ffbs(mat, p, y, seed=11)
-    assert eng.last_variant == "sparse16-sampler" and int((a["status"] != 0).sum().item()) == 0
+    assert eng.last_variant == "sparse16-sampler-shared" and int((a["status"] != 0).sum().item()) == 0   # J_t, H_t, chol(H_t) once per call
     b = eng.ffbs(mat, p, y, seed=11)
+    assert torch.equal(a["theta"], b["theta"]) and torch.equal(a["stats"], b["stats"])
+    b = eng.ffbs(mat, p, y, seed=11, flags=_lib.OPT_SAMPLER_PER_SERIES)     # every series its own factors: the same draws, bit for bit
+    assert eng.last_variant == "sparse16-sampler"
     assert torch.equal(a["theta"], b["theta"]) and torch.equal(a["stats"], b["stats"])
     lo, hi = 6250, 7500                                    # rank 5 of 8
     c = eng.ffbs(mat, p, y[lo:hi], seed=11, series_offset=lo)

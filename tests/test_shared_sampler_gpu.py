@@ -17,7 +17,7 @@ from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
 pytestmark = pytest.mark.gpu
 
 W_C2 = np.array([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4])
-SMALL = _lib.OPT_NO_SMALL_BATCH          # the table also for batches below the size from which it pays
+SMALL = 0
 
 
 @pytest.fixture(scope="module")
@@ -142,8 +142,8 @@ def test_without_statistics_without_draws_and_what_falls_back(eng):
     same(sh, ps)
     sh, ps, _ = both(eng, mat, p, y, want_theta=False)
     same(sh, ps)
-    eng.ffbs(mat, p, y, flags=_lib.OPT_COUNT_STEPS)                      # a small batch: every series its own wave, all resident at once
-    assert eng.last_variant == "sparse16-sampler" and eng.last_counters()[2] == 0
+    eng.ffbs(mat, p, y, flags=_lib.OPT_COUNT_STEPS)                      # the default at every batch size (tools/sweep_c3.sh)
+    assert eng.last_variant == "sparse16-sampler-shared" and eng.last_counters()[2] == N
     eng.ffbs(mat, p, y, flags=SMALL | _lib.OPT_COUNT_STEPS, want_cond=True)      # conditional-moment records: H_t is not in the table
     assert eng.last_variant == "sparse16-sampler"
     plist = [DlmParameters(p.v * (1 + 0.1 * n), p.w, p.m0, p.c0) for n in range(N)]
