@@ -452,8 +452,8 @@ int ensure_cov_stream(dlm_engine* e) {
 }
 // Shared factors of the reference-form backward sampler (dlm_sampler16.hip): the tables are made on the second
 // stream -- a filter and a sampler run of ONE wave on a series of zeros -- while the batch is filtered on the first.
-int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb) {
-  const size_t need = dlm::sampler_shared_ws_bytes(k);
+int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big) {
+  const size_t need = big ? dlm::wave48_sampler_shared_ws_bytes(k) : dlm::sampler_shared_ws_bytes(k);
   if (need > e->sampws_bytes) {
     if (e->sampws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->sampws)); e->sampws = nullptr; e->sampws_bytes = 0; }
     HIP_TRY(e, hipMalloc(&e->sampws, need));
@@ -461,10 +461,11 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb) {
   }
   int rc = ensure_route(e, (size_t)k.N);
   if (rc || (rc = ensure_cov_stream(e))) return rc;
-  dlm::sampler_shared_carve(e->sampws, k, tb);
+  if (big) dlm::wave48_sampler_shared_carve(e->sampws, k, tb); else dlm::sampler_shared_carve(e->sampws, k, tb);
   HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));               // the model and the tables of G are staged
   HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
-  HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
+  if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_tables(k, tb, e->cov_stream));
+  else HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
   HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
   return DLM_OK;
 }
@@ -1031,7 +1032,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
   const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
-  bool shared_factors = false;
+  bool shared_factors = false, shared_big = false;
   dlm::SampTabs stb{};
   // a V_t stream is a scalar per step on the structured d <= 15, p = 1 path (the Student-t DLM, StudentTGibbs.scala:100-136)
   // and goes through; W_t streams and V_t elsewhere would need a factorisation per step
@@ -1078,7 +1079,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     }
     if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need a fast path (structured d <= 15 or 16 <= d <= 48)");
     shared_factors = !simflag && !use_lane(k) && fast_shape_ok(k) && e->sparse_k > 0 && dlm::sampler_shared_eligible(k);
-    if (shared_factors && (rc = start_sampler_tables(e, k, stb))) return rc;
+    shared_big = !simflag && !shared_factors && use_tiled(k) && dlm::wave48_sampler_shared_eligible(k);   // 16 <= d <= 48 on the per-wave kernels
+    if ((shared_factors || shared_big) && (rc = start_sampler_tables(e, k, stb, shared_big))) return rc;
     if ((rc = run_filter(e, k, false))) return rc;
     k.filt_in = k.filt;
   }
@@ -1107,6 +1109,13 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if (!(k.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16)) && dlm::wave48_small_ok(k)) {
     e->variant = "sparse16-sampler";
     HIP_TRY(e, dlm::launch_small_mv_sampler(k, e->stream));
+    return done();
+  }
+  if (shared_big) {
+    e->variant = "wave-sampler-shared";
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));
+    k.route = e->route;
+    HIP_TRY(e, dlm::launch_wave48_sampler_shared_draw(k, stb, e->stream));
     return done();
   }
   if (!(k.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16)) && dlm::wave48_sampler_supported(k)) {

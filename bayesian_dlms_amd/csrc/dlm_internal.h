@@ -127,6 +127,13 @@ hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* ta
 // a.route [N] is filled here (series with a missing observation), the mean-only kernel draws for the others, k_sampler_sp16 for these
 hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
 
+// the same for 16 <= d <= 48 (dlm_wave48.hip): rows of 64 x (4 DT^2 + 16 DT) doubles, per lane [ J^T tiles | row `lane` of L ]
+bool wave48_sampler_shared_eligible(const KArgs& a);
+size_t wave48_sampler_shared_ws_bytes(const KArgs& a);
+void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
+hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s);
+hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb, hipStream_t s);
+
 // ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------
 // Nonzeros of the rows (`rows`) and of the columns (`cols`) of a d x d G with at most 4 per row and column (every
 // model the reference can build): the congruences G C G^T and G^T M G are then two gather passes instead of two

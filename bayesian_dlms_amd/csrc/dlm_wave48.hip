@@ -1879,15 +1879,36 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-template <int DT, int K, bool OUTER>
-__global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
+// Shared factors (dlm_sampler16.hip has the d <= 15 form).  EXP: the series is the one series of zeros, workgroup b
+// makes the table rows of stretch b -- per step computed in full, per lane [ J^T tiles (4 DT^2) | row `lane` of L (16 DT, zero
+// beyond the diagonal) ] and SampTabs::need[t] = 1; a step taken in the steady form leaves need[t] = 0.
+constexpr int WS_STRETCH = 32;             // steps t with t % WS_STRETCH == WS_STRETCH - 1 start from scratch (every series, see dlm_sampler16.hip)
+constexpr int ws_row_doubles(int DT) { return 64 * (4 * DT * DT + 16 * DT); }
+
+template <int DT, int K, bool OUTER, bool EXP = false>
+__global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
+  if (!EXP && a.route && (a.route[blockIdx.x] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int IL = 16 * DT + 1, IMG = 16 * DT * IL, VL = 16 * DT, ND = 16 * DT;
   double* img = sm;       double* keep = sm + IMG;      // keep: direct-inverse scratch; afterwards L (lower + diagonal) and C (strict upper)
   double* mv = keep + IMG; double* thv = mv + VL; double* uv = thv + VL; double* hv = uv + VL; double* zv = hv + VL; double* cdv = zv + VL;
-  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int n = EXP ? 0 : blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
+  const int t_lo = EXP ? (int)blockIdx.x * WS_STRETCH : 0;
+  const int t_hi = EXP ? ((t_lo + WS_STRETCH < T ? t_lo + WS_STRETCH : T) - 1) : T - 1;
   for (int i = lane; i < 6 * VL; i += 64) mv[i] = 0.0;
+  // EXP: row t of the table from the J^T tiles (nullptr: none, the step of theta_T) and the factor in `keep`
+  auto export_row = [&](int t, const d4 (*JT)[DT]) {
+    double* row = tb.rows + (size_t)t * ws_row_doubles(DT) + lane * (4 * DT * DT + 16 * DT);
+#pragma unroll
+    for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+      for (int b = 0; b < DT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[(aa * DT + b) * 4 + r] = JT ? JT[aa][b][r] : 0.0;
+    for (int k = 0; k < ND; ++k) row[4 * DT * DT + k] = (lane < d && k <= lane) ? keep[lane * IL + k] : 0.0;
+    if (lane == 0) tb.need[t] = 1;
+  };
 
   bool jd[DT];
   int cpart[DT], moff[DT];
@@ -2020,15 +2041,16 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
   int n_reuse = 0;      // diagnostic build: steps that took the steady-state path, reported in status[n] >> 8
 #endif
 
-  {   // theta_T ~ N(m_T, C_T)
+  if (!EXP || t_hi == T - 1) {   // theta_T ~ N(m_T, C_T)
     d4 C[DT][DT];
     load_record(C, T, g, c);
     to_image<IL, DT, DT>(C, keep, g, c);
-    if (lane < ND) { zv[lane] = lane < d ? (zin ? zin[(size_t)T * d + lane] : philox_normal(a.seed, series, (unsigned)T, (unsigned)lane)) : 0.0; }
+    if (lane < ND) { zv[lane] = (lane < d && !EXP) ? (zin ? zin[(size_t)T * d + lane] : philox_normal(a.seed, series, (unsigned)T, (unsigned)lane)) : 0.0; }
     wave_sync();
     if (lane < ND) hv[lane] = mv[lane];
     if (chol_rows(keep, d, IL, lane)) st |= DLM_ST_NOT_PD;   // once per series: the in-LDS factorisation (psd pivots: see below)
     wave_sync();
+    if constexpr (EXP) { export_row(T, nullptr); wave_sync(); }
     if (cond) store_cond(C, T, g, c);
     const double th = draw();
     wave_sync();
@@ -2037,7 +2059,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
     wave_sync();
   }
 
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = t_hi; t >= t_lo; --t) {
     int g_ = g, c_ = c;
     asm volatile("" : "+v"(g_), "+v"(c_));
     {
@@ -2045,6 +2067,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
+    if ((t & (WS_STRETCH - 1)) == WS_STRETCH - 1) { have = false; warm = false; }   // a stretch starts from scratch: nothing a step computes depends on the steps above its stretch
     if (a.stats && y && lane < p) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
       const double yv = y[(size_t)t * p + lane];
       if (yv == yv) {
@@ -2054,7 +2077,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
         ssy += (yv - f) * (yv - f); nob += 1.0;
       }
     }
-    if (lane < ND) zv[lane] = lane < d ? (zin ? zin[(size_t)t * d + lane] : philox_normal(a.seed, series, (unsigned)t, (unsigned)lane)) : 0.0;
+    if (lane < ND) zv[lane] = (lane < d && !EXP) ? (zin ? zin[(size_t)t * d + lane] : philox_normal(a.seed, series, (unsigned)t, (unsigned)lane)) : 0.0;
     // steady state: C against the copy kept from the last full step (strict upper triangle of `keep`, diagonal in cdv)
     bool reuse = false;
     {
@@ -2102,6 +2125,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) JTl[aa][b][r] = img[(16 * aa + 4 * r + g) * IL + 16 * b + c];
       matTvec<DT, DT>(JTl, uv, g, hc);
+      if constexpr (EXP) { if (lane == 0) tb.need[t] = 0; }
     } else {
       // R+ = G C G^T + W dt on a copy of C (the congruence works in place), exactly symmetric.  C itself is fetched again
       // when it is next needed (the record is in L2): holding it across the inverse costs 24 registers per tile.
@@ -2214,6 +2238,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
       to_image<IL, DT, DT>(H, img, g, c);
       wave_sync();
       factor_to_keep();
+      if constexpr (EXP) export_row(t, JT);
       have = true; gprev = gi; dtprev = dt;
       wave_sync();
       to_image<IL, DT, DT>(JT, img, g, c);                // J^T stays in the image for the steady-state steps that follow
@@ -2269,7 +2294,8 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
     wave_sync();
     }
   }
-  if (__ballot(lane < d && !isfinite(thv[lane < ND ? lane : 0])) != 0ull) st |= DLM_ST_NONFINITE;
+  if (!EXP && __ballot(lane < d && !isfinite(thv[lane < ND ? lane : 0])) != 0ull) st |= DLM_ST_NONFINITE;
+  if (!EXP && a.route && a.counters && lane == 0) atomicAdd(&a.counters[3], 1ull);   // a series of a shared-factor call that computed its own
   if (a.stats) {
     const int L = stats_len(d, p, a.flags);
     double* so = a.stats + (size_t)n * L;
@@ -2294,6 +2320,215 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a) {
   st |= n_reuse << 8;
 #endif
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The draw against the shared factors, 16 <= d <= 48: one wave per series, k_sampler_w48's steady-state step with nothing of the
+// covariances left in it -- no record of C_t is read (the filtered mean alone, 8 d of the 8 (d + d^2) bytes), J^T lives in registers
+// (the per-series kernel re-reads it from its image every step), the factor's row `lane` too, F in LDS (the per-series kernel
+// reads it from memory in a dependent chain), two steps' normals per Philox / Box-Muller pass.  The operations on the data are
+// k_sampler_w48's, one for one: gather_vec, matTvec, the draw's chain over the pivots (terms beyond the diagonal are zeros of the
+// table: they add nothing), the residual sums in its order.  LDS per wave: F and seven vectors -- no images.
+// ---------------------------------------------------------------------------------------
+template <int DT, int K, bool OUTER>
+__global__ __launch_bounds__(64, 2) void k_mean_sampler_w48(KArgs a, SampTabs tb) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int VL = 16 * DT, ND = 16 * DT, RW = 4 * DT * DT + 16 * DT;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  if (a.route[n] != 0) return;                      // a series with a missing observation: k_sampler_w48 serves it
+  const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8, FLD = d + 1;
+  double* mv = sm; double* thv = mv + VL; double* uv = thv + VL; double* hv = uv + VL; double* zv = hv + VL;   // zv: two steps' normals, [t & 1][VL]
+  double* Ll = zv + 2 * VL;                         // the factor, lower triangle by rows: L[i][k] at i (i + 1) / 2 + k
+  double* Fl = Ll + (ND * (ND + 1)) / 2;            // F by observation component: Fl[j * FLD + k] = F[k][j]
+  for (int i = lane; i < 6 * VL; i += 64) mv[i] = 0.0;
+  const bool stats = a.stats != nullptr, obs = stats && a.y;
+  if (obs) for (int i = lane; i < p * d; i += 64) Fl[(i / d) * FLD + i % d] = a.F[i];
+  bool jd[DT];
+#pragma unroll
+  for (int b = 0; b < DT; ++b) jd[b] = 16 * b + c < d;
+  int rix[DT][K];
+  double rvl[DT][K];
+  {
+    const SparseBig* tr = a.spb;                    // rows of G (time-invariant: the only table)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int s = 0; s < K; ++s) { rix[b][s] = tr->idx[16 * b + c][s]; rvl[b][s] = jd[b] ? tr->val[16 * b + c][s] : 0.0; }
+  }
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const int moff = lane < d ? lane * 8 : OOB;
+  double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
+  const double* y = obs ? a.y + (size_t)n * T * p : nullptr;
+  const double* zin = a.z ? a.z + (size_t)n * (T + 1) * d : nullptr;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+
+  d4 JT[DT][DT];
+#pragma unroll
+  for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+    for (int b = 0; b < DT; ++b) JT[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+  const int loff = (lane * (lane + 1)) / 2;
+  auto load_row = [&](int t, bool withJ) {
+    const double* row = tb.rows + (size_t)t * ws_row_doubles(DT) + lane * RW;
+    if (withJ) {
+#pragma unroll
+      for (int aa = 0; aa < DT; ++aa)
+#pragma unroll
+        for (int b = 0; b < DT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) JT[aa][b][r] = row[(aa * DT + b) * 4 + r];
+    }
+    if (lane < d) for (int k = 0; k <= lane; ++k) Ll[loff + k] = row[4 * DT * DT + k];
+  };
+  // the normals of steps tb_ (lanes 0..31) and tb_ - 1 (lanes 32..63): lane q of a half makes components 2 q and 2 q + 1
+  auto normals2 = [&](int tb_) {
+    const int te = tb_ - (lane >> 5), q = lane & 31;
+    if (te >= 0 && 2 * q < ND) {
+      double ze = 0.0, zo = 0.0;
+      if (2 * q < d) philox_normal2(a.seed, series, (unsigned)te, (unsigned)q, ze, zo);
+      double* zr = zv + (te & 1) * VL + 2 * q;
+      zr[0] = ze; zr[1] = (2 * q + 1 < d) ? zo : 0.0;
+    }
+  };
+  auto draw = [&](const double* zk) {                // theta = h + L z: hv holds h
+    double th = 0.0;
+    if (lane < d) {
+      th = hv[lane];
+      const double* Lr = Ll + loff;
+      for (int k = 0; k <= lane; ++k) th = fma(Lr[k], zk[k], th);
+    }
+    return th;
+  };
+  unsigned long long nmask = 0;
+  auto need_of = [&](int s_) -> bool {
+    if (s_ < 0) return false;
+    if (s_ == T || (s_ & 63) == 63) { const int b = (s_ & ~63) + lane; nmask = __ballot(b <= T && tb.need[b] != 0); }
+    return ((nmask >> (s_ & 63)) & 1ull) != 0;
+  };
+  (void)need_of(T);
+  double mnext;
+  {   // theta_T = m_T + chol(C_T) z_T
+    const double mT = bld(rin, moff, T * recb);
+    mnext = bld(rin, moff, (T > 0 ? T - 1 : 0) * recb);
+    load_row(T, false);
+    if (zin) { if (lane < ND) zv[(T & 1) * VL + lane] = lane < d ? zin[(size_t)T * d + lane] : 0.0; }
+    else { if (lane < ND) zv[(T & 1) * VL + lane] = lane < d ? philox_normal(a.seed, series, (unsigned)T, (unsigned)lane) : 0.0; }
+    if (lane < ND) hv[lane] = lane < d ? mT : 0.0;
+    wave_sync();
+    const double th = draw(zv + (T & 1) * VL);
+    wave_sync();
+    if (lane < ND) thv[lane] = th;
+    if (thout && lane < d) thout[(size_t)T * d + lane] = th;
+    if (!zin) normals2(T - 1);                       // steps T - 1 and T - 2
+    wave_sync();
+  }
+  d4 OUT[OUTER ? DT : 1][OUTER ? DT : 1];
+#pragma unroll
+  for (int aa = 0; aa < (OUTER ? DT : 1); ++aa)
+#pragma unroll
+    for (int b = 0; b < (OUTER ? DT : 1); ++b) OUT[aa][b] = d4{0.0, 0.0, 0.0, 0.0};
+  double ssd[DT];
+#pragma unroll
+  for (int b = 0; b < DT; ++b) ssd[b] = 0.0;
+  double ssy = 0.0, nob = 0.0;
+  double ynext = (y && lane < p && T > 0) ? y[(size_t)(T - 1) * p + lane] : 0.0;
+  for (int t = T - 1; t >= 0; --t) {
+    const bool nd = need_of(t);
+    const double yv = ynext, mc = mnext;
+    if (t > 0) {
+      mnext = bld(rin, moff, (t - 1) * recb);
+      if (y && lane < p) ynext = y[(size_t)(t - 1) * p + lane];
+    }
+    if (obs && lane < p && yv == yv) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
+      const double* Fj = Fl + lane * FLD;
+      double f = 0.0;
+      for (int k = 0; k < d; ++k) f = fma(Fj[k], thv[k], f);
+      ssy += (yv - f) * (yv - f); nob += 1.0;
+    }
+    if (zin) { if (lane < ND) zv[(t & 1) * VL + lane] = lane < d ? zin[(size_t)t * d + lane] : 0.0; }
+    if (nd) load_row(t, true);
+    if (lane < ND) mv[lane] = mc;
+    wave_sync();
+    double a1[DT];
+    gather_vec<DT, K>(mv, rix, rvl, a1);
+    if (g == 0) {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) uv[16 * b + c] = jd[b] ? thv[16 * b + c] - a1[b] : 0.0;
+    }
+    wave_sync();
+    double hc[DT];
+    matTvec<DT, DT>(JT, uv, g, hc);
+    if (g == 0) {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) hv[16 * b + c] = jd[b] ? mv[16 * b + c] + hc[b] : 0.0;      // h = m + J (theta+ - a+)
+    }
+    wave_sync();
+    const double th = draw(zv + (t & 1) * VL);
+    wave_sync();
+    if (lane < ND) hv[lane] = th;                     // hv <- theta_t
+    wave_sync();
+    if (stats) {   // system residual theta_{t+1} - G theta_t
+      double gth[DT];
+      gather_vec<DT, K>(hv, rix, rvl, gth);
+      double df[DT];
+#pragma unroll
+      for (int b = 0; b < DT; ++b) { df[b] = jd[b] ? thv[16 * b + c] - gth[b] : 0.0; ssd[b] += df[b] * df[b]; }
+      if (OUTER) {
+        if (g == 0) {
+#pragma unroll
+          for (int b = 0; b < DT; ++b) uv[16 * b + c] = df[b];
+        }
+        wave_sync();
+#pragma unroll
+        for (int aa = 0; aa < (OUTER ? DT : 1); ++aa)
+#pragma unroll
+          for (int b = 0; b < (OUTER ? DT : 1); ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) OUT[aa][b][r] += uv[16 * aa + 4 * r + g] * df[b];
+      }
+    }
+    wave_sync();
+    if (lane < ND) thv[lane] = hv[lane];
+    if (thout && lane < d) thout[(size_t)t * d + lane] = th;
+    if (!zin && ((T - 1 - t) & 1) == 1) normals2(t - 1);   // the normals of steps t - 1 and t - 2
+    wave_sync();
+  }
+  int st = tb.status[0];
+  if (__ballot(lane < d && !isfinite(thv[lane < ND ? lane : 0])) != 0ull) st |= DLM_ST_NONFINITE;
+  if (stats) {
+    const int L = stats_len(d, p, a.flags);
+    double* so = a.stats + (size_t)n * L;
+    if (lane < p) { so[lane] = ssy; so[p + lane] = nob; }
+    if (lane == 0) so[L - 1] = (double)T;
+    if (OUTER) {
+#pragma unroll
+      for (int aa = 0; aa < (OUTER ? DT : 1); ++aa)
+#pragma unroll
+        for (int b = 0; b < (OUTER ? DT : 1); ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * aa + 4 * r + g, j = 16 * b + c;
+            if (i < d && j < d) so[2 * p + i + j * d] = OUT[aa][b][r];
+          }
+    } else if (g == 0) {
+#pragma unroll
+      for (int b = 0; b < DT; ++b) if (jd[b]) so[2 * p + 16 * b + c] = ssd[b];
+    }
+  }
+  if (a.counters && lane == 0) atomicAdd(&a.counters[2], 1ull);
+  if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+// route[n] = 1: series n has a missing observation component
+__global__ __launch_bounds__(256) void k_mark_gaps_w48(const double* __restrict__ y, int N, int Tp, unsigned char* __restrict__ route) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const double* yn = y + (size_t)n * Tp;
+  bool gap = false;
+  for (int t = lane; t < Tp; t += 64) { const double v = yn[t]; gap |= !(v == v); }
+  const bool any = __ballot(gap) != 0ull;
+  if (lane == 0) route[n] = any ? 1 : 0;
 }
 
 }  // namespace w48
@@ -2438,17 +2673,88 @@ static hipError_t launch_w48_sampler_k(const KArgs& a, int K, hipStream_t s) {
   const size_t lds = sizeof(double) * (size_t)(2 * 16 * DT * (16 * DT + 1) + 6 * 16 * DT);
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0 && a.stats;
   if (K <= 2) {
-    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, true>), dim3(a.N), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, false>), dim3(a.N), dim3(64), lds, s, a);
+    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, true>), dim3(a.N), dim3(64), lds, s, a, SampTabs{});
+    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, false>), dim3(a.N), dim3(64), lds, s, a, SampTabs{});
   } else {
-    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, true>), dim3(a.N), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, false>), dim3(a.N), dim3(64), lds, s, a);
+    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, true>), dim3(a.N), dim3(64), lds, s, a, SampTabs{});
+    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, false>), dim3(a.N), dim3(64), lds, s, a, SampTabs{});
   }
   return hipGetLastError();
 }
 hipError_t launch_wave48_sampler(const KArgs& a, hipStream_t s) {
   if (a.d <= 32) return launch_w48_sampler_k<2>(a, a.spb_k, s);
   return launch_w48_sampler_k<3>(a, a.spb_k, s);
+}
+
+// ---- shared factors: regular grid, time-invariant F / V / W, V, W, C0 shared by the batch -------------------------
+bool wave48_sampler_shared_eligible(const KArgs& a) {
+  const size_t rec = (size_t)a.d + (size_t)a.d * a.d;
+  return wave48_sampler_supported(a) && a.d >= 16 && wave48_filter_supported(a) && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride &&
+         !a.v_stride && !a.w_stride && !a.c0_stride && !a.cond && !a.packed && a.filt && (!a.stats || a.y) && a.T >= 1 && a.T <= 100000 &&
+         !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16 | DLM_OPT_SAMPLER_PER_SERIES)) && ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);
+}
+static size_t up64w(size_t x) { return (x + 63) & ~(size_t)63; }
+static int ws_dt(const KArgs& a) { return a.d <= 32 ? 2 : 3; }
+size_t wave48_sampler_shared_ws_bytes(const KArgs& a) {
+  const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d, zn = (size_t)a.T * a.p > 64 ? (size_t)a.T * a.p : 64;
+  return up64w(n1 * w48::ws_row_doubles(ws_dt(a)) * 8) + up64w(n1 * rec * 8) + up64w(zn * 8) + up64w(n1) + 64;
+}
+void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb) {
+  const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d, zn = (size_t)a.T * a.p > 64 ? (size_t)a.T * a.p : 64;
+  char* p = (char*)ws;
+  tb.rows = (double*)p;  p += up64w(n1 * w48::ws_row_doubles(ws_dt(a)) * 8);
+  tb.zrec = (double*)p;  p += up64w(n1 * rec * 8);
+  tb.zeros = (double*)p; p += up64w(zn * 8);
+  tb.need = (unsigned char*)p; p += up64w(n1);
+  tb.status = (int*)p;
+}
+template <int DT>
+static void launch_w48_tables_k(const KArgs& kp, const SampTabs& tb, hipStream_t s) {
+  const size_t lds = sizeof(double) * (size_t)(2 * 16 * DT * (16 * DT + 1) + 6 * 16 * DT);
+  const dim3 grid((kp.T + w48::WS_STRETCH - 1) / w48::WS_STRETCH);   // one wave per stretch
+  if (kp.spb_k <= 2) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, false, true>), grid, dim3(64), lds, s, kp, tb);
+  else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, false, true>), grid, dim3(64), lds, s, kp, tb);
+}
+hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s) {
+  const size_t zn = (size_t)a.T * a.p > 64 ? (size_t)a.T * a.p : 64;
+  hipError_t err = hipMemsetAsync(tb.zeros, 0, zn * 8, s);
+  if (err != hipSuccess) return err;
+  if ((err = hipMemsetAsync(tb.status, 0, sizeof(int), s)) != hipSuccess) return err;
+  KArgs kf = a;   // the filter on a series of zeros: the covariances of every series without a missing observation, bit for bit
+  kf.N = 1; kf.y = tb.zeros; kf.m0 = tb.zeros; kf.m0_stride = 0; kf.filt = tb.zrec; kf.status = tb.status; kf.stats = nullptr; kf.loglik = nullptr;
+  kf.prior = nullptr; kf.fq = nullptr; kf.route = nullptr; kf.counters = nullptr; kf.theta = nullptr; kf.z = nullptr; kf.series_offset = 0;
+  kf.flags |= DLM_OPT_FORCE_WAVE;   // the kernel family that filters the batch, whatever the batch size
+  if ((err = launch_wave48_filter(kf, kf.spb_k, nullptr, s)) != hipSuccess) return err;
+  KArgs kp = kf;
+  kp.y = nullptr; kp.filt_in = tb.zrec;
+  if (a.d <= 32) launch_w48_tables_k<2>(kp, tb, s); else launch_w48_tables_k<3>(kp, tb, s);
+  return hipGetLastError();
+}
+template <int DT>
+static void launch_w48_mean_k(const KArgs& a, const SampTabs& tb, hipStream_t s) {
+  const size_t lds = sizeof(double) * (size_t)(6 * 16 * DT + (16 * DT * (16 * DT + 1)) / 2 + a.p * (a.d + 1));
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0 && a.stats;
+  if (a.spb_k <= 2) {
+    if (outer) hipLaunchKernelGGL((w48::k_mean_sampler_w48<DT, 2, true>), dim3(a.N), dim3(64), lds, s, a, tb);
+    else hipLaunchKernelGGL((w48::k_mean_sampler_w48<DT, 2, false>), dim3(a.N), dim3(64), lds, s, a, tb);
+  } else {
+    if (outer) hipLaunchKernelGGL((w48::k_mean_sampler_w48<DT, 4, true>), dim3(a.N), dim3(64), lds, s, a, tb);
+    else hipLaunchKernelGGL((w48::k_mean_sampler_w48<DT, 4, false>), dim3(a.N), dim3(64), lds, s, a, tb);
+  }
+}
+hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb, hipStream_t s) {
+  if (!a.route) return hipErrorInvalidValue;
+  hipError_t err;
+  if (a.y) hipLaunchKernelGGL(w48::k_mark_gaps_w48, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T * a.p, a.route);
+  else if ((err = hipMemsetAsync(a.route, 0, (size_t)a.N, s)) != hipSuccess) return err;
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  KArgs km = a;
+  km.route_take = 0;
+  if (a.d <= 32) launch_w48_mean_k<2>(km, tb, s); else launch_w48_mean_k<3>(km, tb, s);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  KArgs kg = a;   // the series with a missing observation: their own factors
+  kg.route_take = 1;
+  return launch_wave48_sampler(kg, s);
 }
 
 }  // namespace dlm

@@ -167,3 +167,61 @@ def test_device_resident_large_batch_is_shared_by_default(eng):
     ref = eng.ffbs(mat, p, y, seed=3, flags=_lib.OPT_SAMPLER_PER_SERIES)
     assert np.array_equal(dev["theta"].cpu().numpy(), ref["theta"], equal_nan=True)
     assert np.array_equal(dev["stats"].cpu().numpy(), ref["stats"], equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# 16 <= d <= 48 (dlm_wave48.hip): the multivariate models of the Inverse-Wishart Gibbs sampler (BASELINE configs[3])
+# ------------------------------------------------------------------------------------------------------------------------
+def blocks(nblk, T, seed, per=2):
+    mod = Dlm.polynomial(per)
+    for _ in range(nblk - 1):
+        mod = mod * Dlm.polynomial(per)
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    d, q = mat.d, mat.p
+    A = np.random.default_rng(seed).standard_normal((d, d))
+    return mat, DlmParameters(np.eye(q) * 1.1, A @ A.T / d + 0.1 * np.eye(d), np.zeros(d), np.eye(d))
+
+
+def both_big(eng, mat, p, y, flags=0, **kw):
+    sh = eng.ffbs(mat, p, y, flags=flags | _lib.OPT_COUNT_STEPS, **kw)
+    cnt = eng.last_counters()
+    assert eng.last_variant == "wave-sampler-shared"
+    ps = eng.ffbs(mat, p, y, flags=flags | _lib.OPT_SAMPLER_PER_SERIES | _lib.OPT_COUNT_STEPS, **kw)
+    assert eng.last_variant == "wave-sampler"
+    assert eng.last_counters()[2:] == (0, 0)
+    return sh, ps, cnt
+
+
+@pytest.mark.parametrize("nblk,T,N,flags", [(20, 130, 6, _lib.OPT_STATS_OUTER), (20, 70, 5, 0), (10, 65, 9, _lib.OPT_STATS_OUTER), (16, 33, 4, _lib.OPT_STATS_OUTER),
+                                            (8, 1, 3, 0), (8, 2, 3, _lib.OPT_STATS_OUTER), (24, 40, 3, _lib.OPT_STATS_OUTER)])
+def test_multivariate_draw_for_draw_the_per_series_kernel(eng, nblk, T, N, flags):
+    """d = 2 nblk, p = nblk (d = 40, p = 20 is C4): two and three tiles per dimension, diagonal and outer-product statistics, one
+    series with a missing component (its own factors, k_sampler_w48)."""
+    mat, p = blocks(nblk, T, seed=nblk)
+    rng = np.random.default_rng(nblk + T)
+    y = rng.standard_normal((N, T, mat.p)).cumsum(axis=1) * 0.5 + rng.standard_normal((N, T, mat.p))
+    if N > 3:
+        y[2, T // 2, 3] = np.nan
+    sh, ps, cnt = both_big(eng, mat, p, y, flags=flags, seed=5, series_offset=3)
+    ngap = 1 if N > 3 else 0
+    assert cnt[2] == N - ngap and cnt[3] == ngap, cnt
+    same(sh, ps)
+    assert np.all(sh["status"] == 0) and np.isfinite(sh["stats"]).all()
+
+
+def test_multivariate_injected_normals_against_the_oracle(eng):
+    T, N = 60, 3
+    mat, p = blocks(10, T, seed=2)
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal((N, T, mat.p)).cumsum(axis=1)
+    z = rng.standard_normal((N, T + 1, mat.d))
+    sh, ps, cnt = both_big(eng, mat, p, y, z=z, flags=_lib.OPT_STATS_OUTER)
+    assert cnt[2] == N
+    same(sh, ps)
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[1])
+    o = oracle.backward_sample(omodel(mat), p.w, f, z[1], factor="chol")
+    np.testing.assert_allclose(sh["theta"][1], o["theta"], rtol=1e-7, atol=1e-8)
+    st = oracle.gibbs_stats(omodel(mat), y[1], sh["theta"][1], want_outer=True)
+    q = mat.p
+    np.testing.assert_allclose(sh["stats"][1][:q], st["ssy"], rtol=1e-9)
+    np.testing.assert_allclose(sh["stats"][1][2 * q:-1], st["outer"], rtol=1e-8, atol=1e-10)
