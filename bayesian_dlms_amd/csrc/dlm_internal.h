@@ -42,6 +42,8 @@ struct KArgs {
   int route_take;
   unsigned long long* counters;   // engine-owned [4], zeroed per call (nullable): steady (short) steps taken by the forward [0] / backward [1] kernel,
                                   // series served by the shared-covariance kernels [2], series sent to their own full recursion [3]
+  int* settle_step;               // the filter of the shared-factor tables' series of zeros (nullptr otherwise): the kernel stops when its covariance
+                                  // recursion has settled and leaves here the last record it wrote -- every later record would repeat that covariance
 };
 
 // Packed record of the structured fast path's internal workspaces: [m (d) | lower triangle of C by rows], padded to a
@@ -118,6 +120,7 @@ struct SampTabs {
   double* zeros;         // max(T, 16) zeros: its observations and initial mean
   unsigned char* need;   // [T+1] 1: row t was written (a full step); 0: the factors of the last row above it
   int* status;           // status of the zero series' two kernels, for every series served by the tables
+  int* settle;           // index of the last record of zrec that was written (KArgs::settle_step): the records above it repeat its covariance
 };
 bool sampler_shared_eligible(const KArgs& a);
 size_t sampler_shared_ws_bytes(const KArgs& a);

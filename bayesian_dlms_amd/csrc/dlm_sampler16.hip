@@ -1022,7 +1022,7 @@ void sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb) {
   tb.zrec = (double*)p;  p += up64(n1 * rec * 8);
   tb.zeros = (double*)p; p += up64((size_t)(a.T > 16 ? a.T : 16) * 8);
   tb.need = (unsigned char*)p; p += up64(n1);
-  tb.status = (int*)p;
+  tb.status = (int*)p; tb.settle = tb.status + 1;
 }
 hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s) {
   hipError_t err = hipMemsetAsync(tb.zeros, 0, (size_t)(a.T > 16 ? a.T : 16) * 8, s);

@@ -667,6 +667,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
     for (int b = 0; b < PT; ++b) missing_here |= jp[b] && !(ycur[b] == ycur[b]);
     bool all = __ballot(missing_here) == 0ull;             // every component of y_t observed
     if (__builtin_amdgcn_readfirstlane((int)(steady && all))) {
+      if (a.settle_step) { if (lane == 0) *a.settle_step = t; break; }   // the series of zeros of a shared-factor table: record t is the last one anyone needs
       // a stretch of steady steps as a loop of its own: one back edge, so that the wait for the next observation counts the
       // stores behind it (vmcnt(42)) -- at the head of the big loop, where two paths meet, it would be vmcnt(0): every step
       // would sit out the latency of its 39 record stores.  (The flags are read through readfirstlane: a branch the compiler
@@ -1882,11 +1883,19 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 // Shared factors (dlm_sampler16.hip has the d <= 15 form).  EXP: the series is the one series of zeros, workgroup b
 // makes the table rows of stretch b -- per step computed in full, per lane [ J^T tiles (4 DT^2) | row `lane` of L (16 DT, zero
 // beyond the diagonal) ] and SampTabs::need[t] = 1; a step taken in the steady form leaves need[t] = 0.
-constexpr int WS_STRETCH = 32;             // steps t with t % WS_STRETCH == WS_STRETCH - 1 start from scratch (every series, see dlm_sampler16.hip)
+// Stretches (every series, see dlm_sampler16.hip): 8 steps long below step 64, where the covariances are still moving and every
+// step is computed in full (~120 us at d = 40: the longest stretch is what a table waits for), 32 steps long above.
+constexpr int WS_STRETCH = 32, WS_SHORT = 8, WS_SHORT_END = 64;
+__host__ __device__ constexpr bool ws_stretch_top(int t) { return (t & (WS_STRETCH - 1)) == WS_STRETCH - 1 || (t < WS_SHORT_END && (t & (WS_SHORT - 1)) == WS_SHORT - 1); }
+__host__ __device__ constexpr int ws_stretches(int T) { return T <= WS_SHORT_END ? (T + WS_SHORT - 1) / WS_SHORT : WS_SHORT_END / WS_SHORT + (T - WS_SHORT_END + WS_STRETCH - 1) / WS_STRETCH; }
+__host__ __device__ constexpr int ws_stretch_lo(int b) { return b < WS_SHORT_END / WS_SHORT ? b * WS_SHORT : WS_SHORT_END + (b - WS_SHORT_END / WS_SHORT) * WS_STRETCH; }
 constexpr int ws_row_doubles(int DT) { return 64 * (4 * DT * DT + 16 * DT); }
 
-template <int DT, int K, bool OUTER, bool EXP = false>
+template <int DT, int K, bool OUTER>
 __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
+  // The table of a shared-factor call is made by THIS kernel (tb.rows set), not by an instantiation of its own: the series that
+  // compute their own factors and the table then run the same machine code, and what they compute agrees bit for bit by construction.
+  const bool EXP = tb.rows != nullptr;
   if (!EXP && a.route && (a.route[blockIdx.x] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int IL = 16 * DT + 1, IMG = 16 * DT * IL, VL = 16 * DT, ND = 16 * DT;
@@ -1894,8 +1903,9 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
   double* mv = keep + IMG; double* thv = mv + VL; double* uv = thv + VL; double* hv = uv + VL; double* zv = hv + VL; double* cdv = zv + VL;
   const int n = EXP ? 0 : blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
-  const int t_lo = EXP ? (int)blockIdx.x * WS_STRETCH : 0;
-  const int t_hi = EXP ? ((t_lo + WS_STRETCH < T ? t_lo + WS_STRETCH : T) - 1) : T - 1;
+  const int t_lo = EXP ? ws_stretch_lo((int)blockIdx.x) : 0;
+  const int t_nx = EXP ? ws_stretch_lo((int)blockIdx.x + 1) : T;
+  const int t_hi = (t_nx < T ? t_nx : T) - 1;
   for (int i = lane; i < 6 * VL; i += 64) mv[i] = 0.0;
   // EXP: row t of the table from the J^T tiles (nullptr: none, the step of theta_T) and the factor in `keep`
   auto export_row = [&](int t, const d4 (*JT)[DT]) {
@@ -1939,8 +1949,9 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
   const unsigned long long series = a.series_offset + (unsigned long long)n;
   int st = 0;
 
+  const int t_last = EXP ? tb.settle[0] : T;      // EXP: the records above this one were not written -- they repeat its covariance
   auto load_record = [&](d4 (&C)[DT][DT], int t, int g, int c) {
-    const int so = t * recb;
+    const int so = (EXP && t > t_last ? t_last : t) * recb;
 #pragma unroll
     for (int aa = 0; aa < DT; ++aa)
 #pragma unroll
@@ -2050,7 +2061,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
     if (lane < ND) hv[lane] = mv[lane];
     if (chol_rows(keep, d, IL, lane)) st |= DLM_ST_NOT_PD;   // once per series: the in-LDS factorisation (psd pivots: see below)
     wave_sync();
-    if constexpr (EXP) { export_row(T, nullptr); wave_sync(); }
+    if (EXP) { export_row(T, nullptr); wave_sync(); }
     if (cond) store_cond(C, T, g, c);
     const double th = draw();
     wave_sync();
@@ -2067,7 +2078,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
-    if ((t & (WS_STRETCH - 1)) == WS_STRETCH - 1) { have = false; warm = false; }   // a stretch starts from scratch: nothing a step computes depends on the steps above its stretch
+    if (ws_stretch_top(t)) { have = false; warm = false; }   // a stretch starts from scratch: nothing a step computes depends on the steps above its stretch
     if (a.stats && y && lane < p) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
       const double yv = y[(size_t)t * p + lane];
       if (yv == yv) {
@@ -2125,7 +2136,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) JTl[aa][b][r] = img[(16 * aa + 4 * r + g) * IL + 16 * b + c];
       matTvec<DT, DT>(JTl, uv, g, hc);
-      if constexpr (EXP) { if (lane == 0) tb.need[t] = 0; }
+      if (EXP) { if (lane == 0) tb.need[t] = 0; }
     } else {
       // R+ = G C G^T + W dt on a copy of C (the congruence works in place), exactly symmetric.  C itself is fetched again
       // when it is next needed (the record is in L2): holding it across the inverse costs 24 registers per tile.
@@ -2238,7 +2249,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
       to_image<IL, DT, DT>(H, img, g, c);
       wave_sync();
       factor_to_keep();
-      if constexpr (EXP) export_row(t, JT);
+      if (EXP) export_row(t, JT);
       have = true; gprev = gi; dtprev = dt;
       wave_sync();
       to_image<IL, DT, DT>(JT, img, g, c);                // J^T stays in the image for the steady-state steps that follow
@@ -2706,14 +2717,20 @@ void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb) {
   tb.zrec = (double*)p;  p += up64w(n1 * rec * 8);
   tb.zeros = (double*)p; p += up64w(zn * 8);
   tb.need = (unsigned char*)p; p += up64w(n1);
-  tb.status = (int*)p;
+  tb.status = (int*)p; tb.settle = tb.status + 1;
 }
 template <int DT>
-static void launch_w48_tables_k(const KArgs& kp, const SampTabs& tb, hipStream_t s) {
+static void launch_w48_tables_k(const KArgs& kp, const SampTabs& tb, bool outer, hipStream_t s) {
   const size_t lds = sizeof(double) * (size_t)(2 * 16 * DT * (16 * DT + 1) + 6 * 16 * DT);
-  const dim3 grid((kp.T + w48::WS_STRETCH - 1) / w48::WS_STRETCH);   // one wave per stretch
-  if (kp.spb_k <= 2) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, false, true>), grid, dim3(64), lds, s, kp, tb);
-  else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, false, true>), grid, dim3(64), lds, s, kp, tb);
+  const dim3 grid(w48::ws_stretches(kp.T));   // one wave per stretch
+  // (the instantiation launch_w48_sampler_k picks for the series of this call that compute their own factors)
+  if (kp.spb_k <= 2) {
+    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, true>), grid, dim3(64), lds, s, kp, tb);
+    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 2, false>), grid, dim3(64), lds, s, kp, tb);
+  } else {
+    if (outer) hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, true>), grid, dim3(64), lds, s, kp, tb);
+    else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, false>), grid, dim3(64), lds, s, kp, tb);
+  }
 }
 hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s) {
   const size_t zn = (size_t)a.T * a.p > 64 ? (size_t)a.T * a.p : 64;
@@ -2724,10 +2741,13 @@ hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& t
   kf.N = 1; kf.y = tb.zeros; kf.m0 = tb.zeros; kf.m0_stride = 0; kf.filt = tb.zrec; kf.status = tb.status; kf.stats = nullptr; kf.loglik = nullptr;
   kf.prior = nullptr; kf.fq = nullptr; kf.route = nullptr; kf.counters = nullptr; kf.theta = nullptr; kf.z = nullptr; kf.series_offset = 0;
   kf.flags |= DLM_OPT_FORCE_WAVE;   // the kernel family that filters the batch, whatever the batch size
+  if ((err = hipMemsetD32Async((hipDeviceptr_t)tb.settle, a.T, 1, s)) != hipSuccess) return err;
+  kf.settle_step = tb.settle;       // (stops where its covariance recursion has settled: within 30 steps for the C4 model)
   if ((err = launch_wave48_filter(kf, kf.spb_k, nullptr, s)) != hipSuccess) return err;
   KArgs kp = kf;
-  kp.y = nullptr; kp.filt_in = tb.zrec;
-  if (a.d <= 32) launch_w48_tables_k<2>(kp, tb, s); else launch_w48_tables_k<3>(kp, tb, s);
+  kp.y = nullptr; kp.filt_in = tb.zrec; kp.settle_step = nullptr;
+  const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0 && a.stats;
+  if (a.d <= 32) launch_w48_tables_k<2>(kp, tb, outer, s); else launch_w48_tables_k<3>(kp, tb, outer, s);
   return hipGetLastError();
 }
 template <int DT>
@@ -2758,3 +2778,4 @@ hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb,
 }
 
 }  // namespace dlm
+
