@@ -1054,6 +1054,9 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   st.out(&k.stats, stats, N * (size_t)dlm_stats_len(model->d, model->p, opts->flags));
   st.zeroed_out(&k.status, (int*)status, N);
   if ((rc = st.commit())) return rc;
+  // the stretches of the reference-form sampler (KArgs::stretches): wherever a shared-factor table is possible for these parameters,
+  // whether or not this call uses one -- a series' draws do not depend on the route it takes
+  k.stretches = (dlm::sampler_shared_model_ok(k) || dlm::wave48_sampler_shared_model_ok(k)) ? 1 : 0;
   if (forward) {
     if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
     if ((rc = mark(e, 0))) return rc;

@@ -42,6 +42,9 @@ struct KArgs {
   int route_take;
   unsigned long long* counters;   // engine-owned [4], zeroed per call (nullable): steady (short) steps taken by the forward [0] / backward [1] kernel,
                                   // series served by the shared-covariance kernels [2], series sent to their own full recursion [3]
+  int stretches;                  // backward sampler: 1 = every stretch of steps starts from scratch (dlm_sampler16.hip: SF_STRETCH), set for the calls
+                                  // whose parameters allow a shared-factor table -- its stretches are made side by side, and a series that computes
+                                  // its own factors in such a call follows the same rule, so that the two agree bit for bit
   int* settle_step;               // the filter of the shared-factor tables' series of zeros (nullptr otherwise): the kernel stops when its covariance
                                   // recursion has settled and leaves here the last record it wrote -- every later record would repeat that covariance
 };
@@ -122,7 +125,8 @@ struct SampTabs {
   int* status;           // status of the zero series' two kernels, for every series served by the tables
   int* settle;           // index of the last record of zrec that was written (KArgs::settle_step): the records above it repeat its covariance
 };
-bool sampler_shared_eligible(const KArgs& a);
+bool sampler_shared_model_ok(const KArgs& a);   // V, W, C0 shared by the batch, regular grid, time-invariant model (what KArgs::stretches follows)
+bool sampler_shared_eligible(const KArgs& a);   // ... and this call can use the table (no conditional-moment records, flags)
 size_t sampler_shared_ws_bytes(const KArgs& a);
 void sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
 // the tables: filter on zeros, then the sampler with its export on (both one wave; stream s)
@@ -131,6 +135,7 @@ hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* ta
 hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
 
 // the same for 16 <= d <= 48 (dlm_wave48.hip): rows of 64 x (4 DT^2 + 16 DT) doubles, per lane [ J^T tiles | row `lane` of L ]
+bool wave48_sampler_shared_model_ok(const KArgs& a);
 bool wave48_sampler_shared_eligible(const KArgs& a);
 size_t wave48_sampler_shared_ws_bytes(const KArgs& a);
 void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);

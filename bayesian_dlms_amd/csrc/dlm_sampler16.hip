@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   for (int t = t_hi; t >= t_lo; --t) {
     // Every SF_STRETCH steps the recursion starts from scratch -- a full step, its inverse not refined from the one before: what a
     // step computes then depends on nothing above its stretch, and the stretches of a shared-factor table are made side by side.
-    if ((t & (SF_STRETCH - 1)) == SF_STRETCH - 1) { have = false; warm = false; }
+    if ((EXP || a.stretches) && (t & (SF_STRETCH - 1)) == SF_STRETCH - 1) { have = false; warm = false; }
     // the normals of records t, t-1, t-2, t-3 (16 components each) are drawn together, one per lane, every fourth step:
     // the generator is the same few hundred instructions whether 13 lanes or 64 need a value
     if (!EXP && !zin && ((T - 1 - t) & 3) == 0) {
@@ -1002,13 +1002,15 @@ static hipError_t launch_rts_t(const KArgs& a, int K, const Tab* tabs_dev, hipSt
 #ifndef DLM_SAMPLER_SHARED_MIN
 #define DLM_SAMPLER_SHARED_MIN 1   // (measured, tools/sweep_c3.sh: the table pays at every batch size -- its stretches are made side by side, a series' own wave makes them one after the other)
 #endif
-bool sampler_shared_eligible(const KArgs& a) {
+bool sampler_shared_model_ok(const KArgs& a) {
   const size_t rec = (size_t)a.d + (size_t)a.d * a.d;
   return a.d <= 15 && a.p == 1 && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !a.v_stride && !a.w_stride && !a.c0_stride &&
-         !a.cond && !a.packed && a.filt && (!a.stats || a.y) && a.T >= 1 && a.T <= 400000 &&
+         !a.packed && a.T >= 1 && a.T <= 400000 && 4 * ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);   // four series' records under one buffer resource
+}
+bool sampler_shared_eligible(const KArgs& a) {
+  return sampler_shared_model_ok(a) && !a.cond && a.filt && (!a.stats || a.y) &&
          !(a.flags & (DLM_OPT_STATS_OUTER | DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16 | DLM_OPT_SAMPLER_PER_SERIES)) &&
-         (a.N >= DLM_SAMPLER_SHARED_MIN || (a.flags & DLM_OPT_NO_SMALL_BATCH)) &&
-         4 * ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);   // four series' records under one buffer resource
+         (a.N >= DLM_SAMPLER_SHARED_MIN || (a.flags & DLM_OPT_NO_SMALL_BATCH));
 }
 static size_t up64(size_t x) { return (x + 63) & ~(size_t)63; }
 size_t sampler_shared_ws_bytes(const KArgs& a) {

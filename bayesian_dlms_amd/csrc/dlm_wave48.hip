@@ -2078,7 +2078,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
     const double dt = a.dt ? a.dt[t] : 1.0;
     const int gi = a.g_index ? a.g_index[t] : 0;
     if (gi != gcur) load_tables(gi);
-    if (ws_stretch_top(t)) { have = false; warm = false; }   // a stretch starts from scratch: nothing a step computes depends on the steps above its stretch
+    if ((EXP || a.stretches) && ws_stretch_top(t)) { have = false; warm = false; }   // a stretch starts from scratch: nothing a step computes depends on the steps above its stretch
     if (a.stats && y && lane < p) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
       const double yv = y[(size_t)t * p + lane];
       if (yv == yv) {
@@ -2698,11 +2698,14 @@ hipError_t launch_wave48_sampler(const KArgs& a, hipStream_t s) {
 }
 
 // ---- shared factors: regular grid, time-invariant F / V / W, V, W, C0 shared by the batch -------------------------
-bool wave48_sampler_shared_eligible(const KArgs& a) {
+bool wave48_sampler_shared_model_ok(const KArgs& a) {
   const size_t rec = (size_t)a.d + (size_t)a.d * a.d;
-  return wave48_sampler_supported(a) && a.d >= 16 && wave48_filter_supported(a) && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride &&
-         !a.v_stride && !a.w_stride && !a.c0_stride && !a.cond && !a.packed && a.filt && (!a.stats || a.y) && a.T >= 1 && a.T <= 100000 &&
-         !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16 | DLM_OPT_SAMPLER_PER_SERIES)) && ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);
+  return tiled_supported(a) && a.d >= 16 && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !a.v_stride && !a.w_stride && !a.c0_stride &&
+         !a.packed && a.T >= 1 && a.T <= 100000 && ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);
+}
+bool wave48_sampler_shared_eligible(const KArgs& a) {
+  return wave48_sampler_shared_model_ok(a) && wave48_sampler_supported(a) && wave48_filter_supported(a) && !a.cond && a.filt && (!a.stats || a.y) &&
+         !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16 | DLM_OPT_SAMPLER_PER_SERIES));
 }
 static size_t up64w(size_t x) { return (x + 63) & ~(size_t)63; }
 static int ws_dt(const KArgs& a) { return a.d <= 32 ? 2 : 3; }

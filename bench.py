@@ -22,7 +22,7 @@ Other configs (so that the driver can time them; each prints the same one-line c
 
 The default run (no flags, one GPU) also times -- a few steps each, AFTER the headline's timed region -- the same workload with
 the steady-state shortcut off (`value_full_recursion`) and with 5 % of the observations missing (`value_missing_0.05`), and the
-other BASELINE configurations (`secondary`: c3 in both sampler forms, c4 with and without the shortcut, c4g, c5, the literal-Q1
+other BASELINE configurations (`secondary`: c3 in both sampler forms (and with the shared factors off, and at one GPU's share of 8), c4 with and without the shortcut, c4g, c5, the literal-Q1
 smoother), each with its own roofline by SURVEY 8d's units, so that the driver's record carries them.  `--no-secondary` skips that.
 
 Prints ONE JSON line on rank 0 with the extra objects
@@ -272,10 +272,13 @@ def add_secondary(line, args, ctx):
     sec["c2_literal_q1"] = brief(run(semantics="literal-q1", steps=3, warmup=1))
     sec["c2_shared_covariance_opt_in"] = brief(run(flags=_lib.OPT_SHARED_COV, steps=5, warmup=1))
     sec["c3_reference_sampler"] = brief(run(config="c3", sampler="reference", steps=3, warmup=1))
+    sec["c3_reference_sampler_own_factors"] = brief(run(config="c3", sampler="reference", flags=_lib.OPT_SAMPLER_PER_SERIES, steps=2, warmup=1))   # every series its own J_t, H_t, chol(H_t)
+    sec["c3_reference_sampler_1250_series"] = brief(run(config="c3", sampler="reference", series=1250, steps=3, warmup=1))   # one GPU's share of configs[2] on 8 GPUs
     sec["c3_simulation_smoother"] = brief(run(config="c3", sampler="simsmooth", steps=3, warmup=1))
     sec["c4"] = brief(run(config="c4", steps=3, warmup=1))
     sec["c4_full_recursion"] = brief(run(config="c4", flags=_lib.OPT_NO_STEADY, steps=2, warmup=1))
     sec["c4g"] = brief(run(config="c4g", steps=2, warmup=1))
+    sec["c4g_own_factors"] = brief(run(config="c4g", flags=_lib.OPT_SAMPLER_PER_SERIES, steps=2, warmup=1))
     sec["c5"] = brief(run(config="c5", steps=2, warmup=1))
     line["secondary"] = sec
 
@@ -418,7 +421,7 @@ def run_one(args, ctx):
         elif cfg == "c3":
             # FFBS with on-device statistics: write + re-read the filtered records, theta never written (8p + 16 (d + d^2) = 2920 B)
             fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * rec, 8.0 * rec, "GB/s", HBM_PEAK_GBS, "hbm"
-            names = ("k_filter_", "k_sampler_")
+            names = ("k_filter_", "k_mean_sampler_" if variant.endswith("-shared") else "k_sampler_")
         elif cfg == "c4" and steady_fraction is not None and steady_fraction["forward"] > 0.5:
             # the covariance recursion of this model settles within 30 steps: from then on both passes stream records (steady-state
             # steps) and the bound is HBM -- the contract's algorithmic bytes 8p + 24 (d + d^2) = 39 520 B per series-step
@@ -428,6 +431,12 @@ def run_one(args, ctx):
             # algorithmic flops: filter 8 d^3 + 6 d^2 p + 2 p^3 / 3, RTS 8.67 d^3
             fwd_u, bwd_u, unit, peak, bound = 8.0 * d ** 3 + 6.0 * d * d * q + 2.0 * q ** 3 / 3.0, 8.67 * d ** 3, "TFLOP/s", MFMA_F64_PEAK_TFLOPS, "mfma"
             names = ("k_filter_", "k_smoother_")
+        elif cfg == "c4g" and variant.endswith("-shared"):
+            # pooled parameters: J_t, H_t and the factors are computed once per call and the covariance recursion of
+            # the forward pass settles within 30 steps -- both passes stream: write + re-read of the filtered records (the contract's
+            # algorithmic bytes; the shared-factor draw kernel in fact re-reads the means alone)
+            fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * rec, 8.0 * rec, "GB/s", HBM_PEAK_GBS, "hbm"
+            names = ("k_filter_", "k_mean_sampler_")
         elif cfg == "c4g":
             # FFBS adds about 8 d^3 (J, H) plus the Cholesky factor d^3 / 3 to the filter's flops
             fwd_u, bwd_u, unit, peak, bound = 8.0 * d ** 3 + 6.0 * d * d * q + 2.0 * q ** 3 / 3.0, 8.0 * d ** 3 + d ** 3 / 3.0, "TFLOP/s", MFMA_F64_PEAK_TFLOPS, "mfma"
@@ -440,7 +449,7 @@ def run_one(args, ctx):
         scale = 1e9 if unit == "GB/s" else 1e12
         achieved = dom_u * nt / (dom_ms * 1e-3) / scale
         short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16", "sparse16-rts": "rts16", "wave-sampler": "w48", "wave-simsmooth": "w48",
-                 "sparse16-simsmooth": "sp16", "svd-jacobi": "jacobi"}.get(variant, variant)
+                 "sparse16-simsmooth": "sp16", "svd-jacobi": "jacobi", "sparse16-sampler-shared": "sp16", "wave-sampler-shared": "w48"}.get(variant, variant)
         kname = (names[1] if dom_is_bwd else names[0]) + short
         workloads = {
             "c2": f"C2: seasonal DLM polynomial(1)|+|seasonal(24,6), d=13, p=1, {job_series} series x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
