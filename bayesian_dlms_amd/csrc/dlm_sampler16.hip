@@ -190,6 +190,7 @@ constexpr int SF_STRETCH = 32;             // steps t with t % SF_STRETCH == SF_
 template <int K, class Tab, bool EXP = false>
 __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __restrict__ sp, SampTabs tb) {   // two waves per SIMD: the step is a long dependent chain
   if (!EXP && a.route && (a.route[blockIdx.x] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
+  if constexpr (EXP) __builtin_amdgcn_s_setprio(3);   // the table's few waves run beside the kernel that filters the batch and are what the draw kernel waits for
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 8 * 16 + 64];
   double* img = lds;       double* inv = lds + IMG;
   double* mv = inv + IMG;  double* thv = mv + 16;   double* uv = thv + 16;   double* zv = uv + 16;

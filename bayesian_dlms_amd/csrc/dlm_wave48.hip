@@ -489,6 +489,7 @@ __device__ __forceinline__ bool chol_rows(double* L, int n, int ld, int lane) { 
 // the image instead of MFMA products (90 of the 190 MFMAs of a step at d = 40, p = 20).
 template <int DT, int PT, int K, int KF>
 __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k_filter_w48(KArgs a, double* innov, int zero_m0) {
+  if (a.settle_step) __builtin_amdgcn_s_setprio(3);   // the series of zeros of a shared-factor table: one wave beside the batch's filter, and the table waits for it
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int IL = il_of(DT, PT), IMG = img_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT), QL = 16 * PT + 1;
   double* img = sm;        double* Fl = sm + IMG;  double* vec0 = Fl + FIMG + inv_extra(DT, PT);   double* inv = inv_in_img(DT, PT) ? img + inv_of(PT) : Fl + FIMG;
@@ -1896,6 +1897,7 @@ __global__ __launch_bounds__(64) void k_sampler_w48(KArgs a, SampTabs tb) {
   // The table of a shared-factor call is made by THIS kernel (tb.rows set), not by an instantiation of its own: the series that
   // compute their own factors and the table then run the same machine code, and what they compute agrees bit for bit by construction.
   const bool EXP = tb.rows != nullptr;
+  if (EXP) __builtin_amdgcn_s_setprio(3);   // the table's few waves run beside the kernel that filters the batch and are what the draw kernel waits for
   if (!EXP && a.route && (a.route[blockIdx.x] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int IL = 16 * DT + 1, IMG = 16 * DT * IL, VL = 16 * DT, ND = 16 * DT;
