@@ -680,13 +680,6 @@ int dlm_last_counters(dlm_engine* e, uint64_t out[4]) {
   return DLM_OK;
 }
 
-#ifdef DLM_DEBUG_HOOKS
-extern "C" int dlm_debug_sampws(dlm_engine* e, void* dst, size_t bytes) {   // diagnostic builds only: the shared-factor workspace of the last call
-  if (!e || !e->sampws) return DLM_ERR_ARG;
-  HIP_TRY(e, hipMemcpy(dst, e->sampws, bytes < e->sampws_bytes ? bytes : e->sampws_bytes, hipMemcpyDeviceToHost));
-  return (int)e->sampws_bytes;
-}
-#endif
 int dlm_engine_wait_stream(dlm_engine* e, void* hip_stream) {
   if (!e) return DLM_ERR_ARG;
   HIP_TRY(e, hipSetDevice(e->device));
