@@ -62,6 +62,10 @@ struct dlm_engine {
   size_t route_bytes = 0;
   void* sampws = nullptr;       // shared factors of the backward sampler: table, the zero series' records, flags
   size_t sampws_bytes = 0;
+  double* zws = nullptr;        // ... and the call's normals in the draw kernel's layout, made on a third stream while the batch is filtered
+  size_t zws_bytes = 0;
+  hipStream_t rng_stream = nullptr;
+  hipEvent_t rng_ev = nullptr;
   hipStream_t cov_stream = nullptr;
   hipEvent_t cov_ev[2] = {nullptr, nullptr};
   // DLM_OPT_COUNT_STEPS: [4] device counters the kernels add to (KArgs::counters), read by dlm_last_counters
@@ -467,6 +471,24 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_tables(k, tb, e->cov_stream));
   else HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
   HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
+  tb.z4 = nullptr;
+  if (!k.z) {   // the normals of the call, on a stream of ordinary priority beside the batch's filter
+    const size_t zb = big ? dlm::wave48_sampler_shared_normals_bytes(k) : dlm::sampler_shared_normals_bytes(k);
+    if (zb > e->zws_bytes) {
+      if (e->zws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->zws)); e->zws = nullptr; e->zws_bytes = 0; }
+      HIP_TRY(e, hipMalloc((void**)&e->zws, zb));
+      e->zws_bytes = zb;
+    }
+    if (!e->rng_stream) {
+      HIP_TRY(e, hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));
+      HIP_TRY(e, hipEventCreateWithFlags(&e->rng_ev, hipEventDisableTiming));
+    }
+    HIP_TRY(e, hipStreamWaitEvent(e->rng_stream, e->cov_ev[0], 0));   // (the draw kernel of the call before has read its normals)
+    if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_normals(k, e->zws, e->rng_stream));
+    else HIP_TRY(e, dlm::launch_sampler_shared_normals(k, e->zws, e->rng_stream));
+    HIP_TRY(e, hipEventRecord(e->rng_ev, e->rng_stream));
+    tb.z4 = e->zws;
+  }
   return DLM_OK;
 }
 int ensure_shared(dlm_engine* e, const KArgs& k, dlm::CovTabs& tb, bool with_backward) {
@@ -633,6 +655,9 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->covws) (void)hipFree(e->covws);
   if (e->route) (void)hipFree(e->route);
   if (e->sampws) (void)hipFree(e->sampws);
+  if (e->zws) (void)hipFree(e->zws);
+  if (e->rng_ev) (void)hipEventDestroy(e->rng_ev);
+  if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   for (auto& ev : e->cov_ev) if (ev) (void)hipEventDestroy(ev);
   if (e->cov_stream) (void)hipStreamDestroy(e->cov_stream);
   if (e->counters) (void)hipFree(e->counters);
@@ -1100,6 +1125,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     // series draw against it; a series with a missing observation computes its own as always
     e->variant = "sparse16-sampler-shared";
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));
+    if (stb.z4) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->rng_ev, 0));
     k.route = e->route;
     HIP_TRY(e, dlm::launch_sampler_shared_draw(k, e->sparse_k, e->sp_dev, stb, e->stream));
     return done();
@@ -1117,6 +1143,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if (shared_big) {
     e->variant = "wave-sampler-shared";
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));
+    if (stb.z4) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->rng_ev, 0));
     k.route = e->route;
     HIP_TRY(e, dlm::launch_wave48_sampler_shared_draw(k, stb, e->stream));
     return done();

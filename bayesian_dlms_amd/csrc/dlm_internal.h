@@ -123,6 +123,8 @@ struct SampTabs {
   double* zeros;         // max(T, 16) zeros: its observations and initial mean
   unsigned char* need;   // [T+1] 1: row t was written (a full step); 0: the factors of the last row above it
   int* status;           // status of the zero series' two kernels, for every series served by the tables
+  double* z4;            // the normals of the call, made while the batch is filtered.  d <= 15 (k_normals4): [ceil(N / 4)][T+1][4][16], 512 bytes per step
+                         //   and wave of the draw kernel; 16 <= d <= 48 (k_normals_rows): [N][T+1][d].  nullptr: injected normals (KArgs::z)
   int* settle;           // index of the last record of zrec that was written (KArgs::settle_step): the records above it repeat its covariance
 };
 bool sampler_shared_model_ok(const KArgs& a);   // V, W, C0 shared by the batch, regular grid, time-invariant model (what KArgs::stretches follows)
@@ -131,6 +133,8 @@ size_t sampler_shared_ws_bytes(const KArgs& a);
 void sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
 // the tables: filter on zeros, then the sampler with its export on (both one wave; stream s)
 hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
+size_t sampler_shared_normals_bytes(const KArgs& a);
+hipError_t launch_sampler_shared_normals(const KArgs& a, double* z4, hipStream_t s);   // the Philox normals of every series and step, in the draw kernel's layout
 // a.route [N] is filled here (series with a missing observation), the mean-only kernel draws for the others, k_sampler_sp16 for these
 hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
 
@@ -141,6 +145,8 @@ size_t wave48_sampler_shared_ws_bytes(const KArgs& a);
 void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
 hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s);
 hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb, hipStream_t s);
+size_t wave48_sampler_shared_normals_bytes(const KArgs& a);
+hipError_t launch_wave48_sampler_shared_normals(const KArgs& a, double* z, hipStream_t s);   // rows [N][T+1][d], SampTabs::z4 of these calls
 
 // ---- multivariate path: workgroup per series, MFMA-tiled GEMMs from LDS, dlm_tiled.hip --------
 // Nonzeros of the rows (`rows`) and of the columns (`cols`) of a d x d G with at most 4 per row and column (every

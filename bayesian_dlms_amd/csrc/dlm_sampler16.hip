@@ -577,7 +577,8 @@ __device__ __forceinline__ double row_pick(double v, int lane, int src) {   // t
   return __hiloint2double(hi, lo);
 }
 
-template <int K, int NR>
+// ZD: the normals come from SampTabs::z4 (k_normals4) by LDS DMA, four steps ahead; otherwise they are the injected ones (KArgs::z)
+template <int K, int NR, bool ZD>
 __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const SparseT* __restrict__ sp, SampTabs tb) {
   __shared__ __attribute__((aligned(16))) double lds[2 * 64 + 4 * 64 + 2 * (SF_SLOT / 8) + SF_AHEAD * 64];
   const int lane = threadIdx.x, j = lane >> 4, c = lane & 15;
@@ -611,25 +612,23 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
     if (lane < 32)   // 4 x 8 pieces; the other lanes' LDS destinations lie beyond the slot
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(mvoff), "s"(rmean), "s"(soff) : "memory");
   };
+  const i4 rz = rsrc_words(ZD ? tb.z4 + (size_t)(n0 / 4) * (T + 1) * 64 : nullptr, ZD ? (unsigned)((size_t)(T + 1) * 512) : 0u);
+  const unsigned zring_lds = lds_addr_of(vZ);
+  const int zvoff = lane * 16;
+  auto dma_z = [&](int tz) {   // the wave's 512 bytes of normals of step tz into slot tz & 3
+    const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)(zring_lds + (unsigned)(tz & 3) * 512u));
+    const int soff = __builtin_amdgcn_readfirstlane((tz > 0 ? tz : 0) * 512);
+    if (lane < 32)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(la), "v"(zvoff), "s"(rz), "s"(soff) : "memory");
+  };
   double* thout = a.theta ? a.theta + (size_t)n0 * (T + 1) * d : nullptr;
   const __amdgpu_buffer_rsrc_t rth = mk_rsrc(thout, thout ? (size_t)nser * (T + 1) * d * 8 : 0);
   const int offth = (!dead && vc && thout) ? (int)((size_t)j * (T + 1) * d * 8) + c * 8 : OOB;
   const double* y = (a.stats && a.y) ? a.y + (size_t)n * T : nullptr;
   const double* zin = a.z ? a.z + (size_t)n * (T + 1) * d : nullptr;
-  const unsigned long long series = a.series_offset + (unsigned long long)n;
   const double Fc = vc ? a.F[c] : 0.0;
   const unsigned char* need = tb.need;
 
-  // the normals of steps tb_ and tb_ - 1: one Philox block and one Box-Muller pair give two components
-  auto normals2 = [&](int tb_) {
-    const int te = tb_ - (c & 1);
-    if (te >= 0) {
-      double ze, zo;
-      philox_normal2(a.seed, series, (unsigned)te, (unsigned)(c >> 1), ze, zo);
-      double* zr = vZ + (te & 3) * 64 + 16 * j + (c & ~1);
-      zr[0] = ze; zr[1] = zo;
-    }
-  };
   double Jc[16], Lr[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) { Jc[k] = 0.0; Lr[k] = 0.0; }
@@ -656,6 +655,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
 
   // requests: the means of steps T .. T - SF_AHEAD + 1 (the oldest), then the table rows T and T - 1
   for (int k = 0; k < SF_AHEAD; ++k) { const int tk = T - k > 0 ? T - k : 0; dma_means(mring_lds + ((T - k) & (SF_AHEAD - 1)) * 512, tk * recb); }
+  if constexpr (ZD) for (int k = 0; k < 4; ++k) dma_z(T - k);   // the normals of steps T .. T - 3
   dma_row<NR>(rtab, ring_lds + (T & 1) * SF_SLOT, T * (SF_ROW * 8), lane, n16);
   dma_row<NR>(rtab, ring_lds + ((T - 1) & 1) * SF_SLOT, (T > 0 ? T - 1 : 0) * (SF_ROW * 8), lane, n16);
   // need[t], need[t - 1], need[t - 2] as the loop goes down: bit (s & 63) of the mask of s's block of 64 steps
@@ -669,9 +669,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
   (void)nd0;
   double thc;
   {   // theta_T = m_T + chol(C_T) z_T
-    if (zin) vZ[(T & 3) * 64 + lane] = vc ? zin[(size_t)T * d + c] : 0.0;
-    else vZ[(T & 3) * 64 + lane] = vc ? philox_normal(a.seed, series, (unsigned)T, (unsigned)c) : 0.0;
-    if (!zin) { normals2(T - 1); }
+    if constexpr (!ZD) vZ[(T & 3) * 64 + lane] = vc ? zin[(size_t)T * d + c] : 0.0;
     vm_wait<0>();
     wave_sync();
     const unsigned slot = ring_lds + (T & 1) * SF_SLOT, mslot = mring_lds + (T & (SF_AHEAD - 1)) * 512;
@@ -682,6 +680,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
     wave_sync();
     dma_means(mslot, (T > SF_AHEAD ? T - SF_AHEAD : 0) * recb);
     if (nd2) dma_row<NR>(rtab, slot, (T - 2) * (SF_ROW * 8), lane, n16);
+    if constexpr (ZD) dma_z(T - 4);
     bst(rth, offth, T * d * 8, thc);
   }
   double ssd = 0.0, ssy = 0.0;
@@ -689,7 +688,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
   double yk[2] = {0.0, 0.0};             // the observations of this row's series, 32 steps at a time
   for (int t = T - 1; t >= 0; --t) {
     nd0 = nd1; nd1 = nd2; nd2 = need_of(t - 2);
-    if (zin) { vZ[(t & 3) * 64 + lane] = vc ? zin[(size_t)t * d + c] : 0.0; wave_sync(); }
+    if constexpr (!ZD) { vZ[(t & 3) * 64 + lane] = vc ? zin[(size_t)t * d + c] : 0.0; wave_sync(); }
     if (y) {   // observation residual of theta_{t+1} (Gibbs.scala:29-39), as k_sampler_sp16
       if (t == T - 1 || (t & 31) == 31) {
         const int base = t & ~31;
@@ -702,10 +701,14 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
       for (int o_ = 8; o_ > 0; o_ >>= 1) part += __shfl_xor(part, o_);
       if (c == 0 && yv == yv) { ssy += (yv - part) * (yv - part); nob += 1; }
     }
-    // Operations younger than the request for row t (issued two steps up, behind that step's request for the means): that step's
-    // store, then the step above this one: means, row t - 1 (when it exists), store.  Without a row for this step the means
-    // of step t are what is waited for: requested SF_AHEAD steps up, at least 2 SF_AHEAD - 1 operations ago.
-    if (nd0) { if (nd1) vm_wait<3 + NR>(); else vm_wait<3>(); } else vm_wait<2 * SF_AHEAD - 1>();
+    // A step issues, in this order: the request for the means (SF_AHEAD steps ahead), for a table row (two steps ahead, when it
+    // exists), for the normals (ZD: four steps ahead, once the draw has read their slot), the store of the draw.  Operations younger
+    // than the request for row t: that step's normals and store, then the step above this one: means, row t - 1 (when it exists),
+    // (normals,) store.  Without a row for this step the normals of step t are what is waited for (the means are older): four steps
+    // up, behind them that step's store and three steps of at least three operations -- or, with injected normals, the means:
+    // 2 SF_AHEAD - 1 operations ago at least.
+    if constexpr (ZD) { if (nd0) { if (nd1) vm_wait<5 + NR>(); else vm_wait<5>(); } else vm_wait<10>(); }
+    else { if (nd0) { if (nd1) vm_wait<3 + NR>(); else vm_wait<3>(); } else vm_wait<2 * SF_AHEAD - 1>(); }
     const unsigned slot = ring_lds + (t & 1) * SF_SLOT, mslot = mring_lds + (t & (SF_AHEAD - 1)) * 512;
     double mr = lds_read64<0>(mslot + lane * 8);
     double mg[K];
@@ -742,8 +745,8 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
     }
     wave_sync();
     thc = th;
+    if constexpr (ZD) dma_z(t - 4);                   // (the draw has read this slot)
     bst(rth, offth, t * d * 8, th);
-    if (!zin && ((T - 1 - t) & 1) == 1) normals2(t - 1);   // the normals of steps t - 1 and t - 2
   }
   vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
   (void)vT_lds;
@@ -1047,16 +1050,45 @@ hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* ta
   }
   return hipGetLastError();
 }
-template <int K>
+template <int K, bool ZD>
 static hipError_t launch_mean_sampler(const KArgs& a, const SparseT* sp, const SampTabs& tb, hipStream_t s) {
   const dim3 grid((a.N + 3) / 4), blk(64);
   const int nr = (17 * a.d + 63) / 64;
   switch (nr) {
-    case 1: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 1>), grid, blk, 0, s, a, sp, tb); break;
-    case 2: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 2>), grid, blk, 0, s, a, sp, tb); break;
-    case 3: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 3>), grid, blk, 0, s, a, sp, tb); break;
-    default: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 4>), grid, blk, 0, s, a, sp, tb); break;
+    case 1: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 1, ZD>), grid, blk, 0, s, a, sp, tb); break;
+    case 2: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 2, ZD>), grid, blk, 0, s, a, sp, tb); break;
+    case 3: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 3, ZD>), grid, blk, 0, s, a, sp, tb); break;
+    default: hipLaunchKernelGGL((s16::k_mean_sampler_sp16<K, 4, ZD>), grid, blk, 0, s, a, sp, tb); break;
   }
+  return hipGetLastError();
+}
+// The normals of the whole call in the draw kernel's layout, made while the batch is filtered: they are a third of the draw
+// kernel's instructions otherwise, in its dependent chain.  One wave per group of four series and 16 steps; lane 16 j + c makes the
+// pair (2 q, 2 q + 1), q = c >> 1, of series j at the steps te = t0 + 2 i + (c & 1): philox_normal2, i.e. philox_normal's values.
+__global__ __launch_bounds__(256) void k_normals4(KArgs a, double* __restrict__ z4) {
+  const int lane = threadIdx.x & 63, j = lane >> 4, c = lane & 15;
+  const int nch = (a.T + 16) / 16;                           // chunks of 16 steps covering 0 .. T
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long g4 = w / nch;
+  if (g4 >= (a.N + 3) / 4) return;
+  const int t0 = (int)(w - g4 * nch) * 16, n = (int)g4 * 4 + j;
+  const bool live = n < a.N && (c & ~1) < a.d;
+  const unsigned long long series = a.series_offset + (unsigned long long)n;
+  double* out = z4 + (size_t)g4 * (a.T + 1) * 64 + 16 * j + (c & ~1);
+  for (int i = 0; i < 8; ++i) {
+    const int te = t0 + 2 * i + (c & 1);
+    if (te > a.T) break;
+    double ze = 0.0, zo = 0.0;
+    if (live) philox_normal2(a.seed, series, (unsigned)te, (unsigned)(c >> 1), ze, zo);
+    if ((c | 1) >= a.d) zo = 0.0;
+    double* o = out + (size_t)te * 64;
+    o[0] = ze; o[1] = zo;
+  }
+}
+size_t sampler_shared_normals_bytes(const KArgs& a) { return (size_t)((a.N + 3) / 4) * ((size_t)a.T + 1) * 512; }
+hipError_t launch_sampler_shared_normals(const KArgs& a, double* z4, hipStream_t s) {
+  const long long waves = (long long)((a.N + 3) / 4) * ((a.T + 16) / 16);
+  hipLaunchKernelGGL(k_normals4, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, z4);
   return hipGetLastError();
 }
 hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s) {
@@ -1067,13 +1099,16 @@ hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;
   km.route_take = 0;
+  if (!a.z && !tb.z4) return hipErrorInvalidValue;   // the normals: injected, or made by launch_sampler_shared_normals
+#define DLM_MS(KK) err = a.z ? launch_mean_sampler<KK, false>(km, tabs_dev, tb, s) : launch_mean_sampler<KK, true>(km, tabs_dev, tb, s)
   switch (K) {
-    case 1: err = launch_mean_sampler<1>(km, tabs_dev, tb, s); break;
-    case 2: err = launch_mean_sampler<2>(km, tabs_dev, tb, s); break;
-    case 3: err = launch_mean_sampler<3>(km, tabs_dev, tb, s); break;
-    case 4: err = launch_mean_sampler<4>(km, tabs_dev, tb, s); break;
+    case 1: DLM_MS(1); break;
+    case 2: DLM_MS(2); break;
+    case 3: DLM_MS(3); break;
+    case 4: DLM_MS(4); break;
     default: return hipErrorInvalidValue;
   }
+#undef DLM_MS
   if (err != hipSuccess) return err;
   KArgs kg = a;   // the series with a missing observation: their own factors
   kg.route_take = 1;

@@ -2446,12 +2446,14 @@ __global__ __launch_bounds__(64, 2) void k_mean_sampler_w48(KArgs a, SampTabs tb
   for (int b = 0; b < DT; ++b) ssd[b] = 0.0;
   double ssy = 0.0, nob = 0.0;
   double ynext = (y && lane < p && T > 0) ? y[(size_t)(T - 1) * p + lane] : 0.0;
+  double znext = (zin && lane < d && T > 0) ? zin[(size_t)(T - 1) * d + lane] : 0.0;   // given normals (injected, or k_normals_rows'): one step ahead
   for (int t = T - 1; t >= 0; --t) {
     const bool nd = need_of(t);
-    const double yv = ynext, mc = mnext;
+    const double yv = ynext, mc = mnext, zc = znext;
     if (t > 0) {
       mnext = bld(rin, moff, (t - 1) * recb);
       if (y && lane < p) ynext = y[(size_t)(t - 1) * p + lane];
+      if (zin && lane < d) znext = zin[(size_t)(t - 1) * d + lane];
     }
     if (obs && lane < p && yv == yv) {   // observation residual of theta_{t+1}, component `lane` (Gibbs.scala:29-39)
       const double* Fj = Fl + lane * FLD;
@@ -2459,7 +2461,7 @@ __global__ __launch_bounds__(64, 2) void k_mean_sampler_w48(KArgs a, SampTabs tb
       for (int k = 0; k < d; ++k) f = fma(Fj[k], thv[k], f);
       ssy += (yv - f) * (yv - f); nob += 1.0;
     }
-    if (zin) { if (lane < ND) zv[(t & 1) * VL + lane] = lane < d ? zin[(size_t)t * d + lane] : 0.0; }
+    if (zin) { if (lane < ND) zv[(t & 1) * VL + lane] = lane < d ? zc : 0.0; }
     if (nd) load_row(t, true);
     if (lane < ND) mv[lane] = mc;
     wave_sync();
@@ -2531,6 +2533,24 @@ __global__ __launch_bounds__(64, 2) void k_mean_sampler_w48(KArgs a, SampTabs tb
   }
   if (a.counters && lane == 0) atomicAdd(&a.counters[2], 1ull);
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+}
+
+// The normals of a shared-factor call as rows [N][T+1][d] (the layout of injected normals), made while the batch is filtered: one
+// thread per Box-Muller pair, philox_normal2 = philox_normal's values.  They are 60 % of the draw kernel's arithmetic otherwise.
+__global__ __launch_bounds__(256) void k_normals_rows(KArgs a, double* __restrict__ z) {
+  const int d = a.d, np = (d + 1) / 2;
+  const long long total = (long long)a.N * (a.T + 1) * np;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % np);
+    const long long nt = i / np;
+    const int t = (int)(nt % (a.T + 1));
+    const long long n = nt / (a.T + 1);
+    double ze, zo;
+    philox_normal2(a.seed, a.series_offset + (unsigned long long)n, (unsigned)t, (unsigned)q, ze, zo);
+    double* o = z + (size_t)nt * d + 2 * q;
+    o[0] = ze;
+    if (2 * q + 1 < d) o[1] = zo;
+  }
 }
 
 // route[n] = 1: series n has a missing observation component
@@ -2767,6 +2787,13 @@ static void launch_w48_mean_k(const KArgs& a, const SampTabs& tb, hipStream_t s)
     else hipLaunchKernelGGL((w48::k_mean_sampler_w48<DT, 4, false>), dim3(a.N), dim3(64), lds, s, a, tb);
   }
 }
+size_t wave48_sampler_shared_normals_bytes(const KArgs& a) { return (size_t)a.N * ((size_t)a.T + 1) * a.d * 8; }
+hipError_t launch_wave48_sampler_shared_normals(const KArgs& a, double* z, hipStream_t s) {
+  const long long total = (long long)a.N * (a.T + 1) * ((a.d + 1) / 2);
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(w48::k_normals_rows, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, s, a, z);
+  return hipGetLastError();
+}
 hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb, hipStream_t s) {
   if (!a.route) return hipErrorInvalidValue;
   hipError_t err;
@@ -2775,6 +2802,7 @@ hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb,
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;
   km.route_take = 0;
+  if (!km.z) km.z = tb.z4;          // the call's normals made beside the filter (k_normals_rows); nullptr: the draw kernel makes them itself
   if (a.d <= 32) launch_w48_mean_k<2>(km, tb, s); else launch_w48_mean_k<3>(km, tb, s);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs kg = a;   // the series with a missing observation: their own factors
