@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/kt_c2 -o run --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_c2_under_rocprof.json 2> $O/kt_c2.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-secondary > $O/pmc_write.log 2>&1
-for c in "c2 --flags 4194304" "c2 --missing 0.05" "c2 --semantics literal-q1" "c2 --records packed" "c2 --flags 16777216" "c3" "c3 --sampler simsmooth" "c4" "c4 --flags 4194304" "c4g" "c5"; do
+for c in "c2 --flags 4194304" "c2 --missing 0.05" "c2 --semantics literal-q1" "c2 --records packed" "c2 --flags 16777216" "c3" "c3 --flags 67108864" "c3 --series 1250" "c3 --sampler simsmooth" "c4" "c4 --flags 4194304" "c4g" "c4g --flags 67108864" "c5"; do
   tag=$(echo $c | tr -d ' -.')
   rocprofv3 --kernel-trace --stats -d $O/kt_$tag -o run --output-format csv -- python3 $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_${tag}_under_rocprof.json 2> $O/kt_$tag.err
 done
