@@ -156,9 +156,11 @@ def gibbs_dinvgamma_device(mod: Dlm, prior_v: InverseGamma, prior_w: InverseGamm
         packed = (V.reshape(-1), p * p, W.reshape(-1), d * d, m0, 0, C0, 0)
         out = engine.ffbs(mat, packed, y, seed=seed * 1000003 + it, series_offset=series_offset, flags=flags,
                           want_theta=False, want_stats=True)
-        V, W = engine.dinvgamma_step(d, p, out["stats"], prior_v, prior_w, iteration=it, seed=seed, series_offset=series_offset)
+        stats = out["stats"]
+        del out     # (the filter workspace returns to the allocator before the next call asks for one)
+        V, W = engine.dinvgamma_step(d, p, stats, prior_v, prior_w, iteration=it, seed=seed, series_offset=series_offset)
         if on_iteration is not None:
-            on_iteration(it, V, W, out["stats"])
+            on_iteration(it, V, W, stats)
     return V, W
 
 
@@ -189,6 +191,9 @@ def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, p
         out = run(mat, params, y, seed=seed * 1000003 + it, series_offset=series_offset, flags=flags,
                   want_theta=keep_theta, want_stats=True)
         stats = out["stats"] if on_device else np.asarray(out["stats"])
+        theta = ((out["theta"] if on_device else np.asarray(out["theta"])) if keep_theta else None)
+        status = out.get("status")
+        del out     # the filter workspace (N (T + 1) (d + d^2) doubles: 26 GB at C4) goes back to the allocator BEFORE the next call asks for one
         if pooled:
             # sum over the series of this shard (dlm_stats_pool), then over the ranks: the only collective on the path
             tot = stats.sum(axis=0) if engine is None else engine.stats_pool(stats)
@@ -219,4 +224,4 @@ def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, p
                     w = np.diag(draw_w_diag(prior_w, body[k], tcount[k], r))
                 new.append(DlmParameters(v, w, old[k].m0, old[k].c0))
             params = new
-        yield GibbsState(params, (out["theta"] if on_device else np.asarray(out["theta"])) if keep_theta else None, stats, out.get("status"))
+        yield GibbsState(params, theta, stats, status)
