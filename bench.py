@@ -255,7 +255,7 @@ def add_secondary(line, args, ctx):
         return r
 
     def brief(r):
-        keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step")}
+        keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "step_ms")}
         keep["workload"] = r["config"]["workload"]
         keep["variant"] = r["config"]["variant"]
         keep["semantics"] = r["config"]["semantics"]
@@ -271,14 +271,14 @@ def add_secondary(line, args, ctx):
     sec = {"c2_full_recursion": brief(full), "c2_missing_0.05": brief(miss)}
     sec["c2_literal_q1"] = brief(run(semantics="literal-q1", steps=3, warmup=1))
     sec["c2_shared_covariance_opt_in"] = brief(run(flags=_lib.OPT_SHARED_COV, steps=5, warmup=1))
-    sec["c3_reference_sampler"] = brief(run(config="c3", sampler="reference", steps=3, warmup=1))
-    sec["c3_reference_sampler_own_factors"] = brief(run(config="c3", sampler="reference", flags=_lib.OPT_SAMPLER_PER_SERIES, steps=2, warmup=1))   # every series its own J_t, H_t, chol(H_t)
-    sec["c3_reference_sampler_1250_series"] = brief(run(config="c3", sampler="reference", series=1250, steps=3, warmup=1))   # one GPU's share of configs[2] on 8 GPUs
-    sec["c3_simulation_smoother"] = brief(run(config="c3", sampler="simsmooth", steps=3, warmup=1))
+    sec["c3_reference_sampler"] = brief(run(config="c3", sampler="reference", steps=3, warmup=2))
+    sec["c3_reference_sampler_own_factors"] = brief(run(config="c3", sampler="reference", flags=_lib.OPT_SAMPLER_PER_SERIES, steps=2, warmup=2))   # every series its own J_t, H_t, chol(H_t)
+    sec["c3_reference_sampler_1250_series"] = brief(run(config="c3", sampler="reference", series=1250, steps=3, warmup=2))   # one GPU's share of configs[2] on 8 GPUs
+    sec["c3_simulation_smoother"] = brief(run(config="c3", sampler="simsmooth", steps=3, warmup=2))
     sec["c4"] = brief(run(config="c4", steps=3, warmup=1))
     sec["c4_full_recursion"] = brief(run(config="c4", flags=_lib.OPT_NO_STEADY, steps=2, warmup=1))
-    sec["c4g"] = brief(run(config="c4g", steps=2, warmup=1))
-    sec["c4g_own_factors"] = brief(run(config="c4g", flags=_lib.OPT_SAMPLER_PER_SERIES, steps=2, warmup=1))
+    sec["c4g"] = brief(run(config="c4g", steps=3, warmup=2))
+    sec["c4g_own_factors"] = brief(run(config="c4g", flags=_lib.OPT_SAMPLER_PER_SERIES, steps=2, warmup=2))
     sec["c5"] = brief(run(config="c5", steps=2, warmup=1))
     line["secondary"] = sec
 
@@ -291,7 +291,7 @@ def run_one(args, ctx):
     from bayesian_dlms_amd.gibbs import GibbsSampling, GibbsWishart, InverseGamma, InverseWishart, shard_bounds
     cfg = args.config
     steps = args.steps if args.steps is not None else {"c2": 20, "c3": 5, "c4": 5, "c4g": 3, "c5": 3}[cfg]
-    warmup = args.warmup if args.warmup is not None else {"c2": 3, "c3": 1, "c4": 1, "c4g": 1, "c5": 1}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"c2": 3, "c3": 2, "c4": 1, "c4g": 2, "c5": 1}[cfg]   # (Gibbs: every workspace of the loop exists after two iterations)
 
     mod, p = multivariate_c4() if cfg in ("c4", "c4g") else seasonal_c2()
     total = args.series if args.series is not None else (2000 if cfg in ("c4", "c4g") else 10000)
@@ -382,10 +382,12 @@ def run_one(args, ctx):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    step_ms, tprev = [], t0
     for _ in range(steps):
         step()                       # synchronous on return (engine stream is drained)
         f, b = eng.last_timing()     # HIP events recorded by the engine around its forward / backward kernels
         fwd_ms.append(f); bwd_ms.append(b)
+        tnow = time.perf_counter(); step_ms.append(round((tnow - tprev) * 1e3, 3)); tprev = tnow
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -463,7 +465,7 @@ def run_one(args, ctx):
                        "c4": "Kalman filter+smooth series*timesteps/sec (d=40)", "c4g": "Gibbs (FFBS + Inverse-Wishart step) series*timesteps/sec (d=40)",
                        "c5": "SVD filter series*timesteps/sec"}[cfg],
             "value": value, "unit": "series*timesteps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "ms_per_step": elapsed / steps * 1e3, "step_ms": step_ms, "higher_is_better": True,
             "scaling": "weak" if (world > 1 and args.scaling == "weak") else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workloads[cfg], "series_total": job_series, "series_per_gpu": N, "T": T, "d": d, "p": q,
