@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64) void k_cov_filter_sp16(KArgs a, const SparseT* 
 constexpr int SM_LDS = 2 * IMG + 3 * 16 + 2;   // backward pass: two images + three 16-vectors + the state of the steady-state test per wave
 // COV: the covariance-only run of the shared-covariance path -- this code on the C_t table (means zero): S_t, bit for bit that of
 // every series of the batch; K_t = C_t F / V and the kind of each step (steady: 1) go to kbtab [T+1][16] for the mean-only kernel.
-template <int K, bool IRR, bool PIPE = false, bool COV = false>
+template <int K, bool IRR, bool PIPE = false, bool COV = false, bool PLAIN = false>
 __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __restrict__ sp, const double* __restrict__ side,
                                               double* lds /* 4 SM_LDS doubles */, char* ring_all, double* __restrict__ kbtab = nullptr) {
   // ring_all: two-slot ring per wave for the LDS-DMA prefetch; a slot is a raw record followed by one
@@ -689,6 +689,10 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   const int n = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4 waves per block, or 1 for small batches (launch)
   if (n >= a.N) return;
   if (!COV && a.route && (a.route[n] != 0) != (a.route_take != 0)) return;   // shared-covariance call: only the series routed here
+  // PLAIN (DLM_OPT_NO_STEADY on a regular grid): no steady-state machinery at all and F, 1 / V in registers -- the kernel of round 1, for the
+  // calls whose every step is a full step (what the machinery costs them: profiles/r03_notes.md section 3)
+  constexpr bool ST = !IRR && !PLAIN;      // steady-state steps possible
+  constexpr bool FREG = IRR || PLAIN;      // F[4r+g], F[c] and 1 / V live in registers (otherwise in spare LDS columns)
   double* imgA = lds + wave * SM_LDS;
   double* imgB = imgA + IMG;
   double* vK = imgB + IMG;       // K_t
@@ -733,7 +737,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   }
   // Regular instantiation: F[4r+g] waits in the spare column 16 of image A (the images have a leading dimension of 17) and is
   // read where a step needs it -- eight registers that decide whether five waves fit a SIMD.
-  if (!IRR) {
+  if (!FREG) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) imgA[(4 * r + g) * LD + 16] = Fr[r];
     imgB[16] = rV;
@@ -764,7 +768,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   { const int t1 = T > 0 ? T - 1 : 0; neq = sd[2 * t1]; niq = sd[2 * t1 + 1]; }
   dma_record(rdma, ring_lds + (T & 1) * slotb, T * rins, lane, n16);
   { const int t1 = T > 0 ? T - 1 : 0;
-    dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * rins, lane, (!IRR && uniform_from_lane(ciq, 0) < 0.0) ? n16m : n16); }
+    dma_record(rdma, ring_lds + ((T - 1) & 1) * slotb, t1 * rins, lane, (ST && uniform_from_lane(ciq, 0) < 0.0) ? n16m : n16); }
   vQ[c] = 0.0;
   d4 out = {0.0, 0.0, 0.0, 0.0};                     // the record stored last (assigned in every step before its store)
   d4 cc = {0.0, 0.0, 0.0, 0.0};
@@ -781,7 +785,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     else if (t == T - 1) vm_wait<5>();
     else vm_wait<9>();
     // C_t is C_{t+1} (the mark on record t+1): only the mean of record t was requested, the covariance stays in the registers
-    const bool inherit = !IRR && same_next;
+    const bool inherit = ST && same_next;
     {
       const unsigned slot = ring_lds + (t & 1) * slotb;
       d4 nr;                                                 // the record as fetched: [C_t | m_t], or only m_t in column 15
@@ -797,7 +801,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     const double eq = uniform_from_lane(ceq, 0), iqraw = uniform_from_lane(ciq, 0);
     const double iq = fabs(iqraw);                           // the forward pass negates 1/Q where C_t is C_{t-1} (its steady state)
     const bool same_c = iqraw < 0.0;
-    const bool mean_only = !IRR && uniform_from_lane(niq, 0) < 0.0;   // C_{t-1} is C_{t-2}: record t-2 needs only its mean
+    const bool mean_only = ST && uniform_from_lane(niq, 0) < 0.0;   // C_{t-1} is C_{t-2}: record t-2 needs only its mean
     ceq = neq; ciq = niq;
     {
       const int tp = t > 1 ? t - 2 : 0;                      // record 0 is re-read harmlessly at the end
@@ -820,7 +824,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     // P_{t-1} = P_t and S_t = S_{t+1}.  What is left of the step is the mean: s_t = m_t + C_t q_t (four FMAs per lane on the
     // symmetric C, one cross-row sum, a transposition through LDS), q_{t-1} = G^T [q_t + F (e_t/Q_t - K.q_t)] -- no MFMA, no
     // rank-two update, no congruence -- and the record store (the covariance registers of the step before, the new mean).
-    if (!IRR && psteady && same_next && observed) {
+    if (ST && psteady && same_next && observed) {
       ++nsteady;
       was_steady = true;
       if (COV && g == 0) ((double*)(bout + (size_t)t * recs + recb))[c] = col15 ? 1.0 : vK[c];   // K_t (that of the step before) and the mark "steady step"
@@ -836,7 +840,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       for (int r = 0; r < 4; ++r) ncq = fma(cc[r], nqr[r], ncq);
       ncq = sum_g(ncq);
       const double kq = uniform_from_lane(row_sum(vK[c] * qcol), 0);   // K_t is K_{t+1}: still in vK
-      vR[c] = fma(IRR ? Fcr : imgA[c * LD + 16], eq - kq, qcol);
+      vR[c] = fma(FREG ? Fcr : imgA[c * LD + 16], eq - kq, qcol);
       imgB[c * LD + 15] = ncq;                               // column 15 of the parked S_t: one read per register fetches [S | -C q]
       wave_sync();
       qcol = vR[idx[0]] * val[0];
@@ -857,7 +861,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     // K_t = C_t F / V  (column 15 would give F.m: masked); it is K_{t+1} when the covariance was inherited
     if (!inherit) {
       d4 fr;
-      if (IRR) { fr[0] = Fr[0]; fr[1] = Fr[1]; fr[2] = Fr[2]; fr[3] = Fr[3]; }
+      if (FREG) { fr[0] = Fr[0]; fr[1] = Fr[1]; fr[2] = Fr[2]; fr[3] = Fr[3]; }
       else {
         fr[0] = lds_read64<0>(fr_lds); fr[1] = lds_read64<4 * LD * 8>(fr_lds); fr[2] = lds_read64<8 * LD * 8>(fr_lds); fr[3] = lds_read64<12 * LD * 8>(fr_lds);
         lds_fence(fr);
@@ -865,7 +869,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       double ks = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ks = fma(cc[r], fr[r], ks);
-      vK[c] = (observed && vc) ? sum_g(ks) * (IRR ? rV : imgB[16]) : 0.0;
+      vK[c] = (observed && vc) ? sum_g(ks) * (FREG ? rV : imgB[16]) : 0.0;
     }
     wave_sync();                                             // also publishes vQ of the last step
     if (COV && g == 0) ((double*)(bout + (size_t)t * recs + recb))[c] = col15 ? 0.0 : vK[c];
@@ -926,14 +930,14 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
           pk[0] = lds_read64<0>(br); pk[1] = lds_read64<4 * LD * 8>(br);
           pk[2] = lds_read64<8 * LD * 8>(br); pk[3] = lds_read64<12 * LD * 8>(br);
           pkc = lds_read64<0>(bc);
-          if (IRR) { fr[0] = Fr[0]; fr[1] = Fr[1]; fr[2] = Fr[2]; fr[3] = Fr[3]; }
+          if (FREG) { fr[0] = Fr[0]; fr[1] = Fr[1]; fr[2] = Fr[2]; fr[3] = Fr[3]; }
           else { fr[0] = lds_read64<8>(br); fr[1] = lds_read64<4 * LD * 8 + 8>(br); fr[2] = lds_read64<8 * LD * 8 + 8>(br); fr[3] = lds_read64<12 * LD * 8 + 8>(br); }
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pk), "+v"(pkc), "+v"(fr)::"memory");
         }
         const double kk = row_sum(vK[c] * (g < 2 ? qcol : pkc));  // rows 0-1: K.q, rows 2-3: K.(P K)
         const double kq = uniform_from_lane(kk, 0), kpk = uniform_from_lane(kk, 32);
         const double sc = iq + kpk;
-        const double Fc = IRR ? Fcr : imgA[c * LD + 16];
+        const double Fc = FREG ? Fcr : imgA[c * LD + 16];
         rcol = fma(Fc, eq - kq, qcol);
         const double u = fma(Fc, sc, -pkc);                  // F_i F_c (1/Q + K'PK) - F_i (PK)_c - (PK)_i F_c = F_i u_c - (PK)_i F_c
 #pragma unroll
@@ -959,7 +963,7 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
       } else Pn = congruence<K>(M, imgA, imgB, idx, val, g, c, (t & 7) == 0);
       // has P reached its limit (and will the next C be this one)?  The same geometric-tail test as in the forward pass,
       // relative to max|P|; any step off the settled, observed stretch starts it over.
-      if (!IRR && may_settle) {
+      if (ST && may_settle) {
         if (!(observed && same_c) || was_steady) { settle_reset(settle); was_steady = false; }   // off the settled, observed stretch, or back from steady steps: start over
         else if ((t & 3) == 2) {
           // (in single precision after scaling by a power of two near Q -- P is of the order of 1 / Q --: the kernel has no
@@ -988,8 +992,8 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
     // output: [S_t | s_t] = [C_t | m_t] - C_t [P_t C_t | -q_t]
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[r] = cc[r] - x2[r];
-    if (!IRR && chk) { psteady = settle_test(settle, chk_dl, chk_mx, 4); chk = false; }
-    if (!IRR && psteady) {                                   // the steady steps may begin: S_t waits for them in the idle image
+    if (ST && chk) { psteady = settle_test(settle, chk_dl, chk_mx, 4); chk = false; }
+    if (ST && psteady) {                                   // the steady steps may begin: S_t waits for them in the idle image
 #pragma unroll
       for (int r = 0; r < 4; ++r) imgB[(4 * r + g) * LD + c] = out[r];
       wave_sync();
@@ -1019,12 +1023,12 @@ __device__ __forceinline__ void smoother_body(const KArgs& a, const SparseT* __r
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
-template <int K, bool IRR, bool PIPE = false>
-__global__ __launch_bounds__(256, PIPE ? 2 : (K <= 2 ? SM_WAVES_K2 : SM_WAVES)) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
+template <int K, bool IRR, bool PIPE = false, bool PLAIN = false>
+__global__ __launch_bounds__(256, PIPE ? 2 : (PLAIN ? SM_WAVES : (K <= 2 ? SM_WAVES_K2 : SM_WAVES))) void k_smoother_sp16(KArgs a, const SparseT* __restrict__ sp,
                                                        const double* __restrict__ side) {
   __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
   extern __shared__ __attribute__((aligned(16))) char ring_all[];
-  smoother_body<K, IRR, PIPE>(a, sp, side, lds, ring_all);
+  smoother_body<K, IRR, PIPE, false, PLAIN>(a, sp, side, lds, ring_all);
 }
 // the covariance-only run: one wave alone on its SIMD (the variant whose output-product MFMAs are spread over the recursion)
 template <int K>
@@ -1743,6 +1747,7 @@ static hipError_t launch_s(const KArgs& a, const SparseT* sp, const double* side
 #ifndef DLM_PIPE_MAX
 #define DLM_PIPE_MAX 3072   // up to three waves per SIMD (measured: 1.86 -> 1.78 ms at 2500 series, 3.00 -> 3.17 at 5000)
 #endif
+  else if ((a.flags & DLM_OPT_NO_STEADY) && a.N > DLM_PIPE_MAX) hipLaunchKernelGGL((k_smoother_sp16<K, false, false, true>), grid, blk, ring, s, a, sp, side);   // every step a full step: the kernel without the machinery
   else if (a.N <= DLM_PIPE_MAX && !(a.flags & DLM_OPT_NO_PIPE)) hipLaunchKernelGGL((k_smoother_sp16<K, false, true>), grid, blk, ring, s, a, sp, side);
   else hipLaunchKernelGGL((k_smoother_sp16<K, false>), grid, blk, ring, s, a, sp, side);
   return hipGetLastError();
