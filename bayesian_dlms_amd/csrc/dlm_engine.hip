@@ -60,6 +60,8 @@ struct dlm_engine {
   size_t covws_bytes = 0;
   unsigned char* route = nullptr;
   size_t route_bytes = 0;
+  unsigned char* plainbuf = nullptr;   // KArgs::plain of the call (k_count_gaps): one byte per series
+  size_t plainbuf_bytes = 0;
   void* sampws = nullptr;       // shared factors of the backward sampler: table, the zero series' records, flags
   size_t sampws_bytes = 0;
   double* zws = nullptr;        // ... and the call's normals in the draw kernel's layout, made on a third stream while the batch is filtered
@@ -445,6 +447,22 @@ int ensure_xplus_bytes(dlm_engine* e, size_t need) {
   }
   return DLM_OK;
 }
+// Structured d <= 15 path on a regular grid: the series that miss more than T / 256 of their observations are marked (from the data
+// alone: the choice does not depend on the batch) and take every step in full -- the forward kernel without its convergence test, the
+// backward kernel in the instantiation without the shortcut's machinery.  With gaps nothing settles, and the machinery only costs.
+int mark_plain(dlm_engine* e, KArgs& k) {
+  k.plain = nullptr;
+  if (!(fast_shape_ok(k) && e->sparse_k > 0) || use_lane(k) || !k.y || k.g_index || k.dt || k.f_stride || k.v_tstride || k.w_tstride ||
+      (k.flags & DLM_OPT_NO_STEADY)) return DLM_OK;
+  if ((size_t)k.N > e->plainbuf_bytes) {
+    if (e->plainbuf) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->plainbuf)); e->plainbuf = nullptr; e->plainbuf_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->plainbuf, (size_t)k.N));
+    e->plainbuf_bytes = (size_t)k.N;
+  }
+  HIP_TRY(e, dlm::launch_sparse16_count_gaps(k, e->plainbuf, e->stream));
+  k.plain = e->plainbuf;
+  return DLM_OK;
+}
 int ensure_cov_stream(dlm_engine* e) {
   if (!e->cov_stream) {
     int lo = 0, hi = 0;   // the few waves of the table kernels go first: they run beside a kernel that fills the device
@@ -654,6 +672,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->spf_dev) (void)hipFree(e->spf_dev);
   if (e->covws) (void)hipFree(e->covws);
   if (e->route) (void)hipFree(e->route);
+  if (e->plainbuf) (void)hipFree(e->plainbuf);
   if (e->sampws) (void)hipFree(e->sampws);
   if (e->zws) (void)hipFree(e->zws);
   if (e->rng_ev) (void)hipEventDestroy(e->rng_ev);
@@ -843,6 +862,7 @@ int dlm_filter_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_param
     if ((rc = packed_path(e, k))) return rc;
     k.packed = 1;
   }
+  if ((rc = mark_plain(e, k))) return rc;
   if (use_shared_cov(e, k)) {
     dlm::CovTabs tb;
     if ((rc = run_shared_filter(e, k, tb, false))) return rc;
@@ -1025,6 +1045,7 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
     k.filt = e->fws;
   }
   if ((rc = mark(e, 0))) return rc;
+  if ((rc = mark_plain(e, k))) return rc;
   if (filt && fast_smoother_ok(e, k) && use_shared_cov(e, k)) {
     dlm::CovTabs tb;
     if ((rc = run_shared_filter(e, k, tb, true))) return rc;

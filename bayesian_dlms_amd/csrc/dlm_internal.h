@@ -42,6 +42,9 @@ struct KArgs {
   int route_take;
   unsigned long long* counters;   // engine-owned [4], zeroed per call (nullable): steady (short) steps taken by the forward [0] / backward [1] kernel,
                                   // series served by the shared-covariance kernels [2], series sent to their own full recursion [3]
+  const unsigned char* plain;     // structured d <= 15 path, regular grid (nullable): plain[n] = 1 -- series n misses enough observations (more than T / 256)
+                                  // that its covariance recursion is not worth testing for convergence: it takes every step in full, in the
+                                  // backward kernel's instantiation without the shortcut's machinery (k_count_gaps fills it from the data alone)
   int stretches;                  // backward sampler: 1 = every stretch of steps starts from scratch (dlm_sampler16.hip: SF_STRETCH), set for the calls
                                   // whose parameters allow a shared-factor table -- its stretches are made side by side, and a series that computes
                                   // its own factors in such a call follows the same rule, so that the two agree bit for bit
@@ -89,6 +92,7 @@ hipError_t launch_small_mv_sampler(const KArgs& a, hipStream_t s);   // the same
 hipError_t launch_sparse16_rts(const KArgs& a, int K, const SparseT* tabs_dev, hipStream_t s);
 hipError_t launch_small_mv_rts(const KArgs& a, hipStream_t s);
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s);
+hipError_t launch_sparse16_count_gaps(const KArgs& a, unsigned char* plain, hipStream_t s);   // KArgs::plain of the call from its observations
 // ---- shared covariance sequence: with parameters shared by the batch and no missing observation C_t, R_t, K_t,
 // Q_t, P_t and S_t do not depend on the data.  ONE wave runs the covariance recursions (the per-series kernels' own code on a
 // series of zeros: the same arithmetic, bit for bit) into L2-resident tables, and every series runs only its mean recursions

@@ -464,7 +464,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
   // m = a + K e: a gather on one 16-vector instead of the congruence, the products with F and the rank-one update.  The
   // record (the same C, the new m) is stored as always.  A missing observation takes the full step again (C changes),
   // and the test starts over.  The backward pass learns from the sign of the side record's 1/Q that C_t is C_{t-1}.
-  const bool may_settle = !IRR && !(a.flags & DLM_OPT_NO_STEADY);   // (the simulation smoother's pass too: y* has the covariance recursion of y)
+  const bool may_settle = !IRR && !(a.flags & DLM_OPT_NO_STEADY) && !(a.plain && a.plain[n]);   // (the simulation smoother's pass too: y* has the covariance recursion of y)
   bool steady = false;
   float* settle = (float*)(imgA + 2 * IMG + 8 * 16);   // state of the steady-state test (dlm_internal.h)
   settle_reset(settle);
@@ -1028,7 +1028,23 @@ __global__ __launch_bounds__(256, PIPE ? 2 : (PLAIN ? SM_WAVES : (K <= 2 ? SM_WA
                                                        const double* __restrict__ side) {
   __shared__ __attribute__((aligned(16))) double lds[4 * SM_LDS];
   extern __shared__ __attribute__((aligned(16))) char ring_all[];
+#ifndef DLM_NO_PLAIN_MIX   // (A/B builds only)
+  if constexpr (!IRR && !PLAIN) {   // a series marked by its gaps (KArgs::plain) takes the body without the shortcut's machinery
+    const int n = blockIdx.x * (int)(blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (a.plain && n < a.N && a.plain[n]) { smoother_body<K, false, PIPE, false, true>(a, sp, side, lds, ring_all); return; }
+  }
+#endif
   smoother_body<K, IRR, PIPE, false, PLAIN>(a, sp, side, lds, ring_all);
+}
+// plain[n] = 1 where series n misses more than T / 256 of its observations (p = 1)
+__global__ __launch_bounds__(256) void k_count_gaps(const double* __restrict__ y, int N, int T, unsigned char* __restrict__ plain) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const double* yn = y + (size_t)n * T;
+  int cnt = 0;
+  for (int t = lane; t < T; t += 64) { const double v = yn[t]; cnt += (v == v) ? 0 : 1; }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) plain[n] = (cnt * 256 > T) ? 1 : 0;
 }
 // the covariance-only run: one wave alone on its SIMD (the variant whose output-product MFMAs are spread over the recursion)
 template <int K>
@@ -1779,7 +1795,7 @@ hipError_t launch_sparse16_simsmooth(const KArgs& a, int K, const SparseT* tabs_
 static KArgs cov_args(const KArgs& a, const CovTabs& tb) {
   KArgs k = a;
   k.N = 1; k.y = nullptr; k.status = nullptr; k.route = nullptr; k.counters = nullptr; k.loglik = nullptr; k.prior = nullptr; k.fq = nullptr;
-  k.filt = tb.ftab; k.filt_in = tb.ftab; k.smooth = tb.btab; k.packed = 0; k.m0_stride = 0;
+  k.filt = tb.ftab; k.filt_in = tb.ftab; k.smooth = tb.btab; k.packed = 0; k.m0_stride = 0; k.plain = nullptr;
   return k;
 }
 template <int K>
@@ -1823,6 +1839,10 @@ hipError_t launch_sparse16_mean_filter(const KArgs& a, int K, const SparseT* row
 hipError_t launch_sparse16_mean_smoother(const KArgs& a, int K, const SparseT* cols_dev, const CovTabs& tabs, hipStream_t s) { DLM_K_SWITCH(launch_ms, a, cols_dev, tabs, s) }
 #undef DLM_K_SWITCH
 
+hipError_t launch_sparse16_count_gaps(const KArgs& a, unsigned char* plain, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, plain);
+  return hipGetLastError();
+}
 hipError_t launch_sparse16_smoother(const KArgs& a, int K, const SparseT* cols_dev, const double* side, hipStream_t s) {
   switch (K) {
     case 1: return launch_s<1>(a, cols_dev, side, s);

@@ -269,7 +269,6 @@ def add_secondary(line, args, ctx):
     line["value_full_recursion"] = full["value"]        # every step recomputes the covariance recursion (DLM_OPT_NO_STEADY)
     line["value_missing_0.05"] = miss["value"]          # 5 % of the observations missing (SURVEY 8d's second run)
     sec = {"c2_full_recursion": brief(full), "c2_missing_0.05": brief(miss)}
-    sec["c2_missing_0.05_full_recursion"] = brief(run(missing=0.05, flags=_lib.OPT_NO_STEADY, steps=5, warmup=1))   # nothing settles with gaps: the kernels without the shortcut's machinery
     sec["c2_literal_q1"] = brief(run(semantics="literal-q1", steps=3, warmup=1))
     sec["c2_shared_covariance_opt_in"] = brief(run(flags=_lib.OPT_SHARED_COV, steps=5, warmup=1))
     sec["c3_reference_sampler"] = brief(run(config="c3", sampler="reference", steps=3, warmup=2))

@@ -118,6 +118,36 @@ def test_freeze_gap_refreeze_late(eng):
     assert rel_cov_err(eng.unpack_records(13, pk["smooth"]), full["smooth"], 13) <= 5e-11
 
 
+@pytest.mark.parametrize("N", [7, 3300])
+def test_series_with_many_gaps_take_every_step_in_full(eng, N):
+    """A series that misses more than T / 256 of its observations is marked from its data alone (k_count_gaps) and never tests its
+    covariance recursion for convergence: forward kernel without the test, backward kernel in the instantiation without the
+    shortcut's machinery -- bit for bit the DLM_OPT_NO_STEADY call for that series, whatever the batch (both batch-size variants
+    of the backward kernel); the other series keep the shortcut."""
+    T = 700
+    mat, p = c2(T)
+    rng = np.random.default_rng(N)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    gaps = rng.random((T,)) < 0.05
+    y[1, gaps, 0] = np.nan                                  # ~35 gaps: marked
+    y[3, 450, 0] = np.nan                                   # one gap: not marked
+    fast = eng.filter_smooth(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
+    nf = eng.last_counters()[0]
+    full = eng.filter_smooth(mat, p, y, flags=_lib.OPT_NO_STEADY)
+    assert nf > 0                                           # (the others do take their short steps)
+    for name in ("filt", "smooth"):
+        assert np.array_equal(fast[name][1], full[name][1], equal_nan=True), name       # the marked series: the every-step path
+        assert rel_cov_err(fast[name], full[name], 13) <= 5e-11
+    C3 = fast["filt"][3][:, 13:]
+    assert np.array_equal(C3[449], C3[430])                 # the series with one gap had settled before it
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[1])
+    s_ = oracle.smoother(omodel(mat), f)
+    np.testing.assert_allclose(fast["smooth"][1][:, :13], s_["s"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(fast["smooth"][1][:, 13:], s_["S"], rtol=1e-8, atol=1e-9)
+    alone = eng.filter_smooth(mat, p, y[1:2])               # the same series in a batch of one: the same bits
+    assert np.array_equal(alone["smooth"][0], fast["smooth"][1], equal_nan=True)
+
+
 @pytest.mark.parametrize("wscale,T", [(1.0, 300), (1e-3, 3000)])
 def test_per_wave_kernels_slow_regime(eng, wscale, T):
     """k_filter_w48 / k_smoother_w48 (16 <= d <= 48): the C4-type model with its W scaled down."""
