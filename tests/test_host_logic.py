@@ -239,8 +239,10 @@ def test_headline_kernels_keep_their_occupancy(tmp_path):
     waves per SIMD) and the forward kernel at <= 96 (five), with no spills -- except, since round 3, ONE value of the backward kernel
     (an LDS address of the transposed read) that lives in scratch and is reloaded only in the every-8th-step symmetrisation branch:
     with the error-bounded steady-state test the allocator needs 98 registers otherwise, and five waves with that reload measured
-    1.5 % faster than four without (profiles/r03_notes.md).  A change that costs a wave per SIMD costs ~3 % of the headline and shows
-    up nowhere else -- so the build is checked here (device-only assembly of dlm_sparse16.hip, ~10 s)."""
+    1.5 % faster than four without (profiles/r03_notes.md).  Since the gap-marked series take the body without the shortcut's machinery
+    inside the same kernel (two inlined bodies) three values are spilled; same-box A/B on the headline: backward 6.05 / 5.96 / 5.95 ms
+    with, 5.98 / 5.96 / 5.96 ms without (profiles/r03_notes.md section 3).  A change that costs a wave per SIMD costs ~3 % of the
+    headline and shows up nowhere else -- so the build is checked here (device-only assembly of dlm_sparse16.hip, ~10 s)."""
     import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -257,8 +259,8 @@ def test_headline_kernels_keep_their_occupancy(tmp_path):
         m = re.match(r"\s*\.(vgpr_count|vgpr_spill_count):\s+(\d+)", line)
         if m and name:
             meta.setdefault(name, {})[m.group(1)] = int(m.group(2))
-    bwd = [v for k, v in meta.items() if "k_smoother_sp16ILi2ELb0ELb0E" in k]
+    bwd = [v for k, v in meta.items() if "k_smoother_sp16ILi2ELb0ELb0ELb0E" in k]       # <K = 2, IRR = false, PIPE = false, PLAIN = false>
     fwd = [v for k, v in meta.items() if "k_filter_sp16ILi2ELb0ELb0ELb0E" in k]
     assert len(bwd) == 1 and len(fwd) == 1, sorted(meta)
-    assert bwd[0]["vgpr_count"] <= 96 and bwd[0]["vgpr_spill_count"] <= 1, bwd
+    assert bwd[0]["vgpr_count"] <= 96 and bwd[0]["vgpr_spill_count"] <= 3, bwd
     assert fwd[0]["vgpr_count"] <= 96 and fwd[0]["vgpr_spill_count"] == 0, fwd
