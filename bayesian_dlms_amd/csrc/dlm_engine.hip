@@ -474,7 +474,7 @@ int ensure_cov_stream(dlm_engine* e) {
 }
 // Shared factors of the reference-form backward sampler (dlm_sampler16.hip): the tables are made on the second
 // stream -- a filter and a sampler run of ONE wave on a series of zeros -- while the batch is filtered on the first.
-int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big) {
+int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big, const double* crec = nullptr, int crec_stride = 0) {
   const size_t need = big ? dlm::wave48_sampler_shared_ws_bytes(k) : dlm::sampler_shared_ws_bytes(k);
   if (need > e->sampws_bytes) {
     if (e->sampws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->sampws)); e->sampws = nullptr; e->sampws_bytes = 0; }
@@ -486,7 +486,9 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   if (big) dlm::wave48_sampler_shared_carve(e->sampws, k, tb); else dlm::sampler_shared_carve(e->sampws, k, tb);
   HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));               // the model and the tables of G are staged
   HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
+  tb.zstride = 0; tb.mc4 = nullptr;
   if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_tables(k, tb, e->cov_stream));
+  else if (crec) HIP_TRY(e, dlm::launch_sampler_shared_tables_from(k, e->sparse_k, e->sp_dev, tb, crec, crec_stride, e->cov_stream));   // the covariances exist already
   else HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
   HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
   tb.z4 = nullptr;
@@ -1066,10 +1068,10 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
 static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
                           const double* y, const double* z, const dlm_options* opts,
                           const double* filt_in, double* filt_ws, double* theta, double* cond,
-                          double* stats, int32_t* status) {
+                          double* stats, int32_t* status, bool forward) {
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
-  const bool forward = filt_ws != nullptr;
+  const bool norec = forward && !filt_ws;     // dlm_ffbs_batch that does not want the filter records
   if (forward && !y) return fail(e, DLM_ERR_ARG, "y is required");
   if (!forward && !filt_in) return fail(e, DLM_ERR_ARG, "filter records are required");
   if (stats && !y) return fail(e, DLM_ERR_ARG, "sufficient statistics need y");
@@ -1086,8 +1088,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes a time-invariant W, and a V_t stream only on the structured d <= 15, p = 1 path (drop DLM_OPT_FFBS_SIMSMOOTH otherwise)");
   st.in(&k.y, y, y ? N * T * p : 0);
   st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + p : d) : 0);
-  if (forward) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
-  else st.in(&k.filt_in, filt_in, N * (T + 1) * rec);
+  if (forward && !norec) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
+  else if (!forward) st.in(&k.filt_in, filt_in, N * (T + 1) * rec);
   st.out(&k.theta, theta, N * (T + 1) * d);
   st.out(&k.cond, cond, N * (T + 1) * rec);
   st.out(&k.stats, stats, N * (size_t)dlm_stats_len(model->d, model->p, opts->flags));
@@ -1096,6 +1098,10 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   // the stretches of the reference-form sampler (KArgs::stretches): wherever a shared-factor table is possible for these parameters,
   // whether or not this call uses one -- a series' draws do not depend on the route it takes
   k.stretches = (dlm::sampler_shared_model_ok(k) || dlm::wave48_sampler_shared_model_ok(k)) ? 1 : 0;
+  if (norec) {   // the records of the forward pass are nobody's output: an engine workspace
+    if ((rc = ensure_fws(e, N * (T + 1) * rec * sizeof(double)))) return rc;
+    k.filt = e->fws;
+  }
   if (forward) {
     if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
     if ((rc = mark(e, 0))) return rc;
@@ -1129,9 +1135,28 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need a fast path (structured d <= 15 or 16 <= d <= 48)");
     shared_factors = !simflag && !use_lane(k) && fast_shape_ok(k) && e->sparse_k > 0 && dlm::sampler_shared_eligible(k);
     shared_big = !simflag && !shared_factors && use_tiled(k) && dlm::wave48_sampler_shared_eligible(k);   // 16 <= d <= 48 on the per-wave kernels
-    if ((shared_factors || shared_big) && (rc = start_sampler_tables(e, k, stb, shared_big))) return rc;
-    if ((rc = run_filter(e, k, false))) return rc;
-    k.filt_in = k.filt;
+    if (norec && shared_factors) {
+      // No records AND shared factors (d <= 15): nothing of the filtered covariances is needed per series -- the draw kernel reads the
+      // means, the table is made from the covariance recursion alone.  So the forward pass is section 4.9's: one wave's covariance
+      // recursion into a table, a mean-only kernel per series (compact means, 128 instead of 1456 bytes per series-step at d = 13);
+      // the table of factors is made from that covariance table while the mean kernel runs; a series with a missing observation is
+      // marked by the mean kernel and runs its own filter and sampler on the workspace.
+      dlm::CovTabs ctb;
+      if ((rc = ensure_shared(e, k, ctb, true))) return rc;
+      k.route = e->route; k.route_take = 0; k.filt = nullptr;
+      HIP_TRY(e, dlm::launch_sparse16_cov_filter(k, e->sparse_k, e->sp_dev, ctb, e->stream));
+      if ((rc = start_sampler_tables(e, k, stb, false, ctb.ftab, ctb.frow))) return rc;
+      HIP_TRY(e, dlm::launch_sparse16_mean_filter(k, e->sparse_k, e->sp_dev, ctb, e->stream));
+      stb.mc4 = ctb.mc;
+      KArgs kg = k;
+      kg.route_take = 1; kg.filt = e->fws;
+      HIP_TRY(e, dlm::launch_sparse16_filter(kg, e->sparse_k, e->sp_dev, nullptr, nullptr, e->stream));
+      k.filt_in = e->fws;
+    } else {
+      if ((shared_factors || shared_big) && (rc = start_sampler_tables(e, k, stb, shared_big))) return rc;
+      if ((rc = run_filter(e, k, false))) return rc;
+      k.filt_in = k.filt;
+    }
   }
   if (!forward && ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST)) || (rc = mark(e, 0)))) return rc;   // the structure tables of G
   if ((rc = mark(e, 1))) return rc;
@@ -1182,15 +1207,14 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
 int dlm_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_params_desc* params,
                    const double* y, const double* z, const dlm_options* opts, double* filt_ws,
                    double* theta, double* cond, double* stats, int32_t* status) {
-  if (e && !filt_ws) return fail(e, DLM_ERR_ARG, "filt_ws workspace is required");
-  return sampler_common(e, model, params, y, z, opts, nullptr, filt_ws, theta, cond, stats, status);
+  return sampler_common(e, model, params, y, z, opts, nullptr, filt_ws, theta, cond, stats, status, true);
 }
 
 int dlm_backward_sample_batch(dlm_engine* e, const dlm_model_desc* model,
                               const dlm_params_desc* params, const double* y, const double* filt,
                               const double* z, const dlm_options* opts, double* theta,
                               double* cond, double* stats, int32_t* status) {
-  return sampler_common(e, model, params, y, z, opts, filt, nullptr, theta, cond, stats, status);
+  return sampler_common(e, model, params, y, z, opts, filt, nullptr, theta, cond, stats, status, false);
 }
 
 int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,

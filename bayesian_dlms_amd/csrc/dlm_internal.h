@@ -129,6 +129,9 @@ struct SampTabs {
   int* status;           // status of the zero series' two kernels, for every series served by the tables
   double* z4;            // the normals of the call, made while the batch is filtered.  d <= 15 (k_normals4): [ceil(N / 4)][T+1][4][16], 512 bytes per step
                          //   and wave of the draw kernel; 16 <= d <= 48 (k_normals_rows): [N][T+1][d].  nullptr: injected normals (KArgs::z)
+  int zstride;           // d <= 15, table kernel: bytes between the records of the series of zeros (0: d + d^2 doubles; the rows of CovTabs::ftab otherwise)
+  const double* mc4;     // d <= 15, draw kernel: the filtered means come from the mean-only forward kernel's compact stream ([ceil(N / 4)][T+1][4][16],
+                         //   CovTabs::mc) instead of the filter records: a dlm_ffbs_batch call that does not want the records (filt_ws == NULL)
   int* settle;           // index of the last record of zrec that was written (KArgs::settle_step): the records above it repeat its covariance
 };
 bool sampler_shared_model_ok(const KArgs& a);   // V, W, C0 shared by the batch, regular grid, time-invariant model (what KArgs::stretches follows)
@@ -137,6 +140,8 @@ size_t sampler_shared_ws_bytes(const KArgs& a);
 void sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
 // the tables: filter on zeros, then the sampler with its export on (both one wave; stream s)
 hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
+// the same from covariance records that exist already (crec, stride bytes apart: the forward table of the shared-covariance kernels)
+hipError_t launch_sampler_shared_tables_from(const KArgs& a, int K, const SparseT* tabs_dev, SampTabs tb, const double* crec, int stride, hipStream_t s);
 size_t sampler_shared_normals_bytes(const KArgs& a);
 hipError_t launch_sampler_shared_normals(const KArgs& a, double* z4, hipStream_t s);   // the Philox normals of every series and step, in the draw kernel's layout
 // a.route [N] is filled here (series with a missing observation), the mean-only kernel draws for the others, k_sampler_sp16 for these

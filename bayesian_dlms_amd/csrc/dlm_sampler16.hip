@@ -228,7 +228,8 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     Wt[r] = va[r] ? W0[i + c * d] : 0.0;
   }
   const int offM = (vc && g == 0) ? c * 8 : OOB;
-  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const int rstr = (EXP && tb.zstride) ? tb.zstride : recb;   // bytes between the input records (the table kernel may read the rows of a covariance table)
+  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * rstr);
   double* cond = a.cond ? a.cond + (size_t)n * (T + 1) * rec : nullptr;
   const __amdgpu_buffer_rsrc_t rco = mk_rsrc(cond, cond ? (size_t)(T + 1) * recb : 0);
   double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   if (!EXP || t_hi == T - 1) {   // theta_T ~ N(m_T, C_T)
     d4 C;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) C[r] = bld(rin, offC[r], T * recb);
-    const double mc = bld(rin, vc ? c * 8 : OOB, T * recb);
+    for (int r = 0; r < 4; ++r) C[r] = bld(rin, offC[r], T * rstr);
+    const double mc = bld(rin, vc ? c * 8 : OOB, T * rstr);
     const double zc = (vc && !EXP) ? (zin ? zin[(size_t)T * d + c] : philox_normal(a.seed, series, (unsigned)T, (unsigned)c)) : 0.0;
     double rows[15];
     factor(C, rows);
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   {
     const int tp = t_hi > 0 ? t_hi : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
-    nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
+    for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * rstr);
+    nm = bld(rin, vc ? c * 8 : OOB, tp * rstr);
   }
   const bool f1 = p == 1 && !a.f_stride;
   const double Fl1 = (f1 && lane < d) ? a.F[lane] : 0.0;
@@ -344,8 +345,8 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
     {
       const int tp = t > 0 ? t - 1 : 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
-      nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
+      for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * rstr);
+      nm = bld(rin, vc ? c * 8 : OOB, tp * rstr);
     }
     const double zc = (vc && !EXP) ? (zin ? zin[(size_t)t * d + c] : zq[16 * ((T - 1 - t) & 3) + c]) : 0.0;
     if (a.w_tstride) {
@@ -600,9 +601,13 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
 #pragma unroll
   for (int s = 0; s < K; ++s) { idx[s] = (16 * j + sp[0].idx[c][s]) * 8; val[s] = vc ? sp[0].val[c][s] : 0.0; }
   const size_t sbytes = (size_t)(T + 1) * recb;
-  const i4 rmean = rsrc_words((const char*)a.filt_in + (size_t)n0 * sbytes, (unsigned)((size_t)nser * sbytes));
+  // the filtered means: the head of each series' records -- or, when the call keeps no records, the mean-only forward kernel's compact stream
+  const bool cm = tb.mc4 != nullptr;
+  const int mstep = cm ? 512 : recb;                 // bytes between two steps of the means
+  const i4 rmean = cm ? rsrc_words(tb.mc4 + (size_t)(n0 / 4) * (T + 1) * 64, (unsigned)((size_t)(T + 1) * 512))
+                      : rsrc_words((const char*)a.filt_in + (size_t)n0 * sbytes, (unsigned)((size_t)nser * sbytes));
   const i4 rtab = rsrc_words(tb.rows, (unsigned)((size_t)(T + 1) * SF_ROW * 8));
-  const int mvoff = (lane < 32 && (lane >> 3) < nser) ? (int)((size_t)(lane >> 3) * sbytes) + (lane & 7) * 16 : OOB;   // 16 doubles from the head of each record
+  const int mvoff = cm ? lane * 16 : ((lane < 32 && (lane >> 3) < nser) ? (int)((size_t)(lane >> 3) * sbytes) + (lane & 7) * 16 : OOB);   // 16 doubles from the head of each record
   const unsigned ring_lds = lds_addr_of(ring), mring_lds = ring_lds + 2 * SF_SLOT;
   const unsigned vT_lds = lds_addr_of(vT);
   const int n16 = d * (SF_ENT / 2);                  // 16-byte pieces of a row that travel
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
   };
 
   // requests: the means of steps T .. T - SF_AHEAD + 1 (the oldest), then the table rows T and T - 1
-  for (int k = 0; k < SF_AHEAD; ++k) { const int tk = T - k > 0 ? T - k : 0; dma_means(mring_lds + ((T - k) & (SF_AHEAD - 1)) * 512, tk * recb); }
+  for (int k = 0; k < SF_AHEAD; ++k) { const int tk = T - k > 0 ? T - k : 0; dma_means(mring_lds + ((T - k) & (SF_AHEAD - 1)) * 512, tk * mstep); }
   if constexpr (ZD) for (int k = 0; k < 4; ++k) dma_z(T - k);   // the normals of steps T .. T - 3
   dma_row<NR>(rtab, ring_lds + (T & 1) * SF_SLOT, T * (SF_ROW * 8), lane, n16);
   dma_row<NR>(rtab, ring_lds + ((T - 1) & 1) * SF_SLOT, (T > 0 ? T - 1 : 0) * (SF_ROW * 8), lane, n16);
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
     read_row(slot, false);
     thc = draw(vc ? mr : 0.0, vZ + (T & 3) * 64);
     wave_sync();
-    dma_means(mslot, (T > SF_AHEAD ? T - SF_AHEAD : 0) * recb);
+    dma_means(mslot, (T > SF_AHEAD ? T - SF_AHEAD : 0) * mstep);
     if (nd2) dma_row<NR>(rtab, slot, (T - 2) * (SF_ROW * 8), lane, n16);
     if constexpr (ZD) dma_z(T - 4);
     bst(rth, offth, T * d * 8, thc);
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
     else if constexpr (K == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(mg[0]), "+v"(mg[1]), "+v"(mg[2])::"memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(mg[0]), "+v"(mg[1]), "+v"(mg[2]), "+v"(mg[3])::"memory");
     if (nd0) read_row(slot, true);
-    dma_means(mslot, (t > SF_AHEAD ? t - SF_AHEAD : 0) * recb);
+    dma_means(mslot, (t > SF_AHEAD ? t - SF_AHEAD : 0) * mstep);
     if (nd2) dma_row<NR>(rtab, slot, (t - 2) * (SF_ROW * 8), lane, n16);
     const double mc = vc ? mr : 0.0;
     double a1 = 0.0;
@@ -1012,7 +1017,7 @@ bool sampler_shared_model_ok(const KArgs& a) {
          !a.packed && a.T >= 1 && a.T <= 400000 && 4 * ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);   // four series' records under one buffer resource
 }
 bool sampler_shared_eligible(const KArgs& a) {
-  return sampler_shared_model_ok(a) && !a.cond && a.filt && (!a.stats || a.y) &&
+  return sampler_shared_model_ok(a) && !a.cond && (!a.stats || a.y) &&
          !(a.flags & (DLM_OPT_STATS_OUTER | DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16 | DLM_OPT_SAMPLER_PER_SERIES)) &&
          (a.N >= DLM_SAMPLER_SHARED_MIN || (a.flags & DLM_OPT_NO_SMALL_BATCH));
 }
@@ -1091,10 +1096,28 @@ hipError_t launch_sampler_shared_normals(const KArgs& a, double* z4, hipStream_t
   hipLaunchKernelGGL(k_normals4, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, z4);
   return hipGetLastError();
 }
+hipError_t launch_sampler_shared_tables_from(const KArgs& a, int K, const SparseT* tabs_dev, SampTabs tb, const double* crec, int stride, hipStream_t s) {
+  hipError_t err = hipMemsetAsync(tb.status, 0, sizeof(int), s);
+  if (err != hipSuccess) return err;
+  KArgs kp = a;
+  kp.N = 1; kp.y = nullptr; kp.filt_in = crec; kp.filt = nullptr; kp.status = tb.status; kp.stats = nullptr; kp.loglik = nullptr; kp.prior = nullptr; kp.fq = nullptr;
+  kp.route = nullptr; kp.counters = nullptr; kp.theta = nullptr; kp.z = nullptr; kp.series_offset = 0; kp.m0_stride = 0;
+  tb.zstride = stride;
+  const dim3 grid((a.T + s16::SF_STRETCH - 1) / s16::SF_STRETCH);
+  switch (K) {
+    case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 3: hipLaunchKernelGGL((s16::k_sampler_sp16<3, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
+    case 4: hipLaunchKernelGGL((s16::k_sampler_sp16<4, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s) {
   if (!a.route) return hipErrorInvalidValue;
   hipError_t err;
-  if (a.y) hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, a.route);
+  if (tb.mc4) { /* the mean-only forward kernel has marked the series it left */ }
+  else if (a.y) hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, a.route);
   else if ((err = hipMemsetAsync(a.route, 0, (size_t)a.N, s)) != hipSuccess) return err;
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;

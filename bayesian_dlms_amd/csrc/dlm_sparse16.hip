@@ -1817,7 +1817,8 @@ static hipError_t launch_mf(const KArgs& a, const SparseT* sp, const CovTabs& tb
 #define DLM_MF(MODE) { if (a.d <= 10) hipLaunchKernelGGL((k_mean_filter_sp16<K, 4, MODE>), grid, blk, ring, s, a, sp, tb); \
                       else if (a.d <= 13) hipLaunchKernelGGL((k_mean_filter_sp16<K, 6, MODE>), grid, blk, ring, s, a, sp, tb); \
                       else hipLaunchKernelGGL((k_mean_filter_sp16<K, 8, MODE>), grid, blk, ring, s, a, sp, tb); }
-  if (tb.mc) DLM_MF(2)                   // fused call: records, and compact means for the backward kernel
+  if (tb.mc && !a.filt) DLM_MF(0)        // dlm_ffbs_batch that keeps no records: the compact means alone (for the shared-factor draw kernel)
+  else if (tb.mc) DLM_MF(2)              // fused call: records, and compact means for the backward kernel
   else DLM_MF(1)                         // dlm_filter_batch: records only
 #undef DLM_MF
   return hipGetLastError();

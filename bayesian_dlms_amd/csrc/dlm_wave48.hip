@@ -2726,7 +2726,7 @@ bool wave48_sampler_shared_model_ok(const KArgs& a) {
          !a.packed && a.T >= 1 && a.T <= 100000 && ((size_t)a.T + 1) * rec * 8 < ((size_t)1 << 31);
 }
 bool wave48_sampler_shared_eligible(const KArgs& a) {
-  return wave48_sampler_shared_model_ok(a) && wave48_sampler_supported(a) && wave48_filter_supported(a) && !a.cond && a.filt && (!a.stats || a.y) &&
+  return wave48_sampler_shared_model_ok(a) && wave48_sampler_supported(a) && wave48_filter_supported(a) && !a.cond && (!a.stats || a.y) &&
          !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_NO_SAMPLER16 | DLM_OPT_SAMPLER_PER_SERIES));
 }
 static size_t up64w(size_t x) { return (x + 63) & ~(size_t)63; }

@@ -367,8 +367,9 @@ class Engine:
         return tuple(int(v) for v in c)
 
     def ffbs(self, mat, params, y, *, z=None, seed=0, series_offset=0, flags=0, want_theta=True,
-             want_cond=False, want_stats=True, filt=None):
-        """FFBS (filt=None) or backward sampling from existing filter records (filt given)."""
+             want_cond=False, want_stats=True, filt=None, want_filt=True):
+        """FFBS (filt=None) or backward sampling from existing filter records (filt given).  want_filt=False: the forward
+        pass's records are not wanted (dlm_ffbs_batch with filt_ws = NULL)."""
         be = self._backend(y)
         N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
         rec = d + d * d
@@ -382,7 +383,7 @@ class Engine:
         stats = be.empty((N, L)) if want_stats else None
         status = be.empty((N,), np.int32)
         if filt is None:
-            ws = be.empty((N, T + 1, rec))
+            ws = be.empty((N, T + 1, rec)) if want_filt else None
             self._check(self.lib.dlm_ffbs_batch(self.h, md, pd, be.ptr(yb), be.ptr(zb), op, be.ptr(ws),
                                                 be.ptr(theta), be.ptr(cond), be.ptr(stats), be.ptr(status)))
         else:

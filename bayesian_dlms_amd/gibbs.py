@@ -127,7 +127,7 @@ class GibbsSampling:
         the reference's arithmetic: raw W in the time update and sqrt(W) in the sampler (Q9)."""
         quirks = (_lib.OPT_SVD_RAW_W_Q2 | _lib.OPT_SVD_SAMPLER_Q9) if literal else 0
 
-        def run(mat, params, yy, seed, series_offset, flags, want_theta, want_stats):
+        def run(mat, params, yy, seed, series_offset, flags, want_theta, want_stats, want_filt=False):
             return engine.svd_ffbs(mat, params, yy, seed=seed, series_offset=series_offset, flags=flags | quirks, want_stats=want_stats)
         return _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, pooled,
                       series_offset, allreduce, keep_theta, run, wishart=False, simsmooth=False)
@@ -155,7 +155,7 @@ def gibbs_dinvgamma_device(mod: Dlm, prior_v: InverseGamma, prior_w: InverseGamm
     for it in range(n_iter):
         packed = (V.reshape(-1), p * p, W.reshape(-1), d * d, m0, 0, C0, 0)
         out = engine.ffbs(mat, packed, y, seed=seed * 1000003 + it, series_offset=series_offset, flags=flags,
-                          want_theta=False, want_stats=True)
+                          want_theta=False, want_stats=True, want_filt=False)
         stats = out["stats"]
         del out     # (the filter workspace returns to the allocator before the next call asks for one)
         V, W = engine.dinvgamma_step(d, p, stats, prior_v, prior_w, iteration=it, seed=seed, series_offset=series_offset)
@@ -189,7 +189,7 @@ def _gibbs(mod, prior_v, prior_w, init_params, times, y, engine, n_iter, seed, p
     rng = np.random.default_rng(seed)            # identical on every rank (pooled draws agree)
     for it in range(n_iter):
         out = run(mat, params, y, seed=seed * 1000003 + it, series_offset=series_offset, flags=flags,
-                  want_theta=keep_theta, want_stats=True)
+                  want_theta=keep_theta, want_stats=True, want_filt=False)     # (a Gibbs iteration never looks at the filter's records)
         stats = out["stats"] if on_device else np.asarray(out["stats"])
         theta = ((out["theta"] if on_device else np.asarray(out["theta"])) if keep_theta else None)
         status = out.get("status")

@@ -282,7 +282,9 @@ int dlm_last_counters(dlm_engine *e, uint64_t out[4]);
  * Replaces Smoothing.ffbsDlm (Smoothing.scala:173-180) and, when `stats` is given, the
  * sums inside GibbsSampling.sampleObservationMatrix / sampleSystemMatrix
  * (Gibbs.scala:23-78) or GibbsWishart.sampleSystemMatrix (GibbsWishart.scala:16-35).
- *   filt_ws [N][T+1][d+d*d]  workspace for the forward pass (required)
+ *   filt_ws [N][T+1][d+d*d]  the forward pass's records (the caller's to read afterwards); NULL: not wanted -- the engine keeps
+ *                            them in a workspace of its own, and where the batch shares V, W, C0 on a regular grid (d <= 15) it
+ *                            does not produce them at all: a mean-only forward pass against one covariance table
  *   z       [N][T+1][d]      injected standard normals; NULL = Philox4x32-10 stream
  *                            keyed by (opts->seed, opts->series_offset + n, t, i)
  *   theta   [N][T+1][d]      the draw                     optional

@@ -225,3 +225,60 @@ def test_multivariate_injected_normals_against_the_oracle(eng):
     q = mat.p
     np.testing.assert_allclose(sh["stats"][1][:q], st["ssy"], rtol=1e-9)
     np.testing.assert_allclose(sh["stats"][1][2 * q:-1], st["outer"], rtol=1e-8, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# dlm_ffbs_batch that does not want the filter's records (filt_ws = NULL): with shared factors at d <= 15 the forward pass is the
+# mean-only kernel against one covariance table (no record is produced at all); otherwise an engine workspace takes them
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,N", [(1000, 37), (1, 5), (2, 3), (65, 4), (129, 300)])
+def test_without_filter_records_the_same_draws(eng, T, N):
+    mat, p = c2(T)
+    rng = np.random.default_rng(200 + T + N)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    if N > 4:
+        y[1, T // 2, 0] = np.nan
+        y[4, 0, 0] = np.nan
+    ngap = 2 if N > 4 else 0
+    ref = eng.ffbs(mat, p, y, seed=21, series_offset=9, flags=_lib.OPT_SAMPLER_PER_SERIES)
+    out = eng.ffbs(mat, p, y, seed=21, series_offset=9, want_filt=False, flags=_lib.OPT_COUNT_STEPS)
+    assert eng.last_variant == "sparse16-sampler-shared" and out["filt"] is None
+    cnt = eng.last_counters()
+    assert cnt[2] >= N - ngap and cnt[3] >= ngap, cnt        # (the mean-only forward kernel counts its series too)
+    for k in ("theta", "stats", "status"):
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
+
+
+def test_without_filter_records_other_shapes_and_fallbacks(eng):
+    rng = np.random.default_rng(77)
+    for d in (6, 11, 15):
+        T = 140
+        Gm = 0.8 * np.eye(d) + 0.15 * np.eye(d, k=1)
+        Fv = rng.standard_normal((d, 1))
+        mat = materialise(Dlm(lambda t: Fv, lambda dt: Gm), np.arange(1, T + 1, dtype=np.float64))
+        A = rng.standard_normal((d, d))
+        p = DlmParameters([[0.9]], A @ A.T / d + 0.1 * np.eye(d), rng.standard_normal(d), np.eye(d) * 2)
+        y = rng.standard_normal((9, T, 1)).cumsum(axis=1)
+        y[3, 70:73, 0] = np.nan
+        ref = eng.ffbs(mat, p, y, seed=d, flags=_lib.OPT_SAMPLER_PER_SERIES)
+        out = eng.ffbs(mat, p, y, seed=d, want_filt=False)
+        assert eng.last_variant == "sparse16-sampler-shared"
+        for k in ("theta", "stats", "status"):
+            assert np.array_equal(out[k], ref[k], equal_nan=True), (d, k)
+    # per-series parameters, the multivariate kernels, the simulation smoother, conditional records: an engine workspace takes the records
+    mat, p = c2(60)
+    y = rng.standard_normal((6, 60, 1)).cumsum(axis=1)
+    plist = [DlmParameters(p.v * (1 + 0.1 * n), p.w, p.m0, p.c0) for n in range(6)]
+    for kw in (dict(params=plist), dict(params=p, flags=_lib.OPT_FFBS_SIMSMOOTH), dict(params=p, want_cond=True)):
+        prm = kw.pop("params")
+        ref = eng.ffbs(mat, prm, y, seed=3, **kw)
+        out = eng.ffbs(mat, prm, y, seed=3, want_filt=False, **kw)
+        for k in ("theta", "stats", "cond"):
+            if ref[k] is not None:
+                assert np.array_equal(out[k], ref[k], equal_nan=True), (kw, k)
+    mb, pb = blocks(10, 50, seed=4)
+    yb = rng.standard_normal((5, 50, mb.p)).cumsum(axis=1)
+    ref = eng.ffbs(mb, pb, yb, seed=8, flags=_lib.OPT_STATS_OUTER)
+    out = eng.ffbs(mb, pb, yb, seed=8, flags=_lib.OPT_STATS_OUTER, want_filt=False)
+    assert eng.last_variant == "wave-sampler-shared"
+    assert np.array_equal(out["theta"], ref["theta"]) and np.array_equal(out["stats"], ref["stats"])
