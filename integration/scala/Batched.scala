@@ -58,6 +58,7 @@ final class Native private[gpu] () {
   @native def filterSmooth(h: Long, model: Array[Long], params: Array[Long], opts: Array[Long], y: Long, filt: Long, smooth: Long, status: Long): Unit
   @native def loglik(h: Long, model: Array[Long], params: Array[Long], opts: Array[Long], y: Long, loglik: Long, status: Long): Unit
   @native def simulate(h: Long, model: Array[Long], params: Array[Long], opts: Array[Long], x: Long, y: Long, status: Long): Unit
+  /** filtWs = 0L: the forward pass's records are not wanted (the engine keeps them to itself; where the batch shares V, W, C0 on a regular grid it does not produce them) */
   @native def ffbs(h: Long, model: Array[Long], params: Array[Long], opts: Array[Long], y: Long, z: Long, filtWs: Long, theta: Long, cond: Long, stats: Long, status: Long): Unit
   @native def statsLen(d: Int, p: Int, flags: Int): Int
   @native def backwardSample(h: Long, model: Array[Long], params: Array[Long], opts: Array[Long], y: Long, filt: Long, z: Long, theta: Long, cond: Long, stats: Long, status: Long): Unit
