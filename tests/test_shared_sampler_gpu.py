@@ -282,3 +282,29 @@ def test_without_filter_records_other_shapes_and_fallbacks(eng):
     out = eng.ffbs(mb, pb, yb, seed=8, flags=_lib.OPT_STATS_OUTER, want_filt=False)
     assert eng.last_variant == "wave-sampler-shared"
     assert np.array_equal(out["theta"], ref["theta"]) and np.array_equal(out["stats"], ref["stats"])
+
+
+def test_without_filter_records_injected_normals_and_per_series_prior_means(eng):
+    T, N = 90, 10
+    mat, p = c2(T)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1)
+    y[7, 40, 0] = np.nan
+    z = rng.standard_normal((N, T + 1, 13))
+    ref = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_SAMPLER_PER_SERIES)
+    out = eng.ffbs(mat, p, y, z=z, want_filt=False)
+    assert eng.last_variant == "sparse16-sampler-shared"
+    for k in ("theta", "stats", "status"):
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[2])
+    o = oracle.backward_sample(omodel(mat), p.w, f, z[2], factor="chol")
+    np.testing.assert_allclose(out["theta"][2], o["theta"], rtol=1e-7, atol=1e-8)
+    from bayesian_dlms_amd.engine import pack_params
+    V, vs, W, ws, m0, ms, C0, cs, vts, wts = pack_params(p, N)
+    m0s = rng.standard_normal((N, 13))
+    packed = (V, 0, W, 0, m0s.reshape(-1), 13, C0, 0, 0, 0)     # per-series prior means share the covariances
+    ref = eng.ffbs(mat, packed, y, seed=2, flags=_lib.OPT_SAMPLER_PER_SERIES)
+    out = eng.ffbs(mat, packed, y, seed=2, want_filt=False)
+    assert eng.last_variant == "sparse16-sampler-shared"
+    for k in ("theta", "stats", "status"):
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
