@@ -486,7 +486,7 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   if (big) dlm::wave48_sampler_shared_carve(e->sampws, k, tb); else dlm::sampler_shared_carve(e->sampws, k, tb);
   HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));               // the model and the tables of G are staged
   HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
-  tb.zstride = 0; tb.mc4 = nullptr;
+  tb.zstride = 0; tb.mc4 = nullptr; tb.marked = 0;
   if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_tables(k, tb, e->cov_stream));
   else if (crec) HIP_TRY(e, dlm::launch_sampler_shared_tables_from(k, e->sparse_k, e->sp_dev, tb, crec, crec_stride, e->cov_stream));   // the covariances exist already
   else HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
@@ -1154,7 +1154,15 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       k.filt_in = e->fws;
     } else {
       if ((shared_factors || shared_big) && (rc = start_sampler_tables(e, k, stb, shared_big))) return rc;
+      if (norec && shared_big) {
+        // 16 <= d <= 48, no records wanted: the draw kernel reads only the means of the series without a gap, so those series'
+        // steady steps store the mean alone (KArgs::keep_cov; the first, full steps still write what the convergence test re-reads)
+        HIP_TRY(e, dlm::launch_wave48_mark_gaps(k, e->route, e->stream));
+        k.keep_cov = e->route;
+        stb.marked = 1;
+      }
       if ((rc = run_filter(e, k, false))) return rc;
+      k.keep_cov = nullptr;
       k.filt_in = k.filt;
     }
   }

@@ -45,6 +45,9 @@ struct KArgs {
   const unsigned char* plain;     // structured d <= 15 path, regular grid (nullable): plain[n] = 1 -- series n misses enough observations (more than T / 256)
                                   // that its covariance recursion is not worth testing for convergence: it takes every step in full, in the
                                   // backward kernel's instantiation without the shortcut's machinery (k_count_gaps fills it from the data alone)
+  const unsigned char* keep_cov;  // per-wave filter, 16 <= d <= 48 (nullable): a dlm_ffbs_batch call that keeps no records and draws against shared factors
+                                  // reads only the MEANS of the series without a gap -- once such a series' covariance has settled its steady steps
+                                  // store the mean alone (keep_cov[n] = 0); the series with a gap (1) write whole records for their own sampler
   int stretches;                  // backward sampler: 1 = every stretch of steps starts from scratch (dlm_sampler16.hip: SF_STRETCH), set for the calls
                                   // whose parameters allow a shared-factor table -- its stretches are made side by side, and a series that computes
                                   // its own factors in such a call follows the same rule, so that the two agree bit for bit
@@ -132,6 +135,7 @@ struct SampTabs {
   int zstride;           // d <= 15, table kernel: bytes between the records of the series of zeros (0: d + d^2 doubles; the rows of CovTabs::ftab otherwise)
   const double* mc4;     // d <= 15, draw kernel: the filtered means come from the mean-only forward kernel's compact stream ([ceil(N / 4)][T+1][4][16],
                          //   CovTabs::mc) instead of the filter records: a dlm_ffbs_batch call that does not want the records (filt_ws == NULL)
+  int marked;            // KArgs::route holds this call's gap marks already (the draw launch does not mark again)
   int* settle;           // index of the last record of zrec that was written (KArgs::settle_step): the records above it repeat its covariance
 };
 bool sampler_shared_model_ok(const KArgs& a);   // V, W, C0 shared by the batch, regular grid, time-invariant model (what KArgs::stretches follows)
@@ -154,6 +158,7 @@ size_t wave48_sampler_shared_ws_bytes(const KArgs& a);
 void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
 hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s);
 hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb, hipStream_t s);
+hipError_t launch_wave48_mark_gaps(const KArgs& a, unsigned char* route, hipStream_t s);   // route[n] = 1: series n has a missing observation component
 size_t wave48_sampler_shared_normals_bytes(const KArgs& a);
 hipError_t launch_wave48_sampler_shared_normals(const KArgs& a, double* z, hipStream_t s);   // rows [N][T+1][d], SampTabs::z4 of these calls
 

@@ -622,6 +622,13 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
 #pragma unroll
     for (int b = 0; b < DT; ++b) bst(rfo, moff[b], so, mv[16 * b + c]);
   };
+  auto store_mean = [&](const __amdgpu_buffer_rsrc_t& rfo, const double* mv, int t, int c) {
+    const int so = t * recb;
+#pragma unroll
+    for (int b = 0; b < DT; ++b) bst(rfo, moff[b], so, mv[16 * b + c]);
+  };
+  // a call whose records nobody reads beyond the means (KArgs::keep_cov): steady steps then store the mean alone
+  const bool mean_only_out = __builtin_amdgcn_readfirstlane((int)(a.keep_cov != nullptr && a.keep_cov[n] == 0)) != 0;
   store_record(rfo, mv, 0, g, c);
   if (pri) store_record(rpr, mv, 0, g, c);
 
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
         if (g == 0 && jd[b]) mv[16 * b + c] = av[16 * b + c] + s_;
       }
       wave_sync();
-      store_record(rfo, mv, t + 1, g, c);
+      if (mean_only_out) store_mean(rfo, mv, t + 1, c); else store_record(rfo, mv, t + 1, g, c);
       if (marks && lane == 0) marks[t + 1] = 1;
       ++nsteady;
       if (++t >= T) break;
@@ -2553,15 +2560,19 @@ __global__ __launch_bounds__(256) void k_normals_rows(KArgs a, double* __restric
   }
 }
 
-// route[n] = 1: series n has a missing observation component
+// route[n] = 1: series n has a missing observation component.  One workgroup per series.
 __global__ __launch_bounds__(256) void k_mark_gaps_w48(const double* __restrict__ y, int N, int Tp, unsigned char* __restrict__ route) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = blockIdx.x;
   if (n >= N) return;
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
   const double* yn = y + (size_t)n * Tp;
   bool gap = false;
-  for (int t = lane; t < Tp; t += 64) { const double v = yn[t]; gap |= !(v == v); }
-  const bool any = __ballot(gap) != 0ull;
-  if (lane == 0) route[n] = any ? 1 : 0;
+  for (int t = threadIdx.x; t < Tp; t += 256) { const double v = yn[t]; gap |= !(v == v); }
+  if (__ballot(gap) != 0ull && (threadIdx.x & 63) == 0) any = 1;   // (every writer writes the same value)
+  __syncthreads();
+  if (threadIdx.x == 0) route[n] = any ? 1 : 0;
 }
 
 }  // namespace w48
@@ -2764,7 +2775,7 @@ hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& t
   if ((err = hipMemsetAsync(tb.status, 0, sizeof(int), s)) != hipSuccess) return err;
   KArgs kf = a;   // the filter on a series of zeros: the covariances of every series without a missing observation, bit for bit
   kf.N = 1; kf.y = tb.zeros; kf.m0 = tb.zeros; kf.m0_stride = 0; kf.filt = tb.zrec; kf.status = tb.status; kf.stats = nullptr; kf.loglik = nullptr;
-  kf.prior = nullptr; kf.fq = nullptr; kf.route = nullptr; kf.counters = nullptr; kf.theta = nullptr; kf.z = nullptr; kf.series_offset = 0;
+  kf.prior = nullptr; kf.fq = nullptr; kf.route = nullptr; kf.counters = nullptr; kf.theta = nullptr; kf.z = nullptr; kf.series_offset = 0; kf.keep_cov = nullptr;
   kf.flags |= DLM_OPT_FORCE_WAVE;   // the kernel family that filters the batch, whatever the batch size
   if ((err = hipMemsetD32Async((hipDeviceptr_t)tb.settle, a.T, 1, s)) != hipSuccess) return err;
   kf.settle_step = tb.settle;       // (stops where its covariance recursion has settled: within 30 steps for the C4 model)
@@ -2794,10 +2805,15 @@ hipError_t launch_wave48_sampler_shared_normals(const KArgs& a, double* z, hipSt
   hipLaunchKernelGGL(w48::k_normals_rows, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, s, a, z);
   return hipGetLastError();
 }
+hipError_t launch_wave48_mark_gaps(const KArgs& a, unsigned char* route, hipStream_t s) {
+  hipLaunchKernelGGL(w48::k_mark_gaps_w48, dim3(a.N), dim3(256), 0, s, a.y, a.N, a.T * a.p, route);
+  return hipGetLastError();
+}
 hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb, hipStream_t s) {
   if (!a.route) return hipErrorInvalidValue;
   hipError_t err;
-  if (a.y) hipLaunchKernelGGL(w48::k_mark_gaps_w48, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T * a.p, a.route);
+  if (tb.marked) { /* the engine marked the gaps before the forward pass */ }
+  else if (a.y) hipLaunchKernelGGL(w48::k_mark_gaps_w48, dim3(a.N), dim3(256), 0, s, a.y, a.N, a.T * a.p, a.route);
   else if ((err = hipMemsetAsync(a.route, 0, (size_t)a.N, s)) != hipSuccess) return err;
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;

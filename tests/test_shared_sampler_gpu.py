@@ -308,3 +308,19 @@ def test_without_filter_records_injected_normals_and_per_series_prior_means(eng)
     assert eng.last_variant == "sparse16-sampler-shared"
     for k in ("theta", "stats", "status"):
         assert np.array_equal(out[k], ref[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("nblk,T,N", [(20, 130, 6), (10, 400, 5), (16, 33, 4)])
+def test_multivariate_without_filter_records(eng, nblk, T, N):
+    """16 <= d <= 48 with filt_ws = NULL: the series without a gap store the mean alone once their covariance recursion has settled
+    (KArgs::keep_cov), the series with a gap whole records for their own sampler -- draws and statistics unchanged, bit for bit."""
+    mat, p = blocks(nblk, T, seed=nblk + 1)
+    rng = np.random.default_rng(nblk * T)
+    y = rng.standard_normal((N, T, mat.p)).cumsum(axis=1) * 0.5 + rng.standard_normal((N, T, mat.p))
+    y[2, T // 2, 1] = np.nan
+    y[3, T - 1, 0] = np.nan
+    ref = eng.ffbs(mat, p, y, seed=6, flags=_lib.OPT_STATS_OUTER | _lib.OPT_SAMPLER_PER_SERIES)
+    out = eng.ffbs(mat, p, y, seed=6, flags=_lib.OPT_STATS_OUTER | _lib.OPT_COUNT_STEPS, want_filt=False)
+    assert eng.last_variant == "wave-sampler-shared" and eng.last_counters()[2:] == (N - 2, 2)
+    for k in ("theta", "stats", "status"):
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
