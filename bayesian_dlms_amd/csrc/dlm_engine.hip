@@ -70,6 +70,7 @@ struct dlm_engine {
   hipEvent_t rng_ev = nullptr;
   hipStream_t cov_stream = nullptr;
   hipEvent_t cov_ev[2] = {nullptr, nullptr};
+  hipEvent_t cov_ev2 = nullptr;   // behind the zero series' filter of a shared-factor table (its steady gain and settle step)
   // DLM_OPT_COUNT_STEPS: [4] device counters the kernels add to (KArgs::counters), read by dlm_last_counters
   unsigned long long* counters = nullptr;
   // DLM_OPT_MODEL_UNCHANGED is verified on the device: model_sum[0] = checksum of (F, G, g_index, dt) at the last fresh
@@ -469,6 +470,7 @@ int ensure_cov_stream(dlm_engine* e) {
     HIP_TRY(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIP_TRY(e, hipStreamCreateWithPriority(&e->cov_stream, hipStreamNonBlocking, hi));
     for (auto& ev : e->cov_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->cov_ev2, hipEventDisableTiming));
   }
   return DLM_OK;
 }
@@ -487,7 +489,7 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));               // the model and the tables of G are staged
   HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
   tb.zstride = 0; tb.mc4 = nullptr; tb.marked = 0;
-  if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_tables(k, tb, e->cov_stream));
+  if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_tables(k, tb, e->cov_stream, e->cov_ev2));
   else if (crec) HIP_TRY(e, dlm::launch_sampler_shared_tables_from(k, e->sparse_k, e->sp_dev, tb, crec, crec_stride, e->cov_stream));   // the covariances exist already
   else HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
   HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
@@ -680,6 +682,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->rng_ev) (void)hipEventDestroy(e->rng_ev);
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   for (auto& ev : e->cov_ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->cov_ev2) (void)hipEventDestroy(e->cov_ev2);
   if (e->cov_stream) (void)hipStreamDestroy(e->cov_stream);
   if (e->counters) (void)hipFree(e->counters);
   if (e->model_sum) (void)hipFree(e->model_sum);
@@ -1159,10 +1162,15 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
         // steady steps store the mean alone (KArgs::keep_cov; the first, full steps still write what the convergence test re-reads)
         HIP_TRY(e, dlm::launch_wave48_mark_gaps(k, e->route, e->stream));
         k.keep_cov = e->route;
+        k.ktab = stb.ktab;     // ... and they leave the filter where the recursion settles: k_steady_filter_w48 carries their means on
         stb.marked = 1;
       }
       if ((rc = run_filter(e, k, false))) return rc;
-      k.keep_cov = nullptr;
+      if (norec && shared_big) {
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev2, 0));   // the zero series' filter: the steady gain and the step it settled at
+        HIP_TRY(e, dlm::launch_wave48_steady_filter(k, stb.ktab, stb.settle, e->stream));
+      }
+      k.keep_cov = nullptr; k.ktab = nullptr;
       k.filt_in = k.filt;
     }
   }

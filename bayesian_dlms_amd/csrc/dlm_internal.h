@@ -48,6 +48,9 @@ struct KArgs {
   const unsigned char* keep_cov;  // per-wave filter, 16 <= d <= 48 (nullable): a dlm_ffbs_batch call that keeps no records and draws against shared factors
                                   // reads only the MEANS of the series without a gap -- once such a series' covariance has settled its steady steps
                                   // store the mean alone (keep_cov[n] = 0); the series with a gap (1) write whole records for their own sampler
+  double* ktab;                   // per-wave filter, with keep_cov: the steady gain K^T (16 PT rows of the LDS image) of the batch -- WRITTEN by the series
+                                  // of zeros where its covariance recursion settles (with settle_step), and, when set for the batch's own filter, the
+                                  // sign that its series without a gap leave at that step: k_steady_filter_w48 carries their means on from there
   int stretches;                  // backward sampler: 1 = every stretch of steps starts from scratch (dlm_sampler16.hip: SF_STRETCH), set for the calls
                                   // whose parameters allow a shared-factor table -- its stretches are made side by side, and a series that computes
                                   // its own factors in such a call follows the same rule, so that the two agree bit for bit
@@ -136,6 +139,7 @@ struct SampTabs {
   const double* mc4;     // d <= 15, draw kernel: the filtered means come from the mean-only forward kernel's compact stream ([ceil(N / 4)][T+1][4][16],
                          //   CovTabs::mc) instead of the filter records: a dlm_ffbs_batch call that does not want the records (filt_ws == NULL)
   int marked;            // KArgs::route holds this call's gap marks already (the draw launch does not mark again)
+  double* ktab;          // 16 <= d <= 48: the steady gain K^T as the zero series' filter leaves it (KArgs::ktab), for k_steady_filter_w48
   int* settle;           // index of the last record of zrec that was written (KArgs::settle_step): the records above it repeat its covariance
 };
 bool sampler_shared_model_ok(const KArgs& a);   // V, W, C0 shared by the batch, regular grid, time-invariant model (what KArgs::stretches follows)
@@ -156,8 +160,12 @@ bool wave48_sampler_shared_model_ok(const KArgs& a);
 bool wave48_sampler_shared_eligible(const KArgs& a);
 size_t wave48_sampler_shared_ws_bytes(const KArgs& a);
 void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb);
-hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s);
+hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s, hipEvent_t after_filter = nullptr);   // after_filter: recorded behind the zero series' filter (ktab, settle)
 hipError_t launch_wave48_sampler_shared_draw(const KArgs& a, const SampTabs& tb, hipStream_t s);
+size_t wave48_ktab_doubles(const KArgs& a);
+// the steady steps of the series without a gap, from record *settle on: a = G m, e = y - F^T a, m = a + K e (the per-wave filter's steady step,
+// operation for operation), the mean stored into the records' mean slots; k.keep_cov marks the series, ktab / settle come from the zero series
+hipError_t launch_wave48_steady_filter(const KArgs& a, const double* ktab, const int* settle, hipStream_t s);
 hipError_t launch_wave48_mark_gaps(const KArgs& a, unsigned char* route, hipStream_t s);   // route[n] = 1: series n has a missing observation component
 size_t wave48_sampler_shared_normals_bytes(const KArgs& a);
 hipError_t launch_wave48_sampler_shared_normals(const KArgs& a, double* z, hipStream_t s);   // rows [N][T+1][d], SampTabs::z4 of these calls

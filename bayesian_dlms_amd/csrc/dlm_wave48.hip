@@ -675,7 +675,12 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
     for (int b = 0; b < PT; ++b) missing_here |= jp[b] && !(ycur[b] == ycur[b]);
     bool all = __ballot(missing_here) == 0ull;             // every component of y_t observed
     if (__builtin_amdgcn_readfirstlane((int)(steady && all))) {
-      if (a.settle_step) { if (lane == 0) *a.settle_step = t; break; }   // the series of zeros of a shared-factor table: record t is the last one anyone needs
+      if (a.settle_step) {   // the series of zeros of a shared-factor table: record t is the last one anyone needs
+        if (lane == 0) *a.settle_step = t;
+        if (a.ktab) for (int i = lane; i < 16 * PT * IL; i += 64) a.ktab[i] = img[i];   // K^T of the steady steps (k_steady_filter_w48)
+        break;
+      }
+      if (mean_only_out && a.ktab) break;   // a series without a gap of a records-free call: k_steady_filter_w48 takes its means from record t on
       // a stretch of steady steps as a loop of its own: one back edge, so that the wait for the next observation counts the
       // stores behind it (vmcnt(42)) -- at the head of the big loop, where two paths meet, it would be vmcnt(0): every step
       // would sit out the latency of its 39 record stores.  (The flags are read through readfirstlane: a branch the compiler
@@ -1869,6 +1874,110 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// The steady steps of k_filter_w48 as a kernel of their own (records-free pooled FFBS): once the covariance
+// recursion has settled a step is a = G m, e = y - F^T a, m = a + K e with the gain of the step before -- a few dozen registers,
+// where the filter holds its matrices in 476.  The series without a gap leave k_filter_w48 at the step it settles (the same
+// step for all of them: the recursion does not see the data) and continue here, several waves per SIMD, with K^T as the series
+// of zeros left it (KArgs::ktab) and the operations of the filter's steady branch one for one.  Only the means are stored.
+// ---------------------------------------------------------------------------------------
+template <int DT, int PT, int K, int KF>
+__global__ __launch_bounds__(64, 4) void k_steady_filter_w48(KArgs a, const double* __restrict__ ktab, const int* __restrict__ settle) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int IL = il_of(DT, PT), FIMG = fimg_of(DT, PT), VL = vl_of(DT, PT), KIMG = 16 * PT * IL;
+  double* img = sm;  double* Fl = sm + KIMG;  double* mv = Fl + (KF > 0 ? 0 : FIMG);  double* av = mv + VL;  double* ev = av + VL;
+  const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  if (!a.keep_cov || a.keep_cov[n] != 0) return;            // the series with a gap ran the whole filter
+  const int d = a.d, p = a.p, T = a.T, rec = d + d * d, recb = rec * 8;
+  const int t0 = settle[0];
+  if (t0 >= T) return;                                       // nothing settled: k_filter_w48 went all the way
+  for (int i = lane; i < 3 * VL; i += 64) mv[i] = 0.0;
+  bool jd[DT], jp[PT];
+#pragma unroll
+  for (int b = 0; b < DT; ++b) jd[b] = 16 * b + c < d;
+#pragma unroll
+  for (int b = 0; b < PT; ++b) jp[b] = 16 * b + c < p;
+  if (KF == 0) load_f_lds<DT, PT>(Fl, a.F, d, p, lane);
+  for (int i = lane; i < KIMG; i += 64) img[i] = ktab[i];
+  int tix[DT][K];
+  double tvl[DT][K];
+  {
+    const SparseBig* tab = a.spb;     // the ROWS of G (time-invariant here)
+#pragma unroll
+    for (int b = 0; b < DT; ++b)
+#pragma unroll
+      for (int s = 0; s < K; ++s) { tix[b][s] = tab->idx[16 * b + c][s]; tvl[b][s] = tab->val[16 * b + c][s]; }
+  }
+  constexpr int KFA = KF > 0 ? KF : 1;
+  int fix[PT][KFA];
+  double fvl[PT][KFA];
+#pragma unroll
+  for (int b = 0; b < PT; ++b)
+#pragma unroll
+    for (int s = 0; s < KFA; ++s) {
+      fix[b][s] = KF > 0 ? a.spf->cidx[16 * b + c][s] : 0;
+      fvl[b][s] = KF > 0 ? a.spf->cval[16 * b + c][s] : 0.0;
+    }
+  double* out = a.filt + (size_t)n * (T + 1) * rec;
+  const __amdgpu_buffer_rsrc_t rfo = mk_rsrc(out, (size_t)(T + 1) * recb);
+  const double* y = a.y + (size_t)n * T * p;
+  const __amdgpu_buffer_rsrc_t ry = mk_rsrc(y, (size_t)T * p * 8);
+  int yoff[PT], moff[DT];
+#pragma unroll
+  for (int b = 0; b < PT; ++b) yoff[b] = jp[b] ? (16 * b + c) * 8 : OOB;
+#pragma unroll
+  for (int b = 0; b < DT; ++b) moff[b] = (jd[b] && g == 0) ? (16 * b + c) * 8 : OOB;
+  if (lane < d) mv[lane] = out[(size_t)t0 * rec + lane];     // m_{t0}, as k_filter_w48 left it
+  double ynext[PT];
+#pragma unroll
+  for (int b = 0; b < PT; ++b) ynext[b] = bld(ry, yoff[b], t0 * p * 8);
+  wave_sync();
+  for (int t = t0; t < T; ++t) {
+    double ycur[PT];
+#pragma unroll
+    for (int b = 0; b < PT; ++b) { ycur[b] = ynext[b]; ynext[b] = bld(ry, t + 1 < T ? yoff[b] : OOB, (t + 1 < T ? t + 1 : 0) * p * 8); }
+    double an[DT];
+    gather_vec<DT, K>(mv, tix, tvl, an);                          // a = G m
+#pragma unroll
+    for (int b = 0; b < DT; ++b) if (g == 0 && jd[b]) av[16 * b + c] = an[b];
+    wave_sync();
+    double fcol[PT];
+    if (KF > 0) {
+#pragma unroll
+      for (int b = 0; b < PT; ++b) {
+        double s_ = 0.0;
+#pragma unroll
+        for (int s = 0; s < KFA; ++s) s_ = fma(av[fix[b][s]], fvl[b][s], s_);
+        fcol[b] = s_;
+      }
+    } else {
+      d4 Fm[DT][PT];
+      f_tiles<DT, PT>(Fl, Fm, g, c);
+      matTvec<DT, PT>(Fm, av, g, fcol);
+    }
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const double e = ycur[b] - fcol[b];
+      if (g == 0) ev[16 * b + c] = jp[b] ? e : 0.0;
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < DT; ++b) {                                // K e, as the filter's steady branch sums it
+      double s_ = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 4 * PT; ++jj) s_ = fma(img[(4 * jj + g) * IL + 16 * b + c], ev[4 * jj + g], s_);
+      s_ = sum_g(s_);
+      if (g == 0 && jd[b]) mv[16 * b + c] = av[16 * b + c] + s_;
+    }
+    wave_sync();
+    const int so = (t + 1) * recb;
+#pragma unroll
+    for (int b = 0; b < DT; ++b) bst(rfo, moff[b], so, mv[16 * b + c]);
+  }
+  if (a.counters && lane == 0) atomicAdd(&a.counters[0], (unsigned long long)(T - t0));
+  if (__ballot(lane < d && !isfinite(mv[lane < VL ? lane : 0])) != 0ull && a.status && lane == 0) atomicOr(&a.status[n], DLM_ST_NONFINITE);
+}
+
+// ---------------------------------------------------------------------------------------
 // The reference's backward sampler (Smoothing.sampleDlm / Smoothing.step, Smoothing.scala:74-122) for 16 <= d <= 48 on
 // register tiles: dlm_sampler16.hip's kernel with DT x DT tiles per matrix.  Per step t = T-1 .. 0, given theta_{t+1}:
 //   a+ = G m, R+ = G C G^T + W dt (dt == 0: a+ = m, R+ = C);  J = C G^T R+^-1 (always the table entry g(dt));
@@ -2744,7 +2853,7 @@ static size_t up64w(size_t x) { return (x + 63) & ~(size_t)63; }
 static int ws_dt(const KArgs& a) { return a.d <= 32 ? 2 : 3; }
 size_t wave48_sampler_shared_ws_bytes(const KArgs& a) {
   const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d, zn = (size_t)a.T * a.p > 64 ? (size_t)a.T * a.p : 64;
-  return up64w(n1 * w48::ws_row_doubles(ws_dt(a)) * 8) + up64w(n1 * rec * 8) + up64w(zn * 8) + up64w(n1) + 64;
+  return up64w(n1 * w48::ws_row_doubles(ws_dt(a)) * 8) + up64w(n1 * rec * 8) + up64w(zn * 8) + up64w(n1) + 64 + up64w(wave48_ktab_doubles(a) * 8);
 }
 void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb) {
   const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d, zn = (size_t)a.T * a.p > 64 ? (size_t)a.T * a.p : 64;
@@ -2753,7 +2862,8 @@ void wave48_sampler_shared_carve(void* ws, const KArgs& a, SampTabs& tb) {
   tb.zrec = (double*)p;  p += up64w(n1 * rec * 8);
   tb.zeros = (double*)p; p += up64w(zn * 8);
   tb.need = (unsigned char*)p; p += up64w(n1);
-  tb.status = (int*)p; tb.settle = tb.status + 1;
+  tb.status = (int*)p; tb.settle = tb.status + 1; p += 64;
+  tb.ktab = (double*)p;
 }
 template <int DT>
 static void launch_w48_tables_k(const KArgs& kp, const SampTabs& tb, bool outer, hipStream_t s) {
@@ -2768,7 +2878,7 @@ static void launch_w48_tables_k(const KArgs& kp, const SampTabs& tb, bool outer,
     else hipLaunchKernelGGL((w48::k_sampler_w48<DT, 4, false>), grid, dim3(64), lds, s, kp, tb);
   }
 }
-hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s) {
+hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& tb, hipStream_t s, hipEvent_t after_filter) {
   const size_t zn = (size_t)a.T * a.p > 64 ? (size_t)a.T * a.p : 64;
   hipError_t err = hipMemsetAsync(tb.zeros, 0, zn * 8, s);
   if (err != hipSuccess) return err;
@@ -2779,9 +2889,11 @@ hipError_t launch_wave48_sampler_shared_tables(const KArgs& a, const SampTabs& t
   kf.flags |= DLM_OPT_FORCE_WAVE;   // the kernel family that filters the batch, whatever the batch size
   if ((err = hipMemsetD32Async((hipDeviceptr_t)tb.settle, a.T, 1, s)) != hipSuccess) return err;
   kf.settle_step = tb.settle;       // (stops where its covariance recursion has settled: within 30 steps for the C4 model)
+  kf.ktab = tb.ktab;                // ... and leaves the steady gain there
   if ((err = launch_wave48_filter(kf, kf.spb_k, nullptr, s)) != hipSuccess) return err;
+  if (after_filter && (err = hipEventRecord(after_filter, s)) != hipSuccess) return err;
   KArgs kp = kf;
-  kp.y = nullptr; kp.filt_in = tb.zrec; kp.settle_step = nullptr;
+  kp.y = nullptr; kp.filt_in = tb.zrec; kp.settle_step = nullptr; kp.ktab = nullptr;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0 && a.stats;
   if (a.d <= 32) launch_w48_tables_k<2>(kp, tb, outer, s); else launch_w48_tables_k<3>(kp, tb, outer, s);
   return hipGetLastError();
@@ -2803,6 +2915,31 @@ hipError_t launch_wave48_sampler_shared_normals(const KArgs& a, double* z, hipSt
   const long long total = (long long)a.N * (a.T + 1) * ((a.d + 1) / 2);
   const long long blocks = (total + 255) / 256;
   hipLaunchKernelGGL(w48::k_normals_rows, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0, s, a, z);
+  return hipGetLastError();
+}
+size_t wave48_ktab_doubles(const KArgs& a) { const int PT = a.p <= 16 ? 1 : 2, DT = a.d <= 16 ? 1 : (a.d <= 32 ? 2 : 3); return (size_t)16 * PT * w48::il_of(DT, PT); }
+template <int DT, int PT>
+static void launch_w48_steady_k(const KArgs& a, const double* ktab, const int* settle, hipStream_t s) {
+  const int kf = (a.spf && !(a.flags & DLM_OPT_NO_SPARSE_F)) ? a.spf_k : 0;
+  const size_t lds = sizeof(double) * (size_t)(16 * PT * w48::il_of(DT, PT) + (kf ? 0 : w48::fimg_of(DT, PT)) + 3 * w48::vl_of(DT, PT));
+  const int K = a.spb_k;
+  if (K <= 2) {
+    if (kf == 1) hipLaunchKernelGGL((w48::k_steady_filter_w48<DT, PT, 2, 1>), dim3(a.N), dim3(64), lds, s, a, ktab, settle);
+    else if (kf > 1) hipLaunchKernelGGL((w48::k_steady_filter_w48<DT, PT, 2, 4>), dim3(a.N), dim3(64), lds, s, a, ktab, settle);
+    else hipLaunchKernelGGL((w48::k_steady_filter_w48<DT, PT, 2, 0>), dim3(a.N), dim3(64), lds, s, a, ktab, settle);
+  } else {
+    if (kf >= 1) hipLaunchKernelGGL((w48::k_steady_filter_w48<DT, PT, 4, 4>), dim3(a.N), dim3(64), lds, s, a, ktab, settle);
+    else hipLaunchKernelGGL((w48::k_steady_filter_w48<DT, PT, 4, 0>), dim3(a.N), dim3(64), lds, s, a, ktab, settle);
+  }
+}
+hipError_t launch_wave48_steady_filter(const KArgs& a, const double* ktab, const int* settle, hipStream_t s) {
+  const bool d2 = a.d <= 32, p1 = a.p <= 16;
+  if (a.d <= 16 && p1) launch_w48_steady_k<1, 1>(a, ktab, settle, s);
+  else if (a.d <= 16) launch_w48_steady_k<1, 2>(a, ktab, settle, s);
+  else if (d2 && p1) launch_w48_steady_k<2, 1>(a, ktab, settle, s);
+  else if (d2) launch_w48_steady_k<2, 2>(a, ktab, settle, s);
+  else if (p1) launch_w48_steady_k<3, 1>(a, ktab, settle, s);
+  else launch_w48_steady_k<3, 2>(a, ktab, settle, s);
   return hipGetLastError();
 }
 hipError_t launch_wave48_mark_gaps(const KArgs& a, unsigned char* route, hipStream_t s) {
