@@ -442,11 +442,13 @@ def run_one(args, ctx):
             fwd_u, bwd_u, unit, peak, bound = 8.0 * d ** 3 + 6.0 * d * d * q + 2.0 * q ** 3 / 3.0, 8.67 * d ** 3, "TFLOP/s", MFMA_F64_PEAK_TFLOPS, "mfma"
             names = ("k_filter_", "k_smoother_")
         elif cfg == "c4g" and variant.endswith("-shared"):
-            # pooled parameters: J_t, H_t and the factors are computed once per call and the covariance recursion of
-            # the forward pass settles within 30 steps -- both passes stream: write + re-read of the filtered records (the contract's
-            # algorithmic bytes; the shared-factor draw kernel in fact re-reads the means alone)
-            fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * rec, 8.0 * rec, "GB/s", HBM_PEAK_GBS, "hbm"
+            # pooled parameters: J_t, H_t and the factors are computed once per call, the covariance recursion of the
+            # forward pass settles within 30 steps and the records are nobody's output (filt_ws = NULL): what moves is the observations,
+            # the means and the normals
+            fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * d, 16.0 * d + 8.0 * q, "GB/s", HBM_PEAK_GBS, "hbm"
             names = ("k_filter_", "k_mean_sampler_")
+            moved_note = ("bytes really moved (the records-free call: observations in and means out in the forward pass, means, normals and observations in the draw "
+                          "kernel; the records of the contract's algorithmic figure are no longer written): the kernels are bound by their dependent chains, not by HBM")
         elif cfg == "c4g":
             # FFBS adds about 8 d^3 (J, H) plus the Cholesky factor d^3 / 3 to the filter's flops
             fwd_u, bwd_u, unit, peak, bound = 8.0 * d ** 3 + 6.0 * d * d * q + 2.0 * q ** 3 / 3.0, 8.0 * d ** 3 + d ** 3 / 3.0, "TFLOP/s", MFMA_F64_PEAK_TFLOPS, "mfma"
