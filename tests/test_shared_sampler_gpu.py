@@ -324,3 +324,32 @@ def test_multivariate_without_filter_records(eng, nblk, T, N):
     assert eng.last_variant == "wave-sampler-shared" and eng.last_counters()[2:] == (N - 2, 2)
     for k in ("theta", "stats", "status"):
         assert np.array_equal(out[k], ref[k], equal_nan=True), k
+
+
+def test_alternating_calls_share_the_engine_workspaces(eng):
+    """The tables, the normals, the gap marks and the side streams are engine state reused from call to call: calls of different
+    shapes and kinds follow each other on one engine (growing and shrinking workspaces, d <= 15 and d >= 16 tables in the same
+    buffer, records kept and not kept) and each equals its own per-series reference."""
+    rng = np.random.default_rng(123)
+    cases = []
+    for T, N in ((129, 300), (40, 9), (700, 21)):
+        mat, p = c2(T)
+        y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+        y[1, T // 3, 0] = np.nan
+        cases.append((mat, p, y, 0))
+    for nblk, T, N in ((10, 90, 5), (20, 60, 4)):
+        mat, p = blocks(nblk, T, seed=nblk)
+        y = rng.standard_normal((N, T, mat.p)).cumsum(axis=1)
+        cases.append((mat, p, y, _lib.OPT_STATS_OUTER))
+    refs = [eng.ffbs(m, p, y, seed=i, flags=f | _lib.OPT_SAMPLER_PER_SERIES) for i, (m, p, y, f) in enumerate(cases)]
+    order = [0, 3, 1, 4, 2, 0, 4, 3, 2, 1]
+    for rnd in range(2):
+        for i in order:
+            m, p, y, f = cases[i]
+            out = eng.ffbs(m, p, y, seed=i, flags=f, want_filt=bool((i + rnd) & 1))
+            assert eng.last_variant.endswith("-shared")
+            for k in ("theta", "stats", "status"):
+                assert np.array_equal(out[k], refs[i][k], equal_nan=True), (rnd, i, k)
+            if i == 0:       # a filter + smoother call in between (its own workspaces, the same streams)
+                fs = eng.filter_smooth(m, p, y)
+                assert np.all(fs["status"] == 0)
