@@ -13,6 +13,10 @@
 // refinement of the previous step's inverse (R+ changes slowly along a series; direct Cholesky inverse when the start
 // is too far off), and the factor of H -- thirteen dependent pivots -- is taken in registers, lane i holding row i, with
 // pivots and multipliers broadcast by v_readlane (chol_draw).
+//
+// Also here (round 3): the shared factors of a pooled batch -- k_sampler_sp16 with its table export (one wave per
+// stretch of 32 steps on a series of zeros), k_mean_sampler_sp16 (the draw against the table, four series per wave, means / table rows
+// / normals by LDS DMA), k_normals4 (the call's normals made beside the forward pass), k_mark_gaps, and their launchers.
 #include "dlm_internal.h"
 #include "../../include/dlm_engine.h"
 
