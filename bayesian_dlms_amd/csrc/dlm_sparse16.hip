@@ -665,6 +665,7 @@ template <int K>
 __global__ __launch_bounds__(64) void k_cov_filter_sp16(KArgs a, const SparseT* __restrict__ sp, double* __restrict__ side,
                                                         double* __restrict__ kftab) {
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
+  __builtin_amdgcn_s_setprio(3);   // one wave that every mean kernel of the call waits for, possibly beside a kernel that fills the device
   filter_body<K, false, false, false, true>(a, sp, side, nullptr, lds, kftab);
 }
 
