@@ -264,3 +264,23 @@ def test_headline_kernels_keep_their_occupancy(tmp_path):
     assert len(bwd) == 1 and len(fwd) == 1, sorted(meta)
     assert bwd[0]["vgpr_count"] <= 96 and bwd[0]["vgpr_spill_count"] <= 3, bwd
     assert fwd[0]["vgpr_count"] <= 96 and fwd[0]["vgpr_spill_count"] == 0, fwd
+
+
+def test_option_flags_agree_between_header_python_and_scala():
+    """dlm_options.flags: every DLM_OPT_* bit of include/dlm_engine.h has the same value in bayesian_dlms_amd/_lib.py, and the
+    bits the Scala shim names (integration/scala/Batched.scala) are the header's."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "dlm_engine.h")).read()
+    bits = {m.group(1): int(m.group(2)) for m in re.finditer(r"DLM_OPT_([A-Z0-9_]+)\s*=\s*1u\s*<<\s*(\d+)", hdr)}
+    assert len(bits) >= 20 and len(set(bits.values())) == len(bits)          # no bit used twice
+    from bayesian_dlms_amd import _lib
+    for name, sh in bits.items():
+        assert getattr(_lib, "OPT_" + name) == 1 << sh, name
+    scala = open(os.path.join(root, "integration", "scala", "Batched.scala")).read()
+    camel = lambda n: "".join(w.capitalize() for w in n.lower().split("_"))
+    named = {m.group(1): int(m.group(2)) for m in re.finditer(r"val (\w+) = 1 << (\d+)", scala)}
+    by_camel = {camel(n).lower(): sh for n, sh in bits.items()}          # (SvdRawWQ2, FfbsSimSmooth: compared without case)
+    assert len(named) >= 10
+    for n, sh in named.items():
+        assert by_camel.get(n.lower()) == sh, n
