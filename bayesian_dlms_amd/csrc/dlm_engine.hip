@@ -71,6 +71,9 @@ struct dlm_engine {
   hipStream_t cov_stream = nullptr;
   hipEvent_t cov_ev[2] = {nullptr, nullptr};
   hipEvent_t cov_ev2 = nullptr;   // behind the zero series' filter of a shared-factor table (its steady gain and settle step)
+  // work of the CURRENT call is (or may be) in flight on the auxiliary streams and e->stream does not depend on it yet: set when the
+  // first operation goes to the stream, cleared by aux_join / drain_all (the rules are written at aux_join)
+  bool cov_busy = false, rng_busy = false;
   // DLM_OPT_COUNT_STEPS: [4] device counters the kernels add to (KArgs::counters), read by dlm_last_counters
   unsigned long long* counters = nullptr;
   // DLM_OPT_MODEL_UNCHANGED is verified on the device: model_sum[0] = checksum of (F, G, g_index, dt) at the last fresh
@@ -102,6 +105,43 @@ int promise_broken(dlm_engine* e) {
       return fail((e), DLM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_err));   \
   } while (0)
 
+// ---- the auxiliary streams (cov_stream: tables of the shared-covariance / shared-factor paths, raised priority; rng_stream: the
+// normals of a shared-factor call) -- who waits for whom.  Two rules, kept by every entry point:
+//   A. when an entry point returns -- success, error or "not eligible after all" -- e->stream depends on everything the call put on
+//      the auxiliary streams (aux_join; AuxScope does it on every exit path).  A caller that synchronises e->stream (every call
+//      without DLM_OPT_ASYNC does, dlm_engine_sync does) has therefore waited for the auxiliary work too, and the next call's work,
+//      whose auxiliary launches wait for an event recorded on e->stream, is ordered behind it.
+//   B. before a workspace any of the three streams may touch is freed or resized, before the engine moves to another stream and
+//      before it is destroyed, all three streams are drained on the host (drain_all).
+// (Round 3 kept neither on its error paths: a return between start_sampler_tables and the hipStreamWaitEvent of the draw left kernels
+// on cov_stream / rng_stream reading the staging arena and e->sampws with nothing ordered behind them, the workspace re-size paths
+// synchronised e->stream alone, and dlm_engine_destroy freed buffers and destroyed streams with auxiliary work possibly in flight.)
+int aux_join(dlm_engine* e) {
+  if (e->cov_busy) {
+    e->cov_busy = false;   // (cleared first: a failing HIP call must not make every later exit path fail again)
+    HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));            // everything queued on the stream so far
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));
+  }
+  if (e->rng_busy) {
+    e->rng_busy = false;
+    HIP_TRY(e, hipEventRecord(e->rng_ev, e->rng_stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->rng_ev, 0));
+  }
+  return DLM_OK;
+}
+int drain_all(dlm_engine* e) {
+  e->cov_busy = e->rng_busy = false;
+  if (e->cov_stream) HIP_TRY(e, hipStreamSynchronize(e->cov_stream));
+  if (e->rng_stream) HIP_TRY(e, hipStreamSynchronize(e->rng_stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return DLM_OK;
+}
+struct AuxScope {   // rule A on every exit path of an entry point that may use the auxiliary streams
+  dlm_engine* e;
+  explicit AuxScope(dlm_engine* e_) : e(e_) {}
+  ~AuxScope() { if (e && (e->cov_busy || e->rng_busy)) (void)aux_join(e); }
+};
+
 // Collects the buffers of one call.  Device mode: pointers pass through.  Host mode: every
 // buffer gets a slot in the engine's arena; inputs are copied up before the launch, outputs
 // are copied back by finish().
@@ -121,7 +161,7 @@ class Stager {
       size_t need = 0;
       for (auto& b : bufs_) if (b.user) { b.offset = need; need += (b.bytes + 255) & ~(size_t)255; }
       if (need > e_->arena_bytes) {
-        if (e_->arena) { HIP_TRY(e_, hipStreamSynchronize(e_->stream)); HIP_TRY(e_, hipFree(e_->arena)); e_->arena = nullptr; e_->arena_bytes = 0; }
+        if (e_->arena) { { const int rcd = drain_all(e_); if (rcd) return rcd; } HIP_TRY(e_, hipFree(e_->arena)); e_->arena = nullptr; e_->arena_bytes = 0; }
         HIP_TRY(e_, hipMalloc(&e_->arena, need));
         e_->arena_bytes = need;
       }
@@ -233,7 +273,7 @@ int analyse_g_tiled(dlm_engine* e, KArgs& k, const double* G_user, bool host_mod
   for (auto& t : tabs) K = t.K > K ? t.K : K;
   for (auto& t : tabs) t.K = K;
   if (tabs.size() > e->spb_count) {
-    if (e->spb_dev) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->spb_dev)); e->spb_dev = nullptr; }
+    if (e->spb_dev) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->spb_dev)); e->spb_dev = nullptr; }
     HIP_TRY(e, hipMalloc((void**)&e->spb_dev, tabs.size() * sizeof(dlm::SparseBig)));
     e->spb_count = tabs.size();
   }
@@ -360,7 +400,7 @@ int analyse_g_fresh(dlm_engine* e, KArgs& k, const double* G_user, bool host_mod
     K = kq > K ? kq : K;
   }
   if (tabs.size() > e->sp_count) {
-    if (e->sp_dev) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->sp_dev)); e->sp_dev = nullptr; }
+    if (e->sp_dev) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->sp_dev)); e->sp_dev = nullptr; }
     HIP_TRY(e, hipMalloc((void**)&e->sp_dev, tabs.size() * sizeof(dlm::SparseT)));
     e->sp_count = tabs.size();
   }
@@ -379,7 +419,7 @@ int mark(dlm_engine* e, int i) {
 
 int ensure_fws(dlm_engine* e, size_t need) {
   if (need > e->fws_bytes) {
-    if (e->fws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->fws)); e->fws = nullptr; e->fws_bytes = 0; }
+    if (e->fws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->fws)); e->fws = nullptr; e->fws_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->fws, need));
     e->fws_bytes = need;
   }
@@ -390,7 +430,7 @@ int ensure_side(dlm_engine* e, const KArgs& k) {
   // (e / Q, 1 / Q) per record for the per-series kernels, and behind them one double per record (e / Q) for the shared-covariance kernels
   const size_t need = sizeof(double) * 3 * (size_t)k.N * ((size_t)k.T + 1);
   if (need > e->side_bytes) {
-    if (e->side) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->side)); e->side = nullptr; e->side_bytes = 0; }
+    if (e->side) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->side)); e->side = nullptr; e->side_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->side, need));
     e->side_bytes = need;
   }
@@ -400,7 +440,7 @@ int ensure_side(dlm_engine* e, const KArgs& k) {
 int ensure_xplus(dlm_engine* e, const KArgs& k) {
   const size_t need = sizeof(double) * (size_t)k.N * ((size_t)k.T + 1) * (size_t)k.d;
   if (need > e->xplus_bytes) {
-    if (e->xplus) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
+    if (e->xplus) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->xplus, need));
     e->xplus_bytes = need;
   }
@@ -411,7 +451,7 @@ int ensure_ystar(dlm_engine* e, const KArgs& k) {
   // innovations [N][T][p], then one byte per record [N][T+1]: the marks "C_t is C_{t-1}" of the per-wave forward kernel's steady steps
   const size_t need = sizeof(double) * (size_t)k.N * (size_t)k.T * (size_t)k.p + (((size_t)k.N * (size_t)(k.T + 1) + 15) & ~(size_t)15);
   if (need > e->ystar_bytes) {
-    if (e->ystar) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->ystar)); e->ystar = nullptr; e->ystar_bytes = 0; }
+    if (e->ystar) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->ystar)); e->ystar = nullptr; e->ystar_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->ystar, need));
     e->ystar_bytes = need;
   }
@@ -434,7 +474,7 @@ bool use_shared_cov(const dlm_engine* e, const KArgs& k) {
 }
 int ensure_route(dlm_engine* e, size_t N) {
   if (N > e->route_bytes) {
-    if (e->route) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->route)); e->route = nullptr; e->route_bytes = 0; }
+    if (e->route) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->route)); e->route = nullptr; e->route_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->route, N));
     e->route_bytes = N;
   }
@@ -442,7 +482,7 @@ int ensure_route(dlm_engine* e, size_t N) {
 }
 int ensure_xplus_bytes(dlm_engine* e, size_t need) {
   if (need > e->xplus_bytes) {
-    if (e->xplus) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
+    if (e->xplus) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->xplus, need));
     e->xplus_bytes = need;
   }
@@ -456,7 +496,7 @@ int mark_plain(dlm_engine* e, KArgs& k) {
   if (!(fast_shape_ok(k) && e->sparse_k > 0) || use_lane(k) || !k.y || k.g_index || k.dt || k.f_stride || k.v_tstride || k.w_tstride ||
       (k.flags & DLM_OPT_NO_STEADY)) return DLM_OK;
   if ((size_t)k.N > e->plainbuf_bytes) {
-    if (e->plainbuf) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->plainbuf)); e->plainbuf = nullptr; e->plainbuf_bytes = 0; }
+    if (e->plainbuf) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->plainbuf)); e->plainbuf = nullptr; e->plainbuf_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->plainbuf, (size_t)k.N));
     e->plainbuf_bytes = (size_t)k.N;
   }
@@ -479,7 +519,7 @@ int ensure_cov_stream(dlm_engine* e) {
 int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big, const double* crec = nullptr, int crec_stride = 0) {
   const size_t need = big ? dlm::wave48_sampler_shared_ws_bytes(k) : dlm::sampler_shared_ws_bytes(k);
   if (need > e->sampws_bytes) {
-    if (e->sampws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->sampws)); e->sampws = nullptr; e->sampws_bytes = 0; }
+    if (e->sampws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->sampws)); e->sampws = nullptr; e->sampws_bytes = 0; }
     HIP_TRY(e, hipMalloc(&e->sampws, need));
     e->sampws_bytes = need;
   }
@@ -487,6 +527,7 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   if (rc || (rc = ensure_cov_stream(e))) return rc;
   if (big) dlm::wave48_sampler_shared_carve(e->sampws, k, tb); else dlm::sampler_shared_carve(e->sampws, k, tb);
   HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));               // the model and the tables of G are staged
+  e->cov_busy = true;                                                 // (from here on every exit path joins the stream: AuxScope)
   HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
   tb.zstride = 0; tb.mc4 = nullptr; tb.marked = 0;
   if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_tables(k, tb, e->cov_stream, e->cov_ev2));
@@ -497,7 +538,7 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   if (!k.z) {   // the normals of the call, on a stream of ordinary priority beside the batch's filter
     const size_t zb = big ? dlm::wave48_sampler_shared_normals_bytes(k) : dlm::sampler_shared_normals_bytes(k);
     if (zb > e->zws_bytes) {
-      if (e->zws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->zws)); e->zws = nullptr; e->zws_bytes = 0; }
+      if (e->zws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->zws)); e->zws = nullptr; e->zws_bytes = 0; }
       HIP_TRY(e, hipMalloc((void**)&e->zws, zb));
       e->zws_bytes = zb;
     }
@@ -505,6 +546,7 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
       HIP_TRY(e, hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));
       HIP_TRY(e, hipEventCreateWithFlags(&e->rng_ev, hipEventDisableTiming));
     }
+    e->rng_busy = true;
     HIP_TRY(e, hipStreamWaitEvent(e->rng_stream, e->cov_ev[0], 0));   // (the draw kernel of the call before has read its normals)
     if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_normals(k, e->zws, e->rng_stream));
     else HIP_TRY(e, dlm::launch_sampler_shared_normals(k, e->zws, e->rng_stream));
@@ -516,7 +558,7 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
 int ensure_shared(dlm_engine* e, const KArgs& k, dlm::CovTabs& tb, bool with_backward) {
   const size_t need = sizeof(double) * dlm::covtabs_doubles(k.d, k.T);
   if (need > e->covws_bytes) {
-    if (e->covws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->covws)); e->covws = nullptr; e->covws_bytes = 0; }
+    if (e->covws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->covws)); e->covws = nullptr; e->covws_bytes = 0; }
     HIP_TRY(e, hipMalloc((void**)&e->covws, need));
     e->covws_bytes = need;
   }
@@ -547,6 +589,7 @@ int run_shared_filter(dlm_engine* e, KArgs& k, dlm::CovTabs& tb, bool with_backw
   HIP_TRY(e, dlm::launch_sparse16_cov_filter(k, e->sparse_k, e->sp_dev, tb, e->stream));
   if (with_backward) {
     HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));
+    e->cov_busy = true;
     HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
     HIP_TRY(e, dlm::launch_sparse16_cov_smoother(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
     HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
@@ -559,6 +602,7 @@ int run_shared_filter(dlm_engine* e, KArgs& k, dlm::CovTabs& tb, bool with_backw
 }
 int run_shared_smoother(dlm_engine* e, KArgs& k, const dlm::CovTabs& tb) {
   HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));   // the S_t table
+  e->cov_busy = false;                                          // (cov_ev[1] was recorded behind the stream's last operation of this call)
   HIP_TRY(e, dlm::launch_sparse16_mean_smoother(k, e->sparse_k, e->sp_dev, tb, e->stream));
   KArgs kg = k;
   kg.route_take = 1;
@@ -665,6 +709,7 @@ int dlm_engine_create(int device, dlm_engine** out) {
 void dlm_engine_destroy(dlm_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  (void)drain_all(e);   // rule B: nothing of a DLM_OPT_ASYNC call (or of a call that failed half-way) is in flight on any of the three streams
   if (e->has_comm) ncclCommDestroy(e->comm);
   if (e->arena) (void)hipFree(e->arena);
   if (e->side) (void)hipFree(e->side);
@@ -704,7 +749,7 @@ int dlm_engine_set_stream(dlm_engine* e, void* hip_stream) {
     // the engine's workspaces (side records, tables, staged parameters) belong to whatever runs on its stream: work still in
     // flight from DLM_OPT_ASYNC calls on the old stream is drained before anything is launched on the new one
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    { const int rcd = drain_all(e); if (rcd) return rcd; }
     e->stream = next;
   }
   return DLM_OK;
@@ -1029,6 +1074,7 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
   if (!y || !smooth) return fail(e, DLM_ERR_ARG, "y and smooth are required");
+  AuxScope aux(e);   // (the shared-covariance path runs its backward covariance table on the second stream)
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, rec = d + d * d;
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);
@@ -1074,6 +1120,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
                           double* stats, int32_t* status, bool forward) {
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
+  AuxScope aux(e);                            // rule A of the auxiliary streams on every exit path below
   const bool norec = forward && !filt_ws;     // dlm_ffbs_batch that does not want the filter records
   if (forward && !y) return fail(e, DLM_ERR_ARG, "y is required");
   if (!forward && !filt_in) return fail(e, DLM_ERR_ARG, "filter records are required");
@@ -1149,6 +1196,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       k.route = e->route; k.route_take = 0; k.filt = nullptr;
       HIP_TRY(e, dlm::launch_sparse16_cov_filter(k, e->sparse_k, e->sp_dev, ctb, e->stream));
       if ((rc = start_sampler_tables(e, k, stb, false, ctb.ftab, ctb.frow))) return rc;
+      if (k.flags & DLM_OPT_TEST_FAIL_AFTER_TABLES) return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_TEST_FAIL_AFTER_TABLES");
       HIP_TRY(e, dlm::launch_sparse16_mean_filter(k, e->sparse_k, e->sp_dev, ctb, e->stream));
       stb.mc4 = ctb.mc;
       KArgs kg = k;
@@ -1157,6 +1205,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       k.filt_in = e->fws;
     } else {
       if ((shared_factors || shared_big) && (rc = start_sampler_tables(e, k, stb, shared_big))) return rc;
+      if ((shared_factors || shared_big) && (k.flags & DLM_OPT_TEST_FAIL_AFTER_TABLES))   // test hook: an error exit with the auxiliary streams busy
+        return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_TEST_FAIL_AFTER_TABLES");
       if (norec && shared_big) {
         // 16 <= d <= 48, no records wanted: the draw kernel reads only the means of the series without a gap, so those series'
         // steady steps store the mean alone (KArgs::keep_cov; the first, full steps still write what the convergence test re-reads)
@@ -1187,7 +1237,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     // series draw against it; a series with a missing observation computes its own as always
     e->variant = "sparse16-sampler-shared";
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));
-    if (stb.z4) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->rng_ev, 0));
+    e->cov_busy = false;
+    if (stb.z4) { HIP_TRY(e, hipStreamWaitEvent(e->stream, e->rng_ev, 0)); e->rng_busy = false; }
     k.route = e->route;
     HIP_TRY(e, dlm::launch_sampler_shared_draw(k, e->sparse_k, e->sp_dev, stb, e->stream));
     return done();
@@ -1205,7 +1256,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if (shared_big) {
     e->variant = "wave-sampler-shared";
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));
-    if (stb.z4) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->rng_ev, 0));
+    e->cov_busy = false;
+    if (stb.z4) { HIP_TRY(e, hipStreamWaitEvent(e->stream, e->rng_ev, 0)); e->rng_busy = false; }
     k.route = e->route;
     HIP_TRY(e, dlm::launch_wave48_sampler_shared_draw(k, stb, e->stream));
     return done();
@@ -1257,7 +1309,7 @@ int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
     if ((rc = ensure_route(e, (size_t)k.N))) return rc;
     const size_t need = sizeof(double) * dlm::svd_shared_ws_doubles(k);
     if (need > e->covws_bytes) {
-      if (e->covws) { HIP_TRY(e, hipStreamSynchronize(e->stream)); HIP_TRY(e, hipFree(e->covws)); e->covws = nullptr; e->covws_bytes = 0; }
+      if (e->covws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->covws)); e->covws = nullptr; e->covws_bytes = 0; }
       HIP_TRY(e, hipMalloc((void**)&e->covws, need));
       e->covws_bytes = need;
     }

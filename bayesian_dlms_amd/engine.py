@@ -237,14 +237,15 @@ class Engine:
         return md, pd, op, bufs
 
     # -- entry points --------------------------------------------------------------
-    def filter(self, mat, params, y, *, want_prior=False, want_fq=False, flags=0):
+    def filter(self, mat, params, y, *, want_prior=False, want_fq=False, flags=0, out=None):
+        """out: an existing record buffer [N][T+1][rec] to write into (its previous content must not matter)."""
         be = self._backend(y)
         N = int(y.shape[0]); d, p, T = mat.d, mat.p, mat.T
         rec = d + d * d
         yb = be.put(y).reshape(N, T, p)
         md, pd, op, keep = self.prepare(mat, params, N, be, flags)
         self._hold(flags, yb)
-        filt = be.empty((N, T + 1, self.lib.dlm_packed_record_doubles(d) if flags & _lib.OPT_PACKED_SYM else rec))
+        filt = out if out is not None else be.empty((N, T + 1, self.lib.dlm_packed_record_doubles(d) if flags & _lib.OPT_PACKED_SYM else rec))
         prior = be.empty((N, T + 1, rec)) if want_prior else None
         fq = be.empty((N, T + 1, p + p * p)) if want_fq else None
         status = be.empty((N,), np.int32)

@@ -167,7 +167,12 @@ def cpu_baseline(config, mat, p, y_host, budget_s=12.0):
         dt = time.perf_counter() - t0
         what = ("oracle/dlm_oracle.c filter + backward sampler (Smoothing.step) + Gibbs sums" if config in ("c3", "c4g")
                 else "oracle/dlm_oracle.c SVD filter (two one-sided Jacobi SVDs per step)") + ", one core, series after series"
+    try:
+        avail_all = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail_all = os.cpu_count() or 1
     out = {"value": n2 * mat.T / dt, "unit": "series*timesteps/s", "cores": cores, "kind": "port",
+           "host_logical_cpus": os.cpu_count() or 1, "cpus_available_to_the_run": avail_all,   # `cores` = the threads actually used (the best of a short sweep up to the available count)
            "sample": f"{n2} of the {y_host.shape[0]} series x T={mat.T} (same inputs), {dt:.1f} s, {what}",
            "scala_reference": "unavailable (no JVM / Breeze jars on the box)"}
     if single is not None:
@@ -264,10 +269,16 @@ def add_secondary(line, args, ctx):
         keep["status_nonzero_series"] = r["status_nonzero_series"]
         return keep
 
-    full = run(flags=_lib.OPT_NO_STEADY, steps=5, warmup=1)
-    miss = run(missing=0.05, steps=5, warmup=1)
-    line["value_full_recursion"] = full["value"]        # every step recomputes the covariance recursion (DLM_OPT_NO_STEADY)
+    # (10 steps after 3 warm-ups each, SURVEY 8d's protocol: with 5 steps after 1 warm-up the first timed steps still paid for the
+    #  workspaces of the configuration before and the two values read 1-3 % low)
+    full = run(flags=_lib.OPT_NO_STEADY, steps=10, warmup=3)
+    miss = run(missing=0.05, steps=10, warmup=3)
+    line["value_full_recursion"] = full["value"]        # every step recomputes the covariance recursion (DLM_OPT_NO_STEADY): the like-for-like figure, the reference recomputes every step
     line["value_missing_0.05"] = miss["value"]          # 5 % of the observations missing (SURVEY 8d's second run)
+    line["config"]["value_full_recursion"] = full["value"]      # (also under `config`: the driver's record keeps that object whole)
+    line["config"]["value_missing_0.05"] = miss["value"]
+    line["config"]["ms_per_step_full_recursion"] = full["ms_per_step"]
+    line["config"]["ms_per_step_missing_0.05"] = miss["ms_per_step"]
     sec = {"c2_full_recursion": brief(full), "c2_missing_0.05": brief(miss)}
     sec["c2_literal_q1"] = brief(run(semantics="literal-q1", steps=3, warmup=1))
     sec["c2_shared_covariance_opt_in"] = brief(run(flags=_lib.OPT_SHARED_COV, steps=5, warmup=1))

@@ -80,6 +80,8 @@ enum {
   DLM_OPT_SAMPLER_PER_SERIES = 1u << 26, /* dlm_ffbs_batch, reference-form sampler: every series computes its own J_t, H_t and factors, also when the batch
                                            shares V, W, C0 on a regular grid (by default one wave computes them once per call and the series draw against
                                            its table: the same draws, bit for bit) */
+  DLM_OPT_TEST_FAIL_AFTER_TABLES = 1u << 30, /* TEST HOOK (tests/test_shared_sampler_gpu.py): dlm_ffbs_batch returns DLM_ERR_UNSUPPORTED right after it has started the
+                                           shared-factor tables and normals on the engine's auxiliary streams -- the error path that must leave the engine usable */
   DLM_OPT_SHARED_COV = 1u << 24         /* d <= 15, p = 1, regular grid, V, W, C0 shared by the batch: ONE wave runs the covariance recursions, every series
                                            only its mean recursions against their tables; a series with a missing observation runs its own recursion
                                            as always.  Bit for bit the results of the default kernels (tests/test_shared_cov_gpu.py) -- and, measured,

@@ -144,6 +144,80 @@ def test_c5_full_size_svd_agrees_with_standard_filter(eng):
     assert float((C - Ck).abs().max()) < 1e-7
 
 
+def test_c5_full_size_T1000_shared_factors_and_own_decompositions(eng):
+    """BASELINE configs[4] at its full length, 10 000 x T = 1000 -- past the ~390-step transient of the shared SVD factors, so that the
+    reuse branch of the table kernel and the mean kernel's long steady stretch are what is tested: the
+    shared-factor records equal the records of series that run their own decompositions (DLM_OPT_SVD_PER_SERIES) bit for bit, a
+    series with a gap is routed, and U D^2 U^T / the means equal the standard filter's on the whole batch."""
+    import torch
+    from bench import seasonal_c2, simulate
+    mod, p = seasonal_c2()
+    T, N, d = 1000, 10000, 13
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    yh = simulate(mat, p, N, seed=6)
+    yh[4321, 700, 0] = np.nan
+    y = torch.as_tensor(yh, device="cuda")
+    sv = eng.svd_filter(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2:] == (N - 1, 1)
+    assert int((sv["status"] != 0).sum().item()) == 0
+    rec = sv["svd"]
+    pick = [0, 4321, 4322, 9999]
+    own = eng.svd_filter(mat, p, y[pick], flags=_lib.OPT_SVD_PER_SERIES)["svd"]
+    assert torch.equal(own, rec[pick])
+    kf = eng.filter(mat, p, y)["filt"]
+    worst_m = worst_c = 0.0
+    for lo in range(0, N, 1000):                       # (in blocks: the reconstruction makes 13.5 GB temporaries per 10 000 series)
+        r = rec[lo:lo + 1000]
+        m, dc, U = r[..., :d], r[..., d:2 * d], r[..., 2 * d:].reshape(-1, T + 1, d, d).transpose(-1, -2)
+        C = (U * (dc * dc).unsqueeze(-2)) @ U.transpose(-1, -2)
+        k = kf[lo:lo + 1000]
+        worst_m = max(worst_m, float((m - k[..., :d]).abs().max()))
+        worst_c = max(worst_c, float((C - k[..., d:].reshape(-1, T + 1, d, d)).abs().max()))
+    assert worst_m < 1e-7 and worst_c < 1e-7, (worst_m, worst_c)
+
+
+def test_c4g_full_size_inside_inverse_wishart_gibbs(eng):
+    """BASELINE configs[3] as the pooled Inverse-Wishart Gibbs sampler calls it (GibbsWishart.scala:40-80): 2000 series x T = 1000,
+    d = 40, p = 20, outer-product statistics, filt_ws = NULL -- the records-free call: every series resident in the (64, 4) draw kernel,
+    the series without a gap leaving k_filter_w48 where the recursion settles (k_steady_filter_w48), gaps routed to k_sampler_w48.
+    The same seed reproduces; a shard with series_offset reproduces its block; a few series equal the generic kernel's draws (the
+    reference's operation sequence in LDS, Smoothing.scala:74-103) at full length; the series with gaps equal their
+    DLM_OPT_SAMPLER_PER_SERIES results bit for bit; the statistics are those of the states."""
+    import torch
+    from bench import multivariate_c4
+    mod, p = multivariate_c4()
+    T, N, d, q = 1000, 2000, 40, 20
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    y = eng.simulate(mat, p, N, seed=0xC46, series_offset=0, device=True, want_x=False)["y"]
+    gaps = [17, 1024, 1999]
+    for i, n in enumerate(gaps):
+        y[n, 100 + 300 * i, i] = float("nan")
+    fl = _lib.OPT_STATS_OUTER
+    a = eng.ffbs(mat, p, y, seed=13, flags=fl | _lib.OPT_COUNT_STEPS, want_filt=False)
+    assert eng.last_variant == "wave-sampler-shared" and eng.last_counters()[2:] == (N - len(gaps), len(gaps))
+    assert int((a["status"] != 0).sum().item()) == 0
+    b = eng.ffbs(mat, p, y, seed=13, flags=fl, want_filt=False)
+    assert torch.equal(a["theta"], b["theta"]) and torch.equal(a["stats"], b["stats"])
+    lo, hi = 1000, 1250                                    # rank 4 of 8
+    c = eng.ffbs(mat, p, y[lo:hi], seed=13, series_offset=lo, flags=fl, want_filt=False)
+    assert torch.equal(c["theta"], a["theta"][lo:hi]) and torch.equal(c["stats"], a["stats"][lo:hi])
+    for n in gaps:                                         # their own factors, whatever the route
+        g = eng.ffbs(mat, p, y[n:n + 1], seed=13, series_offset=n, flags=fl | _lib.OPT_SAMPLER_PER_SERIES)
+        assert eng.last_variant == "wave-sampler"
+        assert torch.equal(g["theta"][0], a["theta"][n]) and torch.equal(g["stats"][0], a["stats"][n])
+    om = _om(mat)
+    for n in (0, 1024, 1998):
+        g = eng.ffbs(mat, p, y[n:n + 1], seed=13, series_offset=n, flags=fl | _lib.OPT_FORCE_GENERIC)
+        assert eng.last_variant == "generic"
+        np.testing.assert_allclose(a["theta"][n].cpu().numpy(), g["theta"][0].cpu().numpy(), rtol=1e-6, atol=1e-6)
+        st = oracle.gibbs_stats(om, y[n].cpu().numpy(), a["theta"][n].cpu().numpy(), want_outer=True)
+        got = a["stats"][n].cpu().numpy()
+        np.testing.assert_allclose(got[:q], st["ssy"], rtol=1e-9)
+        np.testing.assert_array_equal(got[q:2 * q], st["n"])
+        np.testing.assert_allclose(got[2 * q:2 * q + d * d], np.asarray(st["outer"]).reshape(-1, order="F"), rtol=1e-8, atol=1e-8)
+        assert got[-1] == T
+
+
 def test_c3_full_size_ffbs_properties(eng):
     """BASELINE configs[2] (one rank's FFBS pass): 10 000 series x T = 1000, simulation smoother + statistics.  Properties:
     the same seed reproduces the draw bit for bit; a shard [lo, hi) with series_offset = lo draws exactly the same states

@@ -48,10 +48,21 @@ def both(eng, mat, p, y, flags=0, **kw):
     return sh, ps, cnt
 
 
+def _where(a, b):
+    """Where two outputs differ, for the assertion message: count, leading indices, the values, the largest difference."""
+    a, b = np.asarray(a), np.asarray(b)
+    ne = np.argwhere(~((a == b) | ((a != a) & (b != b))))
+    if len(ne) == 0:
+        return "equal"
+    lead = [np.unique(ne[:, ax]).tolist()[:12] for ax in range(ne.shape[1])]
+    vals = [(a[tuple(i)].item(), b[tuple(i)].item()) for i in ne[:4]]
+    return f"{len(ne)} of {a.size} values differ; indices per axis {lead}; first {ne[:4].tolist()} = {vals}; max |diff| {np.nanmax(np.abs(a.astype(float) - b.astype(float))):.3e}"
+
+
 def same(sh, ps):
     for k in ("theta", "stats", "filt", "status"):
         if sh[k] is not None:
-            assert np.array_equal(sh[k], ps[k], equal_nan=True), k
+            assert np.array_equal(sh[k], ps[k], equal_nan=True), (k, _where(sh[k], ps[k]))
 
 
 @pytest.mark.parametrize("T,N", [(1000, 37), (1, 5), (2, 3), (3, 4), (40, 9), (63, 4), (64, 4), (65, 4), (129, 300)])
@@ -205,6 +216,9 @@ def test_multivariate_draw_for_draw_the_per_series_kernel(eng, nblk, T, N, flags
     sh, ps, cnt = both_big(eng, mat, p, y, flags=flags, seed=5, series_offset=3)
     ngap = 1 if N > 3 else 0
     assert cnt[2] == N - ngap and cnt[3] == ngap, cnt
+    if not np.array_equal(sh["filt"], ps["filt"], equal_nan=True):      # which of the two calls left the plain filter's records?
+        ref = eng.filter(mat, p, y)["filt"]
+        raise AssertionError(("filt", "shared call vs dlm_filter_batch: " + _where(sh["filt"], ref), "per-series call vs dlm_filter_batch: " + _where(ps["filt"], ref)))
     same(sh, ps)
     assert np.all(sh["status"] == 0) and np.isfinite(sh["stats"]).all()
 
@@ -353,3 +367,62 @@ def test_alternating_calls_share_the_engine_workspaces(eng):
             if i == 0:       # a filter + smoother call in between (its own workspaces, the same streams)
                 fs = eng.filter_smooth(m, p, y)
                 assert np.all(fs["status"] == 0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The engine's auxiliary streams (tables on cov_stream, normals on rng_stream): rules A and B of dlm_engine.hip (aux_join / drain_all)
+# ------------------------------------------------------------------------------------------------------------------------
+def test_an_error_exit_with_the_auxiliary_streams_busy_leaves_the_engine_usable(eng):
+    """DLM_OPT_TEST_FAIL_AFTER_TABLES makes dlm_ffbs_batch return an error right after the shared-factor tables and the normals were
+    started on the second and third stream (round 3 left such an exit with kernels in flight that nothing waited for: they read the
+    staging arena and the table workspace of the NEXT call).  Every shape of shared-factor call: d <= 15 with and without records,
+    16 <= d <= 48 with and without records; host-memory calls, so that the arena is re-used at once; growing workspaces after the
+    failed call, so that the re-size path frees what the failed call's kernels use."""
+    from bayesian_dlms_amd.engine import EngineError
+    rng = np.random.default_rng(77)
+    cases = []
+    for T, N, want_filt in ((200, 64, True), (200, 64, False)):
+        mat, p = c2(T)
+        cases.append((mat, p, rng.standard_normal((N, T, 1)).cumsum(axis=1), 0, want_filt))
+    for T, N, want_filt in ((70, 6, True), (70, 6, False)):
+        mat, p = blocks(20, T, seed=20)
+        cases.append((mat, p, rng.standard_normal((N, T, mat.p)).cumsum(axis=1), _lib.OPT_STATS_OUTER, want_filt))
+    for i, (mat, p, y, f, wf) in enumerate(cases):
+        ref = eng.ffbs(mat, p, y, seed=40 + i, flags=f | _lib.OPT_SAMPLER_PER_SERIES, want_filt=wf)
+        with pytest.raises(EngineError, match="DLM_OPT_TEST_FAIL_AFTER_TABLES"):
+            eng.ffbs(mat, p, y, seed=40 + i, flags=f | _lib.OPT_TEST_FAIL_AFTER_TABLES, want_filt=wf)
+        # a larger call straight after (every workspace grows: the re-size path must wait for the failed call's kernels) ...
+        yb = np.concatenate([y, y[:, ::-1]], axis=0)
+        big = eng.ffbs(mat, p, yb, seed=40 + i, flags=f, want_filt=wf)
+        assert eng.last_variant.endswith("-shared") and np.all(big["status"] == 0)
+        # ... and the call itself again: the per-series reference, bit for bit
+        out = eng.ffbs(mat, p, y, seed=40 + i, flags=f, want_filt=wf)
+        for k in ("theta", "stats", "status"):
+            assert np.array_equal(out[k], ref[k], equal_nan=True), (i, k)
+        assert np.array_equal(big["theta"][: y.shape[0]], ref["theta"]), i    # (draws are keyed by the series index: the first half is the same batch)
+
+
+def test_an_engine_destroyed_right_after_an_asynchronous_shared_factor_call():
+    """dlm_engine_destroy drains all three streams before it frees the workspaces and destroys the streams (rule B): a
+    DLM_OPT_ASYNC call that is still running when the engine goes away must neither fault nor hang."""
+    import torch
+    from bayesian_dlms_amd.engine import Engine
+    rng = np.random.default_rng(5)
+    for mk, N, T, f in ((lambda T: c2(T), 4000, 300, 0), (lambda T: blocks(20, T, seed=20), 600, 120, _lib.OPT_STATS_OUTER)):
+        mat, p = mk(T)
+        yd = torch.as_tensor(rng.standard_normal((N, T, mat.p)).cumsum(axis=1), device="cuda:0")
+        for want_filt in (True, False):
+            e2 = Engine(0)
+            out = e2.ffbs(mat, p, yd, seed=9, flags=f | _lib.OPT_ASYNC, want_filt=want_filt)
+            assert e2.last_variant.endswith("-shared")
+            e2.close()                                    # kernels of the call are in flight on up to three streams
+            torch.cuda.synchronize()
+            theta = out["theta"].cpu().numpy()
+            assert np.isfinite(theta).all() and int(out["status"].abs().sum().item()) == 0
+    e3 = Engine(0)                                        # the device is fine afterwards
+    mat, p = c2(50)
+    y = rng.standard_normal((8, 50, 1))
+    a = e3.ffbs(mat, p, y, seed=1)
+    b = e3.ffbs(mat, p, y, seed=1, flags=_lib.OPT_SAMPLER_PER_SERIES)
+    assert np.array_equal(a["theta"], b["theta"])
+    e3.close()
