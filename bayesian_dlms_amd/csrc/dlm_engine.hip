@@ -1291,6 +1291,7 @@ int dlm_svd_filter_batch(dlm_engine* e, const dlm_model_desc* model,
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
   if (!y || !svd_rec) return fail(e, DLM_ERR_ARG, "y and svd_rec are required");
+  if (model->d > 48 || model->p > 32) return fail(e, DLM_ERR_UNSUPPORTED, "the SVD (square-root) filter takes d <= 48, p <= 32 in this build");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);
@@ -1325,6 +1326,7 @@ int dlm_svd_ffbs_batch(dlm_engine* e, const dlm_model_desc* model, const dlm_par
   int rc = check_common(e, model, params, opts);
   if (rc) return rc;
   if (!y || !svd_ws) return fail(e, DLM_ERR_ARG, "y and svd_ws are required");
+  if (model->d > 48 || model->p > 32) return fail(e, DLM_ERR_UNSUPPORTED, "the SVD (square-root) sampler takes d <= 48, p <= 32 in this build");
   const size_t d = model->d, p = model->p, T = model->T, N = model->N, srec = 2 * d + d * d;
   KArgs k{};
   Stager st(e, opts->mem == DLM_MEM_HOST);

@@ -200,6 +200,7 @@ hipError_t launch_wave48_sampler(const KArgs& a, hipStream_t s);
 hipError_t launch_tiled_simsmooth(const KArgs& a, double* xplus, double* ystar, hipStream_t s);
 
 // ---- SVD filter / sampler (one-sided Jacobi in LDS), dlm_svd.hip ----------------------
+bool svd_supported(const KArgs& a);      // d <= 48, p <= 32
 size_t svd_filter_lds_bytes(int d, int p);
 hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s);
 hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s);

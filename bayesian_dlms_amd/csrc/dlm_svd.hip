@@ -1,4 +1,5 @@
-// SVD (square-root) Kalman filter and backward sampler: d <= 16, p <= 16.
+// SVD (square-root) Kalman filter and backward sampler: d <= 48, p <= 32 (two instantiations: NM = 16 -- d, p <= 16, fourteen
+// one-wave workgroups per CU -- and NM = 48 -- the multivariate models of BASELINE configs[3], one workgroup per CU).
 //
 // Restates SvdFilter.scala:38-95, :183-236 and SvdSampler.scala:15-60, :94-102 with the two
 // LAPACK dgesdd calls per filter step (one per sampler step) replaced by a per-wavefront
@@ -21,8 +22,10 @@
 
 namespace dlm {
 
-constexpr int SL = 17;   // leading dimension of the d x d LDS matrices
-constexpr int STL = 33;  // largest leading dimension of the stacked matrix (<= 32 rows); kernels use `stl` (odd, sized by the shape)
+// SL = NM + 1 (defined in every template below): leading dimension of the d x d LDS matrices; `stl` (odd, sized by the shape): that of the stacked matrix
+// NM: the largest state / observation dimension of the instantiation (16 or 48).  PK: the row of the stacked matrix where the
+// measurement update parks vm fm^T (at or beyond the largest p of the instantiation).
+template <int NM> struct SvdDim { static constexpr int SL = NM + 1, PK = NM == 16 ? 16 : 32, PMAX = NM == 16 ? 16 : 32; };
 #define M17(buf, i, j) (buf)[(i) + (j) * SL]
 #define STK(i, j) stack[(i) + (j) * stl]
 
@@ -74,20 +77,29 @@ __device__ __forceinline__ double fast_rcp(double x) {
 #ifndef JACOBI_ENDGAME
 #define JACOBI_ENDGAME 1e-13
 #endif
+template <int NM>
 __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V, double* sig, bool warm = false) {
+  constexpr int SL = NM + 1;
+  constexpr int RK = NM / 4;    // rows of a column per lane of its 8-lane group (m <= 2 NM)
+  constexpr int VK = NM / 8;    // rows of V per lane
+  constexpr int NCH = NM / 16;  // an 8-lane group takes NCH of the up to NM / 2 pairs of a round, one after the other
   if (!warm) {
     for (int k = lane; k < n * n; k += 64) M17(V, k % n, k / n) = (k % n == k / n) ? 1.0 : 0.0;
   } else {
     ssync();
-    double row[16];   // lane i < m: row i of A, replaced by row^T V
-    if (lane < m) {
+    // row i of A, replaced by row^T V: lane i and, beyond 64 rows (NM = 48: m <= 96), lane i - 64 in a second pass
+    for (int i0 = 0; i0 < m; i0 += 64) {
+      double row[NM];
+      const int i = i0 + lane;
+      if (i < m) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) row[j] = j < n ? A[lane + j * lda] : 0.0;
-      for (int j = 0; j < n; ++j) {
-        double acc = 0.0;
+        for (int j = 0; j < NM; ++j) row[j] = j < n ? A[i + j * lda] : 0.0;
+        for (int j = 0; j < n; ++j) {
+          double acc = 0.0;
 #pragma unroll
-        for (int l = 0; l < 16; ++l) acc = fma(row[l], l < n ? M17(V, l, j) : 0.0, acc);
-        A[lane + j * lda] = acc;
+          for (int l = 0; l < NM; ++l) acc = fma(row[l], l < n ? M17(V, l, j) : 0.0, acc);
+          A[i + j * lda] = acc;
+        }
       }
     }
   }
@@ -104,22 +116,27 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
     bool rot_any = false, big_any = false;
     // round-robin schedule: group 0 pairs the fixed column np-1 with column r; group g pairs (r + g) and (r - g)
     // modulo np-1 -- both advance by one per round, so no integer division in the loop
-    int ra = grp % (np - 1), rb = (np - 1 - grp) % (np - 1);
+    int ras[NCH], rbs[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) { const int gg = grp + 8 * ch; ras[ch] = gg % (np - 1); rbs[ch] = (np - 1 - gg % (np - 1)) % (np - 1); }
     for (int r = 0; r < np - 1; ++r) {
       ssync();
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+      const int gg = grp + 8 * ch;
       int ca, cb;
-      if (grp == 0) { ca = np - 1; cb = r; }
-      else { ca = ra; cb = rb; }
-      ra = (ra + 1 == np - 1) ? 0 : ra + 1;
-      rb = (rb + 1 == np - 1) ? 0 : rb + 1;
-      const bool act = grp < half && ca < n && cb < n;
+      if (gg == 0) { ca = np - 1; cb = r; }
+      else { ca = ras[ch]; cb = rbs[ch]; }
+      ras[ch] = (ras[ch] + 1 == np - 1) ? 0 : ras[ch] + 1;
+      rbs[ch] = (rbs[ch] + 1 == np - 1) ? 0 : rbs[ch] + 1;
+      const bool act = gg < half && ca < n && cb < n;
       const int p = ca < cb ? ca : cb, q = ca < cb ? cb : ca;
       double* Ap = A + p * lda;
       double* Aq = A + q * lda;
-      double x[4], y[4];
+      double x[RK], y[RK];
       double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < RK; ++k) {
         const int i = sub + 8 * k;
         const bool ok = act && i < m;
         x[k] = ok ? Ap[i] : 0.0;
@@ -139,12 +156,12 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
         const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h * __builtin_amdgcn_rsq(h));
         const double c = fast_rsqrt(fma(t, t, 1.0)), s = t * c;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < RK; ++k) {
           const int i = sub + 8 * k;
           if (i < m) { Ap[i] = fma(c, x[k], -(s * y[k])); Aq[i] = fma(s, x[k], c * y[k]); }
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < VK; ++k) {
           const int i = sub + 8 * k;
           if (i < n) {
             const double vx = M17(V, i, p), vy = M17(V, i, q);
@@ -153,6 +170,7 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
         }
       }
       rot_any |= rot;
+      }
     }
     // Converged when a sweep rotated nothing -- or when all its rotations were below 3e-7: the off-diagonal mass
     // then drops quadratically to ~1e-13 within this very sweep (two decades below the 1e-11 at which factors count as
@@ -187,12 +205,14 @@ __device__ int jacobi_svd(int lane, int m, int n, double* A, int lda, double* V,
 // vanishing weights floored at 1e-13 sqrt(scale) first (a 1e-13 relative perturbation of the matrix, below the
 // steady-state tolerance of this file).  Prototype and stress test: 3000 adversarial cases, |V^T V - I| <= 8e-16.
 // In: lane j < d holds delta_j and w_j.  Out: V (d x d, ld SL, columns = eigenvectors in the caller's coordinates),
-// sig[i] = sqrt(lambda_i).  scr: 6 x 16 doubles of LDS scratch.
+// sig[i] = sqrt(lambda_i).  scr: 6 x NM doubles of LDS scratch.
+template <int NM>
 __device__ void secular_update(int lane, int d, double delta, double w, double* V, double* sig, double* scr) {
-  // LDS scratch (6 x 16 doubles): sorted poles, squared weights, roots' offsets and origins, Gu-Eisenstat weights, permutation.
+  constexpr int SL = NM + 1;
+  // LDS scratch (6 x NM doubles): sorted poles, squared weights, roots' offsets and origins, Gu-Eisenstat weights, permutation.
   // All loops over j read sds[j] / sw2[j] at a wave-uniform address (LDS broadcast): no per-lane register arrays.
-  double* sds = scr; double* sw2 = scr + 16; double* stau = scr + 32; double* sdso = scr + 48; double* szh = scr + 64;
-  int* sperm = (int*)(scr + 80);
+  double* sds = scr; double* sw2 = scr + NM; double* stau = scr + 2 * NM; double* sdso = scr + 3 * NM; double* szh = scr + 4 * NM;
+  int* sperm = (int*)(scr + 5 * NM);
   const double EPS = 2.220446049250313e-16;
   const bool act = lane < d;
   if (act) stau[lane] = delta;
@@ -296,11 +316,13 @@ __device__ void secular_update(int lane, int d, double delta, double w, double* 
 }
 
 // sqrtSvd / sqrtInvSvd (SvdFilter.scala:210-227): out = diag(sig^{+-1/2}) V^T for the SPD n x n Mx.
+template <int NM>
 __device__ int sqrt_svd(int lane, int n, const double* Mx /* global, col-major n x n */, bool inverse,
                         double* out, double* stack, int stl, double* Vacc, double* sig) {
+  constexpr int SL = NM + 1;
   for (int k = lane; k < n * n; k += 64) STK(k % n, k / n) = Mx[k];
   ssync();
-  const int rc = jacobi_svd(lane, n, n, stack, stl, Vacc, sig);
+  const int rc = jacobi_svd<NM>(lane, n, n, stack, stl, Vacc, sig);
   for (int k = lane; k < n * n; k += 64) {
     const int i = k % n, j = k / n;
     const double s = inverse ? 1.0 / sqrt(sig[i]) : sqrt(sig[i]);
@@ -318,51 +340,70 @@ struct SvdLds {
 // The filter needs only the first part (through the first 16 doubles of gs): its vm fm^T scratch lives in rows 16..31
 // of the stacked matrix, so that ten of its one-wave workgroups fit a CU instead of seven (the Jacobi rounds are
 // latency-bound: more waves per SIMD is throughput).
+// (the sampler: eight vectors, six NM x NM matrices, the 2 NM-row stack, two vectors of statistics -- 18 KB at NM = 16, 151 KB at NM = 48)
+template <int NM>
 __device__ __forceinline__ SvdLds carve(double* sm) {
+  constexpr int SL = NM + 1, STLN = 2 * NM + 1;
   SvdLds L;
-  L.m = sm; L.a = L.m + 16; L.dc = L.a + 16; L.dr = L.dc + 16; L.sig = L.dr + 16; L.e = L.sig + 16;
-  L.yv = L.e + 16; L.tv = L.yv + 16;
-  L.uc = L.tv + 16; L.ur = L.uc + 16 * SL; L.V = L.ur + 16 * SL; L.Wadv = L.V + 16 * SL;
-  L.sVinv = L.Wadv + 16 * SL;
-  L.stack = L.sVinv + 16 * SL;
-  L.idx = (int*)(L.stack + 16 * STL);
-  L.gs = L.stack + 16 * STL + 8;
-  L.tmp = L.gs + 16 * SL; L.sWb = L.tmp + 16 * SL;
+  L.m = sm; L.a = L.m + NM; L.dc = L.a + NM; L.dr = L.dc + NM; L.sig = L.dr + NM; L.e = L.sig + NM;
+  L.yv = L.e + NM; L.tv = L.yv + NM;
+  L.uc = L.tv + NM; L.ur = L.uc + NM * SL; L.V = L.ur + NM * SL; L.Wadv = L.V + NM * SL;
+  L.sVinv = nullptr;
+  L.stack = L.Wadv + NM * SL;
+  L.idx = nullptr;
+  L.gs = L.stack + NM * STLN;
+  L.tmp = L.gs + 2 * NM; L.sWb = L.tmp + NM * SL;
   return L;
 }
+template <int NM> constexpr size_t svd_sampler_lds_doubles() { return 8 * NM + 6 * NM * (NM + 1) + NM * (2 * NM + 1) + 2 * NM; }
 // The filter's LDS, sized by the shape: the decompositions are latency-bound (a Jacobi round is a dependent chain of ~2400
 // cycles), so waves per SIMD is throughput -- 11 KB per one-wave workgroup at d = 13, p = 1 (14 per CU) instead of 18.6.
-__device__ __host__ inline int svd_filter_stl(int d, int p) { int r = 2 * d; if (16 + p > r) r = 16 + p; if (p + d > r) r = p + d; return r | 1; }
+__device__ __host__ inline int svd_nm(int d, int p) { return (d <= 16 && p <= 16) ? 16 : 48; }
+__device__ __host__ inline int svd_filter_stl(int d, int p) {
+  const int pk = svd_nm(d, p) == 16 ? 16 : 32;
+  int r = 2 * d; if (pk + p > r) r = pk + p; if (p + d > r) r = p + d; if (r < 6) r = 6; return r | 1;
+}
+// doubles of the stacked matrix's region: n columns of stl rows -- and never less than the 6 NM doubles of scratch the secular
+// update takes there (tiny models used to reach past it, into vectors that happened to be dead)
+__device__ __host__ inline int svd_stack_doubles(int d, int p) {
+  const int n = d > p ? d : p, a = n * svd_filter_stl(d, p), b = 6 * svd_nm(d, p);
+  return a > b ? a : b;
+}
+template <int NM>
 __device__ __forceinline__ SvdLds carve_filter(double* sm, int d, int p) {
+  constexpr int SL = NM + 1;
   const int n = d > p ? d : p;
   SvdLds L;
-  L.m = sm; L.a = L.m + 16; L.dc = L.a + 16; L.dr = L.dc + 16; L.sig = L.dr + 16; L.e = L.sig + 16;
-  L.yv = L.e + 16; L.tv = L.yv + 16;
-  L.uc = L.tv + 16; L.ur = L.uc + n * SL; L.V = L.ur + n * SL; L.Wadv = L.V + n * SL;
+  L.m = sm; L.a = L.m + NM; L.dc = L.a + NM; L.dr = L.dc + NM; L.sig = L.dr + NM; L.e = L.sig + NM;
+  L.yv = L.e + NM; L.tv = L.yv + NM;
+  L.uc = L.tv + NM; L.ur = L.uc + n * SL; L.V = L.ur + n * SL; L.Wadv = L.V + n * SL;
   L.sVinv = L.Wadv + d * SL;
   L.stack = L.sVinv + p * SL;
-  L.idx = (int*)(L.stack + n * svd_filter_stl(d, p));
-  L.gs = L.stack + n * svd_filter_stl(d, p) + 8;
+  L.idx = (int*)(L.stack + svd_stack_doubles(d, p));
+  L.gs = L.stack + svd_stack_doubles(d, p) + NM / 2;
   L.tmp = nullptr; L.sWb = nullptr;
   return L;
 }
 size_t svd_filter_lds_bytes(int d, int p) {
-  const int n = d > p ? d : p;
-  return sizeof(double) * (size_t)(8 * 16 + 3 * n * SL + d * SL + p * SL + n * svd_filter_stl(d, p) + 8 + 16 + 2) + 16;   // (+ 2: the state of the steady-state test behind gs)
+  const int n = d > p ? d : p, nm = svd_nm(d, p), sl = nm + 1;
+  const size_t dbl = (size_t)(8 * nm + 3 * n * sl + d * sl + p * sl + svd_stack_doubles(d, p) + nm / 2 + nm + 2);   // (+ 2: the state of the steady-state test behind gs)
+  return sizeof(double) * dbl + 16;
 }
-size_t svd_sampler_lds_bytes(int, int) { return sizeof(double) * (8 * 16 + 8 * 16 * SL + 16 * STL + 8) + 16; }
+size_t svd_sampler_lds_bytes(int d, int p) { return sizeof(double) * (svd_nm(d, p) == 16 ? svd_sampler_lds_doubles<16>() : svd_sampler_lds_doubles<48>()) + 16; }
 
 // ---------------------------------------------------------------------------------------
 // SVD filter.  Record t: [m_t (d) | dc_t (d) | uc_t (d x d, column-major)].
 // ---------------------------------------------------------------------------------------
 // rec_stride (doubles, 0: 2 d + d^2) / aux: the covariance-only run of the shared-factor path (k_svd_mean_filter below) writes its
 // records as padded table rows and leaves sqrt(V)^-1[0][0] in aux[0].
-__global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restrict__ rec_out, int rec_stride, double* __restrict__ aux) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
+template <int NM>
+__global__ __launch_bounds__(64, NM == 16 ? 4 : 1) void k_svd_filter(KArgs a, double* __restrict__ rec_out, int rec_stride, double* __restrict__ aux) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = rec_stride ? rec_stride : 2 * d + dd;
   if (a.route && (a.route[n] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
-  SvdLds L = carve_filter(sm, d, p);
+  constexpr int SL = NM + 1, PK = SvdDim<NM>::PK;
+  SvdLds L = carve_filter<NM>(sm, d, p);
   double* stack = L.stack;
   const int stl = svd_filter_stl(d, p);
   const double* V = a.V + (size_t)n * a.v_stride;
@@ -377,13 +418,13 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
   if (a.flags & DLM_OPT_SVD_RAW_W_Q2) {
     for (int k = lane; k < dd; k += 64) M17(L.Wadv, k % d, k / d) = W[k];
     ssync();
-  } else if (sqrt_svd(lane, d, W, false, L.Wadv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
-  if (sqrt_svd(lane, p, V, true, L.sVinv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  } else if (sqrt_svd<NM>(lane, d, W, false, L.Wadv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (sqrt_svd<NM>(lane, p, V, true, L.sVinv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
   if (aux && lane == 0) aux[0] = M17(L.sVinv, 0, 0);
   // initialiseState (SvdFilter.scala:83-95): svd(C0) -> dc0 = sqrt(sigma), uc0 = V
   for (int k = lane; k < dd; k += 64) STK(k % d, k / d) = C0[k];
   ssync();
-  if (jacobi_svd(lane, d, d, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (jacobi_svd<NM>(lane, d, d, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
   for (int i = lane; i < d; i += 64) { L.m[i] = m0[i]; L.dc[i] = sqrt(L.sig[i]); out[i] = m0[i]; out[d + i] = sqrt(L.sig[i]); }
   for (int k = lane; k < dd; k += 64) { M17(L.uc, k % d, k / d) = M17(L.V, k % d, k / d); out[2 * d + k] = M17(L.V, k % d, k / d); }
   ssync();
@@ -401,7 +442,7 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
   // and only the mean moves.  Anything that disturbs the covariance (a missing observation, another dt, a variance
   // stream) clears it, the test starts over and the full path resumes.
   bool have_r = false, have_c = false, reuse_r = false, settled = false;
-  float* settle = (float*)(L.gs + 16);
+  float* settle = (float*)(L.gs + NM);
   settle_reset(settle);
   unsigned nsteady = 0;   // steps that skipped both decompositions (KArgs::counters[0])
   bool chain = false;     // the last step computed a measurement update (with transition chain_g / chain_dt, pattern chain_mask)
@@ -437,13 +478,13 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
         ssync();
       } else {
         ssync();
-        if (sqrt_svd(lane, d, Wt, false, L.Wadv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+        if (sqrt_svd<NM>(lane, d, Wt, false, L.Wadv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
         warm_c = false;
       }
     }
     if (a.v_tstride) {
       ssync();
-      if (sqrt_svd(lane, p, V + (size_t)t * a.v_tstride, true, L.sVinv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+      if (sqrt_svd<NM>(lane, p, V + (size_t)t * a.v_tstride, true, L.sVinv, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
       warm_c = false;
     }
     // advState (SvdFilter.scala:183-202)
@@ -474,7 +515,7 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
       }
       ssync();
       SVD_T0
-      { const int rc = jacobi_svd(lane, 2 * d, d, stack, stl, L.ur, L.dr, warm_r); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw1 += rc >> 8; }   // dr = sigma, ur = V
+      { const int rc = jacobi_svd<NM>(lane, 2 * d, d, stack, stl, L.ur, L.dr, warm_r); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw1 += rc >> 8; }   // dr = sigma, ur = V
       SVD_T1
       warm_r = true;
       }
@@ -502,7 +543,7 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
         const int i = k % pm, j = k / pm;
         double s = 0.0;
         for (int l = 0; l < pm; ++l) s = fma(M17(L.sVinv, L.idx[i], L.idx[l]), Ft[j + L.idx[l] * d], s);
-        STK(16 + i, j) = s;                    // vm fm^T, parked in rows 16.. of the stack
+        STK(PK + i, j) = s;                    // vm fm^T, parked in rows PK.. of the stack
       }
       ssync();
       if (reuse_c) ++nsteady;
@@ -511,24 +552,24 @@ __global__ __launch_bounds__(64, 4) void k_svd_filter(KArgs a, double* __restric
       for (int k = lane; k < pm * d; k += 64) {
         const int i = k % pm, j = k / pm;
         double s = 0.0;
-        for (int l = 0; l < d; ++l) s = fma(STK(16 + i, l), M17(L.ur, l, j), s);
+        for (int l = 0; l < d; ++l) s = fma(STK(PK + i, l), M17(L.ur, l, j), s);
         STK(i, j) = s;
       }
-      ssync();                                 // rows 16.. are overwritten next
+      ssync();                                 // rows PK.. are overwritten next
       if (pm == 1 && !(a.flags & DLM_OPT_FORCE_GENERIC)) {
         // one observed component: [w^T ; diag(1 / dr)] has A^T A = diag(1 / dr^2) + w w^T -- no Jacobi sweeps (secular_update)
         const double wj = lane < d ? STK(0, lane) : 0.0;
         const double rj = lane < d ? 1.0 / L.dr[lane] : 0.0;
         ssync();
         SVD_T0
-        secular_update(lane, d, rj * rj, wj, L.V, L.sig, stack);
+        secular_update<NM>(lane, d, rj * rj, wj, L.V, L.sig, stack);
         SVD_T1
         warm_c = false;
       } else {
       for (int k = lane; k < dd; k += 64) { const int i = k % d, j = k / d; STK(pm + i, j) = (i == j) ? 1.0 / L.dr[i] : 0.0; }
       ssync();
       SVD_T0
-      { const int rc = jacobi_svd(lane, pm + d, d, stack, stl, L.V, L.sig, warm_c); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw2 += rc >> 8; }
+      { const int rc = jacobi_svd<NM>(lane, pm + d, d, stack, stl, L.V, L.sig, warm_c); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw2 += rc >> 8; }
       SVD_T1
       warm_c = true;
       }
@@ -764,7 +805,7 @@ hipError_t launch_svd_filter_shared(const KArgs& a, double* svd_rec, double* ws,
   if (err != hipSuccess) return err;
   KArgs kc = a;
   kc.N = 1; kc.y = zeros; kc.m0 = zeros; kc.m0_stride = 0; kc.status = cst; kc.counters = nullptr; kc.route = nullptr;
-  hipLaunchKernelGGL(k_svd_filter, dim3(1), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kc, tab, tstride, aux);
+  hipLaunchKernelGGL(k_svd_filter<16>, dim3(1), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kc, tab, tstride, aux);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;
   km.route = route; km.route_take = 0;
@@ -774,13 +815,15 @@ hipError_t launch_svd_filter_shared(const KArgs& a, double* svd_rec, double* ws,
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs kg = a;
   kg.route = route; kg.route_take = 1;
-  hipLaunchKernelGGL(k_svd_filter, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kg, svd_rec, 0, (double*)nullptr);
+  hipLaunchKernelGGL(k_svd_filter<16>, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kg, svd_rec, 0, (double*)nullptr);
   return hipGetLastError();
 }
 
 // canonical factor: columns of U (d x d, LDS ld SL) and entries of s reordered so that the
 // ordering key is descending, then each column's largest-|.| entry made positive.
+template <int NM>
 __device__ void canon_factor(int lane, int d, double* U, double* s, const double* key, double* Utmp, double* stmp) {
+  constexpr int SL = NM + 1;
   if (lane < d) {
     int rank = 0;
     for (int k = 0; k < d; ++k) rank += (key[k] > key[lane]) || (key[k] == key[lane] && k < lane);
@@ -800,18 +843,20 @@ __device__ void canon_factor(int lane, int d, double* U, double* s, const double
 // ---------------------------------------------------------------------------------------
 // SVD backward sampler + Gibbs statistics (SvdSampler.scala:15-60)
 // ---------------------------------------------------------------------------------------
+template <int NM>
 __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __restrict__ rec_in) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = 2 * d + dd;
-  SvdLds L = carve(sm);
+  constexpr int SL = NM + 1;
+  SvdLds L = carve<NM>(sm);
   double* stack = L.stack;
-  constexpr int stl = STL;
+  constexpr int stl = 2 * NM + 1;
   double* th = L.e;      // theta_{t+1}
   double* zv = L.yv;     // normals
   double* ssv = L.dr;    // per-state sum of squares (diag statistics)
   double* outer = L.ur;  // outer-product statistics
-  double* ssy = L.gs; double* nob = L.gs + 16;
+  double* ssy = L.gs; double* nob = L.gs + NM;
   const double* W = a.W + (size_t)n * a.w_stride;
   const double* rin = rec_in + (size_t)n * (T + 1) * srec;
   const double* y = a.y ? a.y + (size_t)n * T * p : nullptr;
@@ -822,10 +867,10 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
   int st = 0;
 
   // ps.w of SvdSampler.ffbs: sqrtSvd(W) literally (Q9), sqrtInvSvd(W) for the consistent form
-  if (sqrt_svd(lane, d, W, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+  if (sqrt_svd<NM>(lane, d, W, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
   for (int i = lane; i < d; i += 64) ssv[i] = 0.0;
   for (int k = lane; k < dd; k += 64) M17(outer, k % d, k / d) = 0.0;
-  for (int i = lane; i < 32; i += 64) ssy[i] = 0.0;
+  for (int i = lane; i < 2 * NM; i += 64) ssy[i] = 0.0;
   ssync();
 
   // initialise (SvdSampler.scala:38-45): theta_T = m_T + uc_T diag(dc_T) z, canonical factor order
@@ -837,7 +882,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
     }
     for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = r[2 * d + k];
     ssync();
-    canon_factor(lane, d, L.uc, L.dc, L.sig, L.tmp, L.tv);
+    canon_factor<NM>(lane, d, L.uc, L.dc, L.sig, L.tmp, L.tv);
     for (int i = lane; i < d; i += 64) {
       double s = L.m[i];
       for (int k = 0; k < d; ++k) s = fma(M17(L.uc, i, k) * L.dc[k], zv[k], s);
@@ -868,7 +913,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
     for (int k = lane; k < dd; k += 64) M17(L.uc, k % d, k / d) = r[2 * d + k];
     ssync();
     if (a.w_tstride) {   // the step from record t uses W_t, the transition into observation t (DlmFsvSystem.scala:196-205)
-      if (sqrt_svd(lane, d, W + (size_t)t * a.w_tstride, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+      if (sqrt_svd<NM>(lane, d, W + (size_t)t * a.w_tstride, !(a.flags & DLM_OPT_SVD_SAMPLER_Q9), L.sWb, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
     }
     // a_{t+1} = G m_t ; tmp = sqrtWb G
     for (int i = lane; i < d; i += 64) {
@@ -892,7 +937,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
       STK(d + i, j) = (i == j) ? 1.0 / L.dc[i] : 0.0;
     }
     ssync();
-    if (jacobi_svd(lane, 2 * d, d, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
+    if (jacobi_svd<NM>(lane, 2 * d, d, stack, stl, L.V, L.sig)) st |= DLM_ST_NOCONV;
     // uh = uc V -> Wadv buffer ; dh = 1/sigma -> tv
     for (int k = lane; k < dd; k += 64) {
       const int i = k % d, j = k / d;
@@ -902,7 +947,7 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
     }
     for (int i = lane; i < d; i += 64) L.tv[i] = 1.0 / L.sig[i];
     ssync();
-    canon_factor(lane, d, L.Wadv, L.tv, L.sig, L.V, L.dc);   // V, dc are free scratch now
+    canon_factor<NM>(lane, d, L.Wadv, L.tv, L.sig, L.V, L.dc);   // V, dc are free scratch now
     double* uh = L.Wadv; double* dh = L.tv;
     // h = m + uh dh^2 uh^T G^T sqrtWb^T sqrtWb (theta_{t+1} - a_{t+1})
     double* u = L.sig;   // d-vectors: reuse sig, dc as scratch
@@ -954,15 +999,35 @@ __global__ __launch_bounds__(64) void k_svd_sampler(KArgs a, const double* __res
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
+bool svd_supported(const KArgs& a) { return a.d >= 1 && a.d <= 48 && a.p >= 1 && a.p <= 32; }
+// the NM = 48 instantiations take up to 151 KB of the CU's 160 KB of LDS: above the 64 KB a kernel gets without asking
+static hipError_t svd_big_lds_once() {
+  static hipError_t done = []() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svd_filter<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_svd_sampler<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }();
+  return done;
+}
 hipError_t launch_svd_filter(const KArgs& a, double* svd_rec, hipStream_t s) {
-  if (a.d > 16 || a.p > 16) return hipErrorNotSupported;
-  hipLaunchKernelGGL(k_svd_filter, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec, 0, (double*)nullptr);
+  if (!svd_supported(a)) return hipErrorNotSupported;
+  if (svd_nm(a.d, a.p) == 16) hipLaunchKernelGGL(k_svd_filter<16>, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec, 0, (double*)nullptr);
+  else {
+    const hipError_t e = svd_big_lds_once();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_svd_filter<48>, dim3(a.N), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, a, svd_rec, 0, (double*)nullptr);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_svd_sampler(const KArgs& a, const double* svd_rec, hipStream_t s) {
-  if (a.d > 16 || a.p > 16) return hipErrorNotSupported;
-  hipLaunchKernelGGL(k_svd_sampler, dim3(a.N), dim3(64), svd_sampler_lds_bytes(a.d, a.p), s, a, svd_rec);
+  if (!svd_supported(a)) return hipErrorNotSupported;
+  if (svd_nm(a.d, a.p) == 16) hipLaunchKernelGGL(k_svd_sampler<16>, dim3(a.N), dim3(64), svd_sampler_lds_bytes(a.d, a.p), s, a, svd_rec);
+  else {
+    const hipError_t e = svd_big_lds_once();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_svd_sampler<48>, dim3(a.N), dim3(64), svd_sampler_lds_bytes(a.d, a.p), s, a, svd_rec);
+  }
   return hipGetLastError();
 }
 

@@ -317,7 +317,8 @@ int dlm_backward_sample_batch(dlm_engine *e, const dlm_model_desc *model,
 /* ---- SVD (square-root) filter / sampler -------------------------------------------
  * Replaces SvdFilter.filterDlm (SvdFilter.scala:158-161) and SvdSampler.ffbsDlm
  * (SvdSampler.scala:79-82).  svd_rec [N][T+1][d + d + d*d] = (m_t, dc_t, uc_t) with
- * C_t = uc diag(dc^2) uc^T. */
+ * C_t = uc diag(dc^2) uc^T.  d <= 48, p <= 32 (DLM_ERR_UNSUPPORTED beyond): one wavefront per series, the
+ * decompositions in LDS; models with d, p <= 16 keep fourteen series per CU, larger ones one. */
 int dlm_svd_filter_batch(dlm_engine *e, const dlm_model_desc *model,
                          const dlm_params_desc *params, const double *y,
                          const dlm_options *opts, double *svd_rec, int32_t *status);
