@@ -212,7 +212,7 @@ int check_common(dlm_engine* e, const dlm_model_desc* m, const dlm_params_desc* 
   if ((p->v_tstride != 0 && p->v_tstride != (int64_t)m->p * m->p) || (p->w_tstride != 0 && p->w_tstride != (int64_t)m->d * m->d))
     return fail(e, DLM_ERR_ARG, "v_tstride must be 0 or p*p, w_tstride 0 or d*d");
   if (o->mem != DLM_MEM_DEVICE && o->mem != DLM_MEM_HOST) return fail(e, DLM_ERR_ARG, "opts->mem");
-  if (m->d > 64 || m->p > 64) return fail(e, DLM_ERR_UNSUPPORTED, "d and p are limited to 64 in this build");
+  if (m->d > 64 || m->p > 64) return fail(e, DLM_ERR_UNSUPPORTED, "d and p are limited to 64 in this build (and by the LDS of one CU on the general kernels: see the entry point's message)");
   HIP_TRY(e, hipSetDevice(e->device));
   return DLM_OK;
 }
@@ -472,14 +472,17 @@ int packed_path(dlm_engine* e, KArgs& k) {
 bool use_shared_cov(const dlm_engine* e, const KArgs& k) {
   return fast_shape_ok(k) && e->sparse_k > 0 && !dlm::lane_supported(k) && dlm::shared_cov_eligible(k);
 }
+// route: one byte per series; behind it (64-byte aligned) one int per series, the step a series left the per-wave filter at (KArgs::leave_step)
+size_t route_pad(size_t N) { return (N + 63) & ~(size_t)63; }
 int ensure_route(dlm_engine* e, size_t N) {
   if (N > e->route_bytes) {
     if (e->route) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->route)); e->route = nullptr; e->route_bytes = 0; }
-    HIP_TRY(e, hipMalloc((void**)&e->route, N));
+    HIP_TRY(e, hipMalloc((void**)&e->route, route_pad(N) + N * sizeof(int)));
     e->route_bytes = N;
   }
   return DLM_OK;
 }
+int* leave_of(dlm_engine* e) { return (int*)(e->route + route_pad(e->route_bytes)); }
 int ensure_xplus_bytes(dlm_engine* e, size_t need) {
   if (need > e->xplus_bytes) {
     if (e->xplus) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->xplus)); e->xplus = nullptr; e->xplus_bytes = 0; }
@@ -631,6 +634,8 @@ int run_filter(dlm_engine* e, const KArgs& k, bool want_side) {
     HIP_TRY(e, dlm::launch_tiled_filter(k, want_side ? e->ystar : nullptr, e->stream));
   } else {
     e->variant = "generic";
+    if (dlm::generic_filter_lds_bytes(k.d, k.p) > 160 * 1024)   // 3 d + 4 d^2 + 2 d p + 2 p^2 + 3 p doubles of one CU's 160 KB of LDS
+      return fail(e, DLM_ERR_UNSUPPORTED, "the general filter kernel keeps a series' matrices in the LDS of one CU: this d, p needs more than its 160 KB (d = 64 fits with p <= 12, p = 64 with d <= 26)");
     HIP_TRY(e, dlm::launch_generic_filter(k, e->stream));
   }
   return DLM_OK;
@@ -663,6 +668,8 @@ int run_smoother(dlm_engine* e, const KArgs& k, bool have_side) {
     HIP_TRY(e, dlm::launch_small_mv_rts(k, e->stream));
   } else {
     e->variant = "generic";
+    if (dlm::generic_smoother_lds_bytes(k.d, k.p) > 160 * 1024)
+      return fail(e, DLM_ERR_UNSUPPORTED, "the general RTS smoother kernel keeps six d x d matrices in the LDS of one CU: d <= 58 (structured models with d <= 48 take the per-wave kernels)");
     HIP_TRY(e, dlm::launch_generic_smoother(k, e->stream));
   }
   return DLM_OK;
@@ -1213,6 +1220,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
         HIP_TRY(e, dlm::launch_wave48_mark_gaps(k, e->route, e->stream));
         k.keep_cov = e->route;
         k.ktab = stb.ktab;     // ... and they leave the filter where the recursion settles: k_steady_filter_w48 carries their means on
+        k.leave_step = leave_of(e);
+        HIP_TRY(e, hipMemsetD32Async((hipDeviceptr_t)k.leave_step, k.T, (size_t)k.N, e->stream));   // T: the series ran the whole filter
         stb.marked = 1;
       }
       if ((rc = run_filter(e, k, false))) return rc;
@@ -1220,7 +1229,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev2, 0));   // the zero series' filter: the steady gain and the step it settled at
         HIP_TRY(e, dlm::launch_wave48_steady_filter(k, stb.ktab, stb.settle, e->stream));
       }
-      k.keep_cov = nullptr; k.ktab = nullptr;
+      k.keep_cov = nullptr; k.ktab = nullptr; k.leave_step = nullptr;
       k.filt_in = k.filt;
     }
   }
@@ -1268,6 +1277,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
     return done();
   }
   e->variant = "generic";
+  if (dlm::generic_sampler_lds_bytes(k.d, k.p) > 160 * 1024)
+    return fail(e, DLM_ERR_UNSUPPORTED, "the general backward sampler kernel keeps seven d x d matrices in the LDS of one CU: d <= 53 (structured models with d <= 48 take the per-wave kernels)");
   HIP_TRY(e, dlm::launch_generic_sampler(k, e->stream));
   return done();
 }

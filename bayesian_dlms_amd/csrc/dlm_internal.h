@@ -51,6 +51,9 @@ struct KArgs {
   double* ktab;                   // per-wave filter, with keep_cov: the steady gain K^T (16 PT rows of the LDS image) of the batch -- WRITTEN by the series
                                   // of zeros where its covariance recursion settles (with settle_step), and, when set for the batch's own filter, the
                                   // sign that its series without a gap leave at that step: k_steady_filter_w48 carries their means on from there
+  int* leave_step;                // per-wave filter, with ktab set for the batch's own filter: [N] the step at which series n left k_filter_w48 (its own
+                                  // convergence test; T: it never did) -- k_steady_filter_w48 carries series n on from THAT record, so that no assumption
+                                  // about every series settling at the zero series' step is needed
   int stretches;                  // backward sampler: 1 = every stretch of steps starts from scratch (dlm_sampler16.hip: SF_STRETCH), set for the calls
                                   // whose parameters allow a shared-factor table -- its stretches are made side by side, and a series that computes
                                   // its own factors in such a call follows the same rule, so that the two agree bit for bit

@@ -140,6 +140,10 @@ hipError_t launch_loglik_q7(const KArgs& a, const double* records, void* ws, hip
   hipError_t err = hipMemsetAsync(wbad, 0, sizeof(int) * nset, s);
   if (err != hipSuccess) return err;
   const size_t lds1 = sizeof(double) * 2 * (size_t)d * (d + 1);
+  if (lds1 > 64 * 1024) {   // d = 64: 66 560 bytes, above what a kernel gets without asking
+    static const hipError_t big = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spd_inverse_logdet), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (big != hipSuccess) return big;
+  }
   hipLaunchKernelGGL(k_spd_inverse_logdet, dim3((unsigned)nset), dim3(64), lds1, s, d, (int)nset, a.W, (long long)a.w_stride, Winv, logdet, wbad);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   const int g_in_lds = ((size_t)a.n_g * d * d * 8 <= 32768) ? 1 : 0;

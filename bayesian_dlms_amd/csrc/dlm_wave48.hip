@@ -680,7 +680,10 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
         if (a.ktab) for (int i = lane; i < 16 * PT * IL; i += 64) a.ktab[i] = img[i];   // K^T of the steady steps (k_steady_filter_w48)
         break;
       }
-      if (mean_only_out && a.ktab) break;   // a series without a gap of a records-free call: k_steady_filter_w48 takes its means from record t on
+      if (mean_only_out && a.ktab) {        // a series without a gap of a records-free call: k_steady_filter_w48 takes its means from record t on
+        if (a.leave_step && lane == 0) a.leave_step[n] = t;
+        break;
+      }
       // a stretch of steady steps as a loop of its own: one back edge, so that the wait for the next observation counts the
       // stores behind it (vmcnt(42)) -- at the head of the big loop, where two paths meet, it would be vmcnt(0): every step
       // would sit out the latency of its 39 record stores.  (The flags are read through readfirstlane: a branch the compiler
@@ -1888,8 +1891,15 @@ __global__ __launch_bounds__(64, 4) void k_steady_filter_w48(KArgs a, const doub
   const int n = blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   if (!a.keep_cov || a.keep_cov[n] != 0) return;            // the series with a gap ran the whole filter
   const int d = a.d, p = a.p, T = a.T, rec = d + d * d, recb = rec * 8;
-  const int t0 = settle[0];
-  if (t0 >= T) return;                                       // nothing settled: k_filter_w48 went all the way
+  // the record this series left k_filter_w48 at (its own convergence test).  It is the zero series' step (settle[0]) -- the recursion does
+  // not see the data and both ran the same kernel -- but nothing here depends on that: the means continue from the series' own record,
+  // with the zero series' steady gain (the two agree within DLM_SETTLE_TOL even if the steps should ever differ)
+  const int t0 = a.leave_step ? a.leave_step[n] : settle[0];
+  if (t0 >= T) return;                                       // this series did not settle: k_filter_w48 went all the way
+  if (settle[0] >= T) {                                      // (cannot happen: the series left, but the zero series has no steady gain to give)
+    if (a.status && lane == 0) atomicOr(&a.status[n], DLM_ST_NOCONV | DLM_ST_NONFINITE);
+    return;
+  }
   for (int i = lane; i < 3 * VL; i += 64) mv[i] = 0.0;
   bool jd[DT], jp[PT];
 #pragma unroll
