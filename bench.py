@@ -79,19 +79,38 @@ def simulate(mat, p, N, seed):
     return y
 
 
-def traffic_from_profiles(kernel, N, T, config):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note +
-    WRITE_SIZE, profiles/r0X_hbm_traffic.json), valid for the default workload only; None otherwise (PMC counters cannot be
-    read from inside the run)."""
-    if config != "c2" or (N, T) != (10000, 1000):
+def profile_tag(args):
+    """The name tools/profile_round4.sh gives this configuration (its bench arguments without blanks, dashes and dots), or None."""
+    if args.T != 1000 or args.records != "dense" or args.gpus != 1:
         return None
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            k = json.load(open(path))["kernels"].get(kernel)
-            if k is not None:
-                return k["hbm_bytes_per_launch"]
-    return None
+    tag = args.config
+    opts = [(args.flags != 0, f"flags{args.flags}"), (args.missing > 0.0, "missing" + str(args.missing).replace(".", "")),
+            (args.semantics != "textbook", "semantics" + args.semantics.replace("-", "")), (args.series is not None, f"series{args.series}"),
+            (args.config in ("c3", "c4g") and args.sampler != "reference", "sampler" + args.sampler)]
+    on = [name for cond, name in opts if cond]
+    if len(on) > 1:
+        return None
+    return tag + (on[0] if on else "")
+
+
+def traffic_from_profiles(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (2 x FETCH_SIZE per the gfx950 note + WRITE_SIZE,
+    profiles/r04_hbm_traffic.json: one entry per configuration, kernel and grid size, tools/profile_round4.sh) -- PMC counters cannot be
+    read from inside the run.  The figure is DROPPED (None, with the reason) when the .hip file that defines the kernel has changed
+    since the counters were taken: a stale number is not reported."""
+    import hashlib
+    tag = profile_tag(args)
+    path = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+    if tag is None or not os.path.exists(path):
+        return None, "no PMC pass for this configuration"
+    ents = [e for e in json.load(open(path))["configs"].get(tag, []) if kernel in e["kernel"]]
+    if not ents:
+        return None, "no PMC pass for this configuration"
+    e = max(ents, key=lambda x: x["grid_threads"])        # (the batch's launch, not the one-wave table launches of the same kernel)
+    src = os.path.join(ROOT, "bayesian_dlms_amd", "csrc", e["source"] or "")
+    if not e.get("source") or not os.path.exists(src) or hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] != e["source_sha16"]:
+        return None, f"PMC figure dropped: {e.get('source')} changed since profiles/r04_hbm_traffic.json was taken"
+    return e["hbm_bytes_per_launch"], None
 
 
 def measure_copy_peak(torch, dev, nbytes=4 << 30):
@@ -265,7 +284,7 @@ def add_secondary(line, args, ctx):
         keep["variant"] = r["config"]["variant"]
         keep["semantics"] = r["config"]["semantics"]
         keep["steady_fraction"] = r["config"].get("steady_fraction")
-        keep["roofline"] = {k: r["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "forward_ms", "backward_ms", "note") if k in r["roofline"]}
+        keep["roofline"] = {k: r["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_GBps", "traffic_note", "peak_measured", "frac_of_measured", "avg_launch_ms", "forward_ms", "backward_ms", "note") if k in r["roofline"]}
         keep["status_nonzero_series"] = r["status_nonzero_series"]
         return keep
 
@@ -466,13 +485,13 @@ def run_one(args, ctx):
             names = ("k_filter_", "k_sampler_")
         else:
             fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * (2 * d + d * d), 0.0, "GB/s", HBM_PEAK_GBS, "hbm"
-            names = ("k_svd_filter_", "")
+            names = ("k_svd_filter", "")
         dom_is_bwd = b_ms >= f_ms and bwd_u > 0
         dom_u, dom_ms = (bwd_u, b_ms) if dom_is_bwd else (fwd_u, f_ms)
         scale = 1e9 if unit == "GB/s" else 1e12
         achieved = dom_u * nt / (dom_ms * 1e-3) / scale
         short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16", "sparse16-rts": "rts16", "wave-sampler": "w48", "wave-simsmooth": "w48",
-                 "sparse16-simsmooth": "sp16", "svd-jacobi": "jacobi", "sparse16-sampler-shared": "sp16", "wave-sampler-shared": "w48"}.get(variant, variant)
+                 "sparse16-simsmooth": "sp16", "svd-jacobi": "", "sparse16-sampler-shared": "sp16", "wave-sampler-shared": "w48"}.get(variant, variant)
         kname = (names[1] if dom_is_bwd else names[0]) + short
         workloads = {
             "c2": f"C2: seasonal DLM polynomial(1)|+|seasonal(24,6), d=13, p=1, {job_series} series x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
@@ -500,11 +519,15 @@ def run_one(args, ctx):
                        "parallelism": f"series-sharded x{world}" + (", one RCCL all-reduce of %d doubles per iteration (comm world %d)" % (2 * q + (d if cfg == "c3" else d * d) + 1, comm_world)
                                                                     if cfg in ("c3", "c4g") else ", no collective")},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": traffic_from_profiles(kname, N, T, cfg) if not packed and args.missing == 0.0 and not (flags & _lib.OPT_NO_STEADY) and args.semantics == "textbook" else None,
+                         "frac": achieved / peak, "traffic": None,
                          "algorithmic_units_per_launch": dom_u * nt, "avg_launch_ms": dom_ms,
                          "forward_ms": f_ms, "backward_ms": b_ms},
             "status_nonzero_series": status_bad,
         }
+        tr_bytes, tr_note = traffic_from_profiles(kname, args)
+        line["roofline"]["traffic"] = tr_bytes
+        if tr_note:
+            line["roofline"]["traffic_note"] = tr_note
         line["roofline"]["achieved_basis"] = "ALGORITHMIC units per launch (SURVEY 8d) / launch time"
         if moved_note:
             line["roofline"]["achieved_basis"] = moved_note
