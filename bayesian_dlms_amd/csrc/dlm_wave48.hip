@@ -653,6 +653,8 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
   settle_reset(settle);
   unsigned nsteady = 0;                       // steady steps taken (KArgs::counters[0])
   bool sreset = false;                        // the convergence test starts over at its next evaluation
+  int tleave = T;                             // the step at which a series of a records-free call left for k_steady_filter_w48 (KArgs::leave_step; written after
+                                              // the loop: a store inside it cost this kernel 400 spilled registers)
 
   for (int t = 0; t < T; ++t) {
     // opaque copies of the lane coordinates: the compiler would otherwise hoist the few dozen address computations of
@@ -680,10 +682,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
         if (a.ktab) for (int i = lane; i < 16 * PT * IL; i += 64) a.ktab[i] = img[i];   // K^T of the steady steps (k_steady_filter_w48)
         break;
       }
-      if (mean_only_out && a.ktab) {        // a series without a gap of a records-free call: k_steady_filter_w48 takes its means from record t on
-        if (a.leave_step && lane == 0) a.leave_step[n] = t;
-        break;
-      }
+      if (mean_only_out && a.ktab) { tleave = t; break; }   // a series without a gap of a records-free call: k_steady_filter_w48 takes its means from record t on
       // a stretch of steady steps as a loop of its own: one back edge, so that the wait for the next observation counts the
       // stores behind it (vmcnt(42)) -- at the head of the big loop, where two paths meet, it would be vmcnt(0): every step
       // would sit out the latency of its 39 record stores.  (The flags are read through readfirstlane: a branch the compiler
@@ -942,6 +941,7 @@ __global__ __launch_bounds__(64, (DT <= 2 && PT == 1 && KF <= 1) ? 2 : 1) void k
     }
   }
   if (a.loglik && lane == 0) a.loglik[n] = ll;
+  if (a.leave_step && lane == 0) a.leave_step[n] = tleave;
   if (a.counters && lane == 0 && nsteady) atomicAdd(&a.counters[0], (unsigned long long)nsteady);
   bool bad = false;
 #pragma unroll
