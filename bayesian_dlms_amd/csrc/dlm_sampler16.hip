@@ -187,7 +187,13 @@ constexpr int SF_ENT = 34;                 // 272 bytes per component: sixteen l
 constexpr int SF_ROW = 16 * SF_ENT;
 constexpr int SF_SLOT = 4096;              // LDS bytes of a ring slot (15 * 272 = 4080 at most travel)
 constexpr int SF_AHEAD = 8;                // the filtered means are requested this many steps ahead
-constexpr int SF_STRETCH = 32;             // steps t with t % SF_STRETCH == SF_STRETCH - 1 start from scratch (k_sampler_sp16, every series)
+// Stretches: steps t at the top of one start from scratch (k_sampler_sp16, every series).  32 steps long -- and 16 below step SF_SHORT_END, where
+// the filtered covariance of a typical model is still moving and every step of a stretch is computed in full: the longest stretch is what the
+// draw kernel of a shared-factor call waits for (C3: the table 1.24 -> 0.7 ms, no longer behind the forward mean kernel).
+constexpr int SF_STRETCH = 32, SF_SHORT = 16, SF_SHORT_END = 384;
+__host__ __device__ constexpr bool sf_stretch_top(int t) { return (t & (SF_STRETCH - 1)) == SF_STRETCH - 1 || (t < SF_SHORT_END && (t & (SF_SHORT - 1)) == SF_SHORT - 1); }
+__host__ __device__ constexpr int sf_stretches(int T) { return T <= SF_SHORT_END ? (T + SF_SHORT - 1) / SF_SHORT : SF_SHORT_END / SF_SHORT + (T - SF_SHORT_END + SF_STRETCH - 1) / SF_STRETCH; }
+__host__ __device__ constexpr int sf_stretch_lo(int b) { return b < SF_SHORT_END / SF_SHORT ? b * SF_SHORT : SF_SHORT_END + (b - SF_SHORT_END / SF_SHORT) * SF_STRETCH; }
 
 // Tab: SparseT (the d <= 15, p = 1 tables) or SparseBig (the tables of the multivariate paths); any p <= 64 -- the
 // observations only enter the statistics.
@@ -203,8 +209,9 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   // scratch, see SF_STRETCH)
   const int n = EXP ? 0 : blockIdx.x, lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, rec = d + dd, recb = rec * 8;
-  const int t_lo = EXP ? (int)blockIdx.x * SF_STRETCH : 0;
-  const int t_hi = EXP ? ((t_lo + SF_STRETCH < T ? t_lo + SF_STRETCH : T) - 1) : T - 1;
+  const int t_lo = EXP ? sf_stretch_lo((int)blockIdx.x) : 0;
+  const int t_nx = EXP ? sf_stretch_lo((int)blockIdx.x + 1) : T;
+  const int t_hi = (t_nx < T ? t_nx : T) - 1;
   const bool vc = c < d;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
   for (int i = lane; i < 8 * 16; i += 64) mv[i] = 0.0;
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(64, 2) void k_sampler_sp16(KArgs a, const Tab* __re
   for (int t = t_hi; t >= t_lo; --t) {
     // Every SF_STRETCH steps the recursion starts from scratch -- a full step, its inverse not refined from the one before: what a
     // step computes then depends on nothing above its stretch, and the stretches of a shared-factor table are made side by side.
-    if ((EXP || a.stretches) && (t & (SF_STRETCH - 1)) == SF_STRETCH - 1) { have = false; warm = false; }
+    if ((EXP || a.stretches) && sf_stretch_top(t)) { have = false; warm = false; }
     // the normals of records t, t-1, t-2, t-3 (16 components each) are drawn together, one per lane, every fourth step:
     // the generator is the same few hundred instructions whether 13 lanes or 64 need a value
     if (!EXP && !zin && ((T - 1 - t) & 3) == 0) {
@@ -1049,7 +1056,7 @@ hipError_t launch_sampler_shared_tables(const KArgs& a, int K, const SparseT* ta
   if ((err = launch_sparse16_filter(kf, K, tabs_dev, nullptr, nullptr, s)) != hipSuccess) return err;
   KArgs kp = kf;
   kp.y = nullptr; kp.filt_in = tb.zrec;
-  const dim3 grid((a.T + s16::SF_STRETCH - 1) / s16::SF_STRETCH);   // one wave per stretch
+  const dim3 grid(s16::sf_stretches(a.T));   // one wave per stretch
   switch (K) {
     case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
     case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
@@ -1107,7 +1114,7 @@ hipError_t launch_sampler_shared_tables_from(const KArgs& a, int K, const Sparse
   kp.N = 1; kp.y = nullptr; kp.filt_in = crec; kp.filt = nullptr; kp.status = tb.status; kp.stats = nullptr; kp.loglik = nullptr; kp.prior = nullptr; kp.fq = nullptr;
   kp.route = nullptr; kp.counters = nullptr; kp.theta = nullptr; kp.z = nullptr; kp.series_offset = 0; kp.m0_stride = 0;
   tb.zstride = stride;
-  const dim3 grid((a.T + s16::SF_STRETCH - 1) / s16::SF_STRETCH);
+  const dim3 grid(s16::sf_stretches(a.T));
   switch (K) {
     case 1: hipLaunchKernelGGL((s16::k_sampler_sp16<1, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
     case 2: hipLaunchKernelGGL((s16::k_sampler_sp16<2, SparseT, true>), grid, dim3(64), 0, s, kp, tabs_dev, tb); break;
