@@ -1139,10 +1139,11 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
   bool shared_factors = false, shared_big = false;
   dlm::SampTabs stb{};
-  // a V_t stream is a scalar per step on the structured d <= 15, p = 1 path (the Student-t DLM, StudentTGibbs.scala:100-136)
-  // and goes through; W_t streams and V_t elsewhere would need a factorisation per step
-  if (simflag && (params->w_tstride || (params->v_tstride && !(model->p == 1 && model->d <= 15))))
-    return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes a time-invariant W, and a V_t stream only on the structured d <= 15, p = 1 path (drop DLM_OPT_FFBS_SIMSMOOTH otherwise)");
+  // On the structured d <= 15, p = 1 path a V_t stream is a scalar per step (the Student-t DLM, StudentTGibbs.scala:100-136) and a W_t
+  // stream (DlmFsvSystem.scala:137-208 feeds one W per step) a 13-pivot Cholesky factor per step; elsewhere they would need the
+  // factorisation of a p x p / 48 x 48 matrix per step: the reference-form sampler serves those callers
+  if (simflag && (params->w_tstride || params->v_tstride) && !(model->p == 1 && model->d <= 15))
+    return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes V_t / W_t streams only on the structured d <= 15, p = 1 path (drop DLM_OPT_FFBS_SIMSMOOTH otherwise)");
   st.in(&k.y, y, y ? N * T * p : 0);
   st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + p : d) : 0);
   if (forward && !norec) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
@@ -1162,7 +1163,7 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if (forward) {
     if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
     if ((rc = mark(e, 0))) return rc;
-    if (simflag && use_lane(k) && !k.v_tstride) {
+    if (simflag && use_lane(k) && !k.v_tstride && !k.w_tstride) {
       if ((rc = ensure_xplus(e, k))) return rc;
       e->variant = "lane-simsmooth";
       HIP_TRY(e, dlm::launch_lane_simsmooth(k, e->xplus, e->stream));
@@ -1180,8 +1181,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       if ((rc = mark(e, 2))) return rc;
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
-    if (simflag && k.v_tstride)
-      return fail(e, DLM_ERR_UNSUPPORTED, "a V_t stream with DLM_OPT_FFBS_SIMSMOOTH needs the structured d <= 15, p = 1 path (this G is dense)");
+    if (simflag && (k.v_tstride || k.w_tstride))
+      return fail(e, DLM_ERR_UNSUPPORTED, "a V_t / W_t stream with DLM_OPT_FFBS_SIMSMOOTH needs the structured d <= 15, p = 1 path (this G is dense)");
     if (simflag && use_tiled(k)) {
       if ((rc = ensure_xplus(e, k)) || (rc = ensure_ystar(e, k))) return rc;
       e->variant = dlm::wave48_simsmooth_supported(k) ? "wave-simsmooth" : "tiled-simsmooth";

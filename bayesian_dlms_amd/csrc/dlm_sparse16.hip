@@ -427,7 +427,7 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
     bool offd = false;
 #pragma unroll
     for (int r = 0; r < 4; ++r) offd |= (4 * r + g != c) && (w[r] != 0.0 || cc[r] != 0.0);
-    wdiag = (__ballot(offd) == 0ull);                       // W and C0 both diagonal: no factorisation
+    wdiag = (__ballot(offd) == 0ull) && !(IRR && a.w_tstride);   // W and C0 both diagonal: no factorisation (a W_t stream is factored at every step)
     const double z0 = (c < d) ? (zin ? zin[c] : philox_normal(a.seed, series, 0u, (unsigned)c)) : 0.0;
     if (wdiag) {
       wsd = vc ? sqrt(W[c * d + c]) : 0.0;
@@ -580,6 +580,12 @@ __device__ __forceinline__ void filter_body(const KArgs& a, const SparseT* __res
     if (SIM) {
       // x+_t = G x+_{t-1} + L_W z ;  y+_t = F^T x+_t + sqrt(V) z_v ;  y*_t = y_t - y+_t
       const double* zr = vZ + 16 * (t & 3);
+      if (IRR && a.w_tstride && dt != 0.0) {   // W_t of this step (DlmFsvSystem.scala:137-208): its Cholesky factor, 13 pivots in LDS
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) imgW[(4 * r + g) * LD + c] = w[r];
+        wave_chol(imgW, d, g, c);
+      }
       if (dt != 0.0) {
         double xg = vX[idx[0]] * val[0];
 #pragma unroll

@@ -576,16 +576,19 @@ def test_svd_ffbs_draws_and_stats(eng, literal):
 # FFBS by the Durbin-Koopman simulation smoother (DLM_OPT_FFBS_SIMSMOOTH)
 # ------------------------------------------------------------------------------------------
 def dk_reference_draw(mat, p, y, z):
-    """theta = E[x | y - y+] + x+ with (x+, y+) simulated from z [T+1][d+1]; smoothing by the oracle."""
+    """theta = E[x | y - y+] + x+ with (x+, y+) simulated from z [T+1][d+1]; smoothing by the oracle.  p.w / p.v may be [T] streams
+    (W_t drives the transition into record t, V_t observation t)."""
     d, T = mat.d, mat.T
     G = oracle.from_cm(mat.G[: d * d], d, d); F = mat.F[:d]
-    Lc, Lw = np.linalg.cholesky(p.c0), np.linalg.cholesky(p.w)
+    Lc = np.linalg.cholesky(p.c0)
+    Lws = [np.linalg.cholesky(w) for w in p.w] if p.w.ndim == 3 else [np.linalg.cholesky(p.w)] * T
+    svs = [np.sqrt(v[0, 0]) for v in p.v] if p.v.ndim == 3 else [np.sqrt(p.v[0, 0])] * T
     x = p.m0 + Lc @ z[0, :d]
     xs, yp = [x], np.empty((T, 1))
     for t in range(1, T + 1):
-        x = G @ x + Lw @ z[t, :d]
+        x = G @ x + Lws[t - 1] @ z[t, :d]
         xs.append(x)
-        yp[t - 1, 0] = F @ x + np.sqrt(p.v[0, 0]) * z[t, d]
+        yp[t - 1, 0] = F @ x + svs[t - 1] * z[t, d]
     om = omodel(mat)
     f = oracle.kf_filter(om, p.v, p.w, np.zeros(d), p.c0, y - yp)      # zero prior mean
     s = oracle.smoother(om, f, compat_q1=False)
@@ -621,6 +624,33 @@ def test_ffbs_simulation_smoother_matches_reference_construction(eng, dense_w):
     out3 = eng.ffbs(mat, p, y, seed=5, series_offset=2, flags=flags)
     zz = oracle.normals(5, 2 + 1, 91, 14)
     np.testing.assert_allclose(out3["theta"][1], dk_reference_draw(mat, p, y[1], zz), rtol=1e-7, atol=1e-8)
+
+
+def test_ffbs_simulation_smoother_with_variance_streams(eng):
+    """DlmFsvSystem.ffbs feeds one W per step (DlmFsvSystem.scala:137-208), StudentT.filter one V per step (StudentTGibbs.scala:100-136):
+    the simulation smoother on the structured d <= 15, p = 1 path takes both streams -- the Cholesky factor of W_t at every step of the
+    simulation, W_t / V_t in the filter of y - y+ -- against the same construction from the oracle's filter and smoother (injected normals);
+    elsewhere the streams are refused with a message."""
+    mod, mat, p0 = seasonal_model(T=70)
+    d, T = 13, 70
+    rng = np.random.default_rng(23)
+    Ws = np.empty((T, d, d)); Vs = np.empty((T, 1, 1))
+    for t in range(T):
+        A = rng.standard_normal((d, d)) * 0.3
+        Ws[t] = A @ A.T + np.diag(rng.uniform(0.05, 0.5, d))
+        Vs[t, 0, 0] = rng.uniform(0.5, 2.0)
+    N = 3
+    y = simulate(mat, p0, N, seed=62, missing=0.1)
+    z = rng.standard_normal((N, T + 1, d + 1))
+    for p in (DlmParameters(p0.v, Ws, p0.m0, p0.c0), DlmParameters(Vs, Ws, rng.standard_normal(d), np.eye(d) * 2.0)):
+        out = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
+        assert eng.last_variant == "sparse16-simsmooth" and np.all(out["status"] == 0)
+        for n in range(N):
+            np.testing.assert_allclose(out["theta"][n], dk_reference_draw(mat, p, y[n], z[n]), rtol=1e-7, atol=1e-8)
+    big, pb = _block_model(10, 12, 2)          # d = 20, p = 10: a W_t stream there is refused, not silently ignored
+    Wb = np.stack([pb.w] * 12)
+    with pytest.raises(Exception, match="streams only on the structured"):
+        eng.ffbs(big, DlmParameters(pb.v, Wb, pb.m0, pb.c0), np.zeros((2, 12, big.p)), flags=_lib.OPT_FFBS_SIMSMOOTH)
 
 
 def test_ffbs_simulation_smoother_distribution(eng):
@@ -1213,8 +1243,11 @@ def test_time_varying_variance_streams(eng, case):
         np.testing.assert_allclose(ll[n], oracle.loglik(omodel(mat), f, y[n]), rtol=1e-9, atol=1e-8)
         ref = oracle.backward_sample(omodel(mat), Ws, f, z[n], factor="chol")
         np.testing.assert_allclose(draws["theta"][n], ref["theta"], rtol=1e-6, atol=1e-7)
-    with pytest.raises(EngineError):
-        eng.ffbs(mat, p, y, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    if d <= 15 and q == 1 and expect == "sparse16":   # the simulation smoother takes the streams on the structured d <= 15, p = 1 path (round 4) ...
+        assert np.all(eng.ffbs(mat, p, y, flags=_lib.OPT_FFBS_SIMSMOOTH)["status"] == 0) and eng.last_variant == "sparse16-simsmooth"
+    else:                                             # ... and refuses them elsewhere (the reference-form sampler above serves those callers)
+        with pytest.raises(EngineError):
+            eng.ffbs(mat, p, y, flags=_lib.OPT_FFBS_SIMSMOOTH)
     if d <= 16 and q <= 16:   # the SVD entry points take the streams too (round 2): equal to the standard filter
         sv = eng.svd_filter(mat, p, y)
         assert np.all(sv["status"] == 0)
@@ -1554,7 +1587,7 @@ def test_lane_per_series_small_models(eng, kind):
 def test_simulation_smoother_with_scalar_variance_stream(eng):
     """The Student-t DLM's FFBS (StudentTGibbs.scala:100-136: V_t = V / lambda_t, p = 1) on the structured fast path with
     DLM_OPT_FFBS_SIMSMOOTH: the draw is the Durbin-Koopman construction with the per-step variances, statistics included;
-    W_t streams and V_t on other paths are refused."""
+    V_t on other paths is refused (W_t streams: test_ffbs_simulation_smoother_with_variance_streams)."""
     mod, mat, p = seasonal_model(T=60)
     d, T, N = 13, mat.T, 3
     rng = np.random.default_rng(808)
@@ -1579,9 +1612,11 @@ def test_simulation_smoother_with_scalar_variance_stream(eng):
         st = oracle.gibbs_stats(om, y[n], ref)
         np.testing.assert_allclose(out["stats"][n, 0], st["ssy"][0], rtol=1e-7)
         np.testing.assert_allclose(out["stats"][n, 2:2 + d], st["ss"], rtol=1e-7)
+    # a W_t stream goes through too since round 4 (test_ffbs_simulation_smoother_with_variance_streams): the same W at every step is the
+    # time-invariant call (the factor recomputed per step: the same numbers up to rounding)
     Wt = np.tile(p.w, (T, 1, 1))
-    with pytest.raises(EngineError):
-        eng.ffbs(mat, DlmParameters(p.v, Wt, p.m0, p.c0), y, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    same_w = eng.ffbs(mat, DlmParameters(Vt, Wt, p.m0, p.c0), y, z=z, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    np.testing.assert_allclose(same_w["theta"], out["theta"], rtol=1e-9, atol=1e-10)
 
 
 @pytest.mark.parametrize("shape", ["bivariate_local_level", "d6_p3_irregular", "d12_p4_harmonics"])
