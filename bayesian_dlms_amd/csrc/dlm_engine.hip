@@ -1142,8 +1142,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   // On the structured d <= 15, p = 1 path a V_t stream is a scalar per step (the Student-t DLM, StudentTGibbs.scala:100-136) and a W_t
   // stream (DlmFsvSystem.scala:137-208 feeds one W per step) a 13-pivot Cholesky factor per step; elsewhere they would need the
   // factorisation of a p x p / 48 x 48 matrix per step: the reference-form sampler serves those callers
-  if (simflag && (params->w_tstride || params->v_tstride) && !(model->p == 1 && model->d <= 15))
-    return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes V_t / W_t streams only on the structured d <= 15, p = 1 path (drop DLM_OPT_FFBS_SIMSMOOTH otherwise)");
+  if (simflag && params->v_tstride && !(model->p == 1 && model->d <= 15))
+    return fail(e, DLM_ERR_UNSUPPORTED, "the simulation smoother takes a V_t stream only on the structured d <= 15, p = 1 path (drop DLM_OPT_FFBS_SIMSMOOTH otherwise)");
   st.in(&k.y, y, y ? N * T * p : 0);
   st.in(&k.z, z, z ? N * (T + 1) * (simflag ? d + p : d) : 0);
   if (forward && !norec) st.out(&k.filt, filt_ws, N * (T + 1) * rec);
@@ -1181,9 +1181,14 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       if ((rc = mark(e, 2))) return rc;
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
-    if (simflag && (k.v_tstride || k.w_tstride))
-      return fail(e, DLM_ERR_UNSUPPORTED, "a V_t / W_t stream with DLM_OPT_FFBS_SIMSMOOTH needs the structured d <= 15, p = 1 path (this G is dense)");
+    if (simflag && (k.v_tstride || (k.w_tstride && !use_tiled(k))))
+      return fail(e, DLM_ERR_UNSUPPORTED, "a V_t / W_t stream with DLM_OPT_FFBS_SIMSMOOTH needs a structured G (this one is dense); V_t also p = 1");
     if (simflag && use_tiled(k)) {
+      if (k.w_tstride) {   // a W_t stream (DlmFsvSystem.ffbs): the per-wave kernels, whose simulation prologue factors W_t at every step -- at any batch size
+        k.flags |= DLM_OPT_FORCE_WAVE;
+        if (!dlm::wave48_simsmooth_supported(k))
+          return fail(e, DLM_ERR_UNSUPPORTED, "a W_t stream with DLM_OPT_FFBS_SIMSMOOTH needs a structured G (at most four nonzeros per row and column); the reference-form sampler takes any model");
+      }
       if ((rc = ensure_xplus(e, k)) || (rc = ensure_ystar(e, k))) return rc;
       e->variant = dlm::wave48_simsmooth_supported(k) ? "wave-simsmooth" : "tiled-simsmooth";
       HIP_TRY(e, dlm::launch_tiled_simsmooth(k, e->xplus, e->ystar, e->stream));

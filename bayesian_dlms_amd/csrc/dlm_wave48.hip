@@ -1846,6 +1846,13 @@ __global__ __launch_bounds__(64) void k_sim_prologue_w48(KArgs a, double* __rest
       gcur = gi;
     }
     if (KF == 0 && a.f_stride) { wave_sync(); load_f_lds<3, 2>(Fl, a.F + (size_t)t * a.f_stride, d, p, lane); }
+    if (a.w_tstride) {   // W_t of the transition into record t + 1 (DlmFsvSystem.scala:137-208 feeds one W per step): its factor, d pivots by one wave
+      wave_sync();
+      const double* Wt = W + (size_t)t * a.w_tstride;
+      for (int idx = lane; idx < d * d; idx += 64) { const int i = idx % d, j = idx / d; Lw[i * ldw + j] = Wt[idx]; }
+      wave_sync();
+      if (chol_rows(Lw, d, ldw, lane)) st |= DLM_ST_NOT_PD;
+    }
     for (int i = lane; i < d + p; i += 64)
       z[i] = zin ? zin[(size_t)(t + 1) * (d + p) + i] : philox_normal(a.seed, series, (unsigned)(t + 1), (unsigned)i);
     wave_sync();
@@ -2801,7 +2808,7 @@ hipError_t launch_wave48_filter(const KArgs& a, int K, double* innov, hipStream_
 // y* = y - y+ in `ystar`; the forward pass filters y* from a zero prior mean and overwrites y*_t by its innovation (it has
 // read y*_{t+1} by then); the mean-only backward pass adds x+.
 bool wave48_simsmooth_supported(const KArgs& a) {
-  return shape_ok(a) && a.spb && !a.v_tstride && !a.w_tstride && !a.cond && wave48_wanted(a);
+  return shape_ok(a) && a.spb && !a.v_tstride && !a.cond && wave48_wanted(a);   // (a W_t stream only enters the simulation: k_sim_prologue_w48 factors it per step; V_t would enter the backward gain)
 }
 
 template <int DT, int PT>

@@ -647,10 +647,27 @@ def test_ffbs_simulation_smoother_with_variance_streams(eng):
         assert eng.last_variant == "sparse16-simsmooth" and np.all(out["status"] == 0)
         for n in range(N):
             np.testing.assert_allclose(out["theta"][n], dk_reference_draw(mat, p, y[n], z[n]), rtol=1e-7, atol=1e-8)
-    big, pb = _block_model(10, 12, 2)          # d = 20, p = 10: a W_t stream there is refused, not silently ignored
-    Wb = np.stack([pb.w] * 12)
-    with pytest.raises(Exception, match="streams only on the structured"):
-        eng.ffbs(big, DlmParameters(pb.v, Wb, pb.m0, pb.c0), np.zeros((2, 12, big.p)), flags=_lib.OPT_FFBS_SIMSMOOTH)
+    # 16 <= d <= 48 and small multivariate models (the per-wave kernels): W_t streams at any batch size -- the factor of W_t per step in the
+    # simulation prologue; a V_t stream (it would enter the backward gain) and a dense G are refused with a message
+    for nblk, per, Tb in ((10, 2, 40), (20, 2, 30), (3, 2, 50)):
+        big, pb = _block_model(nblk, Tb, per, seed=5 + nblk)
+        db, qb = big.d, big.p
+        Wb = np.empty((Tb, db, db))
+        for t in range(Tb):
+            A = rng.standard_normal((db, db)) * 0.2
+            Wb[t] = A @ A.T + np.diag(rng.uniform(0.05, 0.4, db))
+        pw = DlmParameters(pb.v, Wb, pb.m0, pb.c0)
+        yb = rng.standard_normal((3, Tb, qb)).cumsum(axis=1)
+        yb[1, Tb // 2, 0] = np.nan
+        zb = rng.standard_normal((3, Tb + 1, db + qb))
+        ob = eng.ffbs(big, pw, yb, z=zb, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_FORCE_WAVE)     # (the module's "workgroup" run adds DLM_OPT_NO_WAVE otherwise)
+        assert eng.last_variant == "wave-simsmooth" and np.all(ob["status"] == 0)
+        for n in range(3):
+            np.testing.assert_allclose(ob["theta"][n], dk_reference_draw_mv(big, pw, yb[n], zb[n]), rtol=1e-6, atol=1e-7)
+    with pytest.raises(Exception, match="V_t stream only"):
+        eng.ffbs(big, DlmParameters(np.stack([pb.v] * Tb), pb.w, pb.m0, pb.c0), yb, flags=_lib.OPT_FFBS_SIMSMOOTH)
+    with pytest.raises(Exception, match="structured G"):      # the workgroup-per-series kernels factor W once
+        eng.ffbs(big, pw, yb, flags=_lib.OPT_FFBS_SIMSMOOTH | _lib.OPT_NO_WAVE)
 
 
 def test_ffbs_simulation_smoother_distribution(eng):
@@ -922,11 +939,12 @@ def dk_reference_draw_mv(mat, p, y, z):
     """Multivariate version of dk_reference_draw: z [T+1][d+p] (state noise, then observation noise)."""
     d, q, T = mat.d, mat.p, mat.T
     G = oracle.from_cm(mat.G[: d * d], d, d); F = oracle.from_cm(mat.F[: d * q], d, q)
-    Lc, Lw, Lv = np.linalg.cholesky(p.c0), np.linalg.cholesky(p.w), np.linalg.cholesky(p.v)
+    Lc, Lv = np.linalg.cholesky(p.c0), np.linalg.cholesky(p.v)
+    Lws = [np.linalg.cholesky(w) for w in p.w] if p.w.ndim == 3 else [np.linalg.cholesky(p.w)] * T     # (a W_t stream: W_t drives the transition into record t)
     x = p.m0 + Lc @ z[0, :d]
     xs, yp = [x], np.empty((T, q))
     for t in range(1, T + 1):
-        x = G @ x + Lw @ z[t, :d]
+        x = G @ x + Lws[t - 1] @ z[t, :d]
         xs.append(x)
         yp[t - 1] = F.T @ x + Lv @ z[t, d:]
     om = omodel(mat)
