@@ -1137,6 +1137,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   Stager st(e, opts->mem == DLM_MEM_HOST);
   stage_model(st, k, model, params, opts);
   const bool simflag = forward && (opts->flags & DLM_OPT_FFBS_SIMSMOOTH) && !cond;
+  const bool eig = (opts->flags & DLM_OPT_DRAW_EIG) != 0;   // the reference's eigen-factor for the draw: the general kernel's backward pass (any forward kernel)
+  if (eig && simflag) return fail(e, DLM_ERR_ARG, "DLM_OPT_DRAW_EIG selects the factor of the reference-form backward sampler; the simulation smoother (DLM_OPT_FFBS_SIMSMOOTH) factors nothing per step");
   bool shared_factors = false, shared_big = false;
   dlm::SampTabs stb{};
   // On the structured d <= 15, p = 1 path a V_t stream is a scalar per step (the Student-t DLM, StudentTGibbs.scala:100-136) and a W_t
@@ -1196,8 +1198,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       return st.finish(opts->flags & DLM_OPT_ASYNC);
     }
     if (simflag && z) return fail(e, DLM_ERR_UNSUPPORTED, "injected normals with DLM_OPT_FFBS_SIMSMOOTH need a fast path (structured d <= 15 or 16 <= d <= 48)");
-    shared_factors = !simflag && !use_lane(k) && fast_shape_ok(k) && e->sparse_k > 0 && dlm::sampler_shared_eligible(k);
-    shared_big = !simflag && !shared_factors && use_tiled(k) && dlm::wave48_sampler_shared_eligible(k);   // 16 <= d <= 48 on the per-wave kernels
+    shared_factors = !simflag && !eig && !use_lane(k) && fast_shape_ok(k) && e->sparse_k > 0 && dlm::sampler_shared_eligible(k);
+    shared_big = !simflag && !eig && !shared_factors && use_tiled(k) && dlm::wave48_sampler_shared_eligible(k);   // 16 <= d <= 48 on the per-wave kernels
     if (norec && shared_factors) {
       // No records AND shared factors (d <= 15): nothing of the filtered covariances is needed per series -- the draw kernel reads the
       // means, the table is made from the covariance recursion alone.  So the forward pass is section 4.9's: one wave's covariance
@@ -1242,6 +1244,13 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
   if (!forward && ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST)) || (rc = mark(e, 0)))) return rc;   // the structure tables of G
   if ((rc = mark(e, 1))) return rc;
   auto done = [&]() { const int r = mark(e, 2); return r ? r : st.finish(opts->flags & DLM_OPT_ASYNC); };
+  if (eig) {
+    if (dlm::generic_sampler_lds_bytes(k.d, k.p) > 160 * 1024)
+      return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_DRAW_EIG runs on the general backward sampler kernel: d <= 53");
+    e->variant = "generic-eig";
+    HIP_TRY(e, dlm::launch_generic_sampler(k, e->stream));
+    return done();
+  }
   if (use_lane(k)) {
     e->variant = "lane-sampler";
     HIP_TRY(e, dlm::launch_lane_sampler(k, e->stream));

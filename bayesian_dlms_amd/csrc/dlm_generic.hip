@@ -65,6 +65,61 @@ __device__ bool chol_lds(int lane, int n, double* A, bool psd = false) {
   return bad;
 }
 
+// Symmetric eigendecomposition by cyclic Jacobi on one wave -- the factor the REFERENCE draws with (MultivariateGaussianSvd.scala:13-22:
+// eigSym(cov), draw = mu + E sqrt(Lambda) z), in the oracle's restatement of it (oracle/dlm_oracle.c: eig_sym -- the same pair order,
+// rotation formulas and stopping rule; Breeze's eigSym is LAPACK dsyevd, whose eigenvector signs are implementation-defined: both
+// sides make the largest-|.| entry of each column positive).  S (n x n, column-major, symmetric) is destroyed and receives the
+// eigenvectors, columns in ascending order of the eigenvalues `lam`; E: n x n scratch; tmp: n doubles of scratch.
+__device__ void eig_lds(int lane, int n, double* S, double* E, double* lam, double* tmp) {
+  for (int i = lane; i < n * n; i += 64) E[i] = (i % n == i / n) ? 1.0 : 0.0;
+  wsync();
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    for (int i = lane; i < n * n; i += 64) { const double v = S[i] * S[i]; if (i % n == i / n) dia += v; else off += v; }
+    for (int o_ = 32; o_ > 0; o_ >>= 1) { off += __shfl_xor(off, o_); dia += __shfl_xor(dia, o_); }
+    if (off <= 1e-60 + 1e-32 * dia) break;                       // (wave-uniform: every lane holds the same sums)
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = S[CM(p, q, n)];
+        if (apq == 0.0) continue;
+        const double app = S[CM(p, p, n)], aqq = S[CM(q, q, n)];
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+        wsync();                                                   // every lane has read the pivot entries
+        for (int k = lane; k < n; k += 64) {                       // columns p, q
+          const double skp = S[CM(k, p, n)], skq = S[CM(k, q, n)];
+          S[CM(k, p, n)] = c * skp - s * skq;
+          S[CM(k, q, n)] = s * skp + c * skq;
+          const double ekp = E[CM(k, p, n)], ekq = E[CM(k, q, n)];
+          E[CM(k, p, n)] = c * ekp - s * ekq;
+          E[CM(k, q, n)] = s * ekp + c * ekq;
+        }
+        wsync();
+        for (int k = lane; k < n; k += 64) {                       // rows p, q
+          const double spk = S[CM(p, k, n)], sqk = S[CM(q, k, n)];
+          S[CM(p, k, n)] = c * spk - s * sqk;
+          S[CM(q, k, n)] = s * spk + c * sqk;
+        }
+        wsync();
+      }
+  }
+  wsync();
+  for (int j = lane; j < n; j += 64) tmp[j] = S[CM(j, j, n)];
+  wsync();
+  for (int j = lane; j < n; j += 64) {                             // ascending order (ties by index), canonical sign, into S
+    const double lj = tmp[j];
+    int rank = 0;
+    for (int k = 0; k < n; ++k) rank += (tmp[k] < lj) || (tmp[k] == lj && k < j);
+    int arg = 0; double best = -1.0;
+    for (int i = 0; i < n; ++i) { const double v = fabs(E[CM(i, j, n)]); if (v > best * (1.0 + 1e-12)) { best = v; arg = i; } }
+    const double sg = E[CM(arg, j, n)] < 0.0 ? -1.0 : 1.0;
+    lam[rank] = lj;
+    for (int i = 0; i < n; ++i) S[CM(i, rank, n)] = sg * E[CM(i, j, n)];
+  }
+  wsync();
+}
+
 // Solve (L L^T) X = B in place for the n x nrhs LDS matrix B; one lane per right-hand side.
 __device__ void chol_solve_lds(int lane, int n, int nrhs, const double* L, double* B) {
   for (int c = lane; c < nrhs; c += 64) {
@@ -342,6 +397,7 @@ __global__ __launch_bounds__(64) void k_sampler_generic(KArgs a) {
   double* thout = a.theta ? a.theta + (size_t)n * (T + 1) * d : nullptr;
   double* cond = a.cond ? a.cond + (size_t)n * (T + 1) * rec : nullptr;
   const bool outer = (a.flags & DLM_OPT_STATS_OUTER) != 0;
+  const bool eig = (a.flags & DLM_OPT_DRAW_EIG) != 0;
   const unsigned long long series = a.series_offset + (unsigned long long)n;
   int st = 0;
 
@@ -363,11 +419,21 @@ __global__ __launch_bounds__(64) void k_sampler_generic(KArgs a) {
       for (int i = lane; i < dd; i += 64) c[d + i] = H[i];
     }
     wsync();
+    if (eig) {   // the reference's factor: theta = m + E sqrt(Lambda) z (a rounding-level negative eigenvalue counts as zero and is flagged: the reference would draw NaN)
+      eig_lds(lane, d, H, D, a1, u);
+      for (int i = lane; i < d; i += 64) {
+        double acc = h[i];
+        for (int k = 0; k < d; ++k) { const double lk = a1[k]; acc = fma(H[CM(i, k, d)] * sqrt(lk > 0.0 ? lk : 0.0), zv[k], acc); }
+        th[i] = acc;
+      }
+      if (a1[0] < 0.0) st |= DLM_ST_NOT_PD;
+    } else {
     if (chol_lds(lane, d, H, true)) st |= DLM_ST_NOT_PD;
     for (int i = lane; i < d; i += 64) {
       double acc = h[i];
       for (int k = 0; k <= i; ++k) acc = fma(H[CM(i, k, d)], zv[k], acc);
       th[i] = acc;
+    }
     }
     wsync();
     if (thout) for (int i = lane; i < d; i += 64) thout[(size_t)T * d + i] = th[i];
@@ -436,12 +502,25 @@ __global__ __launch_bounds__(64) void k_sampler_generic(KArgs a) {
       for (int i = lane; i < d; i += 64) c[i] = h[i];
       for (int i = lane; i < dd; i += 64) c[d + i] = T2[i];
     }
+    if (eig) {
+      wsync();
+      eig_lds(lane, d, T2, D, a1, u);                            // (D, a1 and u are free here)
+      if (a1[0] < 0.0) st |= DLM_ST_NOT_PD;
+      for (int i = lane; i < d; i += 64) {
+        double acc = h[i];
+        for (int k = 0; k < d; ++k) { const double lk = a1[k]; acc = fma(T2[CM(i, k, d)] * sqrt(lk > 0.0 ? lk : 0.0), zv[k], acc); }
+        R[i] = acc;                                              // (R's d x d block is spent: theta_t parks there while u is scratch)
+      }
+      wsync();
+      for (int i = lane; i < d; i += 64) u[i] = R[i];
+    } else {
     if (chol_lds(lane, d, T2, true)) st |= DLM_ST_NOT_PD;
     // theta_t = h + L z ; system-innovation statistic of (theta_t, theta_{t+1})
     for (int i = lane; i < d; i += 64) {
       double acc = h[i];
       for (int k = 0; k <= i; ++k) acc = fma(T2[CM(i, k, d)], zv[k], acc);
       u[i] = acc;  // theta_t
+    }
     }
     wsync();
     if (a.stats) {

@@ -80,6 +80,10 @@ enum {
   DLM_OPT_SAMPLER_PER_SERIES = 1u << 26, /* dlm_ffbs_batch, reference-form sampler: every series computes its own J_t, H_t and factors, also when the batch
                                            shares V, W, C0 on a regular grid (by default one wave computes them once per call and the series draw against
                                            its table: the same draws, bit for bit) */
+  DLM_OPT_DRAW_EIG = 1u << 27,          /* dlm_ffbs_batch / dlm_backward_sample_batch, reference-form sampler: draw with the REFERENCE's factor, theta = h + E sqrt(Lambda) z from
+                                           the symmetric eigendecomposition of H (MultivariateGaussianSvd.scala:13-22; eigenvalues ascending, the largest-|.| entry of each
+                                           eigenvector positive -- LAPACK leaves the sign open), instead of the engine's lower Cholesky factor.  The same distribution,
+                                           other draws; served by the general LDS kernel (d <= 53): for parity with the literal operation sequence, not for speed */
   DLM_OPT_TEST_FAIL_AFTER_TABLES = 1u << 30, /* TEST HOOK (tests/test_shared_sampler_gpu.py): dlm_ffbs_batch returns DLM_ERR_UNSUPPORTED right after it has started the
                                            shared-factor tables and normals on the engine's auxiliary streams -- the error path that must leave the engine usable */
   DLM_OPT_SHARED_COV = 1u << 24         /* d <= 15, p = 1, regular grid, V, W, C0 shared by the batch: ONE wave runs the covariance recursions, every series

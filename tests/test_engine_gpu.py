@@ -379,6 +379,53 @@ def test_ffbs_moments_draws_and_stats(eng):
     np.testing.assert_allclose(pooled, out2["stats"].sum(axis=0), rtol=1e-12)
 
 
+@pytest.mark.parametrize("shape", ["seasonal_d13", "blocks_d20_p10", "local_level", "dense_d9_p2"])
+def test_ffbs_with_the_references_eigen_factor(eng, shape):
+    """DLM_OPT_DRAW_EIG: the draw factor of the reference itself -- MultivariateGaussianSvd (MultivariateGaussianSvd.scala:13-22):
+    eigSym(H), theta = h + E sqrt(Lambda) z -- on the device (the general kernel's backward pass; eigenvalues ascending, the sign LAPACK
+    leaves open fixed as in the oracle).  Against the oracle's factor = "eig" branch under injected normals: draws, conditional moments
+    and statistics (1e-7); the draws differ from the Cholesky-factor draws of the same normals, the conditional moments do not."""
+    rng = np.random.default_rng({"seasonal_d13": 1, "blocks_d20_p10": 2, "local_level": 3, "dense_d9_p2": 4}[shape])
+    if shape == "seasonal_d13":
+        mod, mat, p = seasonal_model(T=40)
+        A = rng.standard_normal((13, 13))
+        p = DlmParameters(p.v, A @ A.T / 13 + p.w, rng.standard_normal(13), np.diag(np.linspace(0.5, 2.0, 13)))
+    elif shape == "blocks_d20_p10":
+        mat, p = _block_model(10, 25, 2, seed=3)
+    elif shape == "local_level":
+        mat = materialise(Dlm.polynomial(1), np.arange(1, 31, dtype=np.float64))
+        p = DlmParameters([[2.0]], [[3.0]], [0.0], [[10.0]])
+    else:
+        A = rng.standard_normal((9, 9)); G1 = 0.9 * A / np.abs(np.linalg.eigvals(A)).max()
+        F = rng.standard_normal((9, 2))
+        mat = materialise(Dlm(lambda t: F, lambda dt: G1), np.arange(1, 31, dtype=np.float64))
+        A2 = rng.standard_normal((9, 9))
+        p = DlmParameters(np.eye(2) * 0.8, A2 @ A2.T / 9 + 0.2 * np.eye(9), np.zeros(9), np.eye(9) + 0.1 * A2 @ A2.T)
+    d, q, T = mat.d, mat.p, mat.T
+    N = 3
+    y = rng.standard_normal((N, T, q)).cumsum(axis=1)
+    y[1, T // 3, 0] = np.nan
+    z = rng.standard_normal((N, T + 1, d))
+    out = eng.ffbs(mat, p, y, z=z, flags=_lib.OPT_DRAW_EIG, want_cond=True)
+    assert eng.last_variant == "generic-eig" and np.all(out["status"] == 0)
+    chol = eng.ffbs(mat, p, y, z=z, want_cond=True)
+    om = omodel(mat)
+    for n in range(N):
+        f = oracle.kf_filter(om, p.v, p.w, p.m0, p.c0, y[n])
+        o = oracle.backward_sample(om, p.w, f, z[n], factor="eig")
+        np.testing.assert_allclose(out["theta"][n], o["theta"], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(out["cond"][n][:, :d], o["h"], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(out["cond"][n][:, d:], o["H"], rtol=1e-7, atol=1e-8)
+        st = oracle.gibbs_stats(om, y[n], o["theta"])
+        np.testing.assert_allclose(out["stats"][n, :q], st["ssy"], rtol=1e-6)
+        np.testing.assert_allclose(out["stats"][n, 2 * q:2 * q + d], st["ss"], rtol=1e-6)
+    if d > 1:
+        assert np.abs(out["theta"] - chol["theta"]).max() > 1e-3          # another factor, other draws ...
+    np.testing.assert_allclose(out["cond"][:, T], chol["cond"][:, T], rtol=1e-9, atol=1e-10)   # ... of the same conditional law (record T: m_T, C_T)
+    with pytest.raises(EngineError):
+        eng.ffbs(mat, p, y, flags=_lib.OPT_DRAW_EIG | _lib.OPT_FFBS_SIMSMOOTH)
+
+
 def test_ffbs_distribution_matches_rts(eng):
     """(iii) many draws of one series: sample mean/cov of theta_t match the RTS smoother."""
     mod = Dlm.polynomial(2)
