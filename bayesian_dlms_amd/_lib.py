@@ -32,6 +32,7 @@ OPT_SHARED_COV = 1 << 24
 OPT_SVD_PER_SERIES = 1 << 25
 OPT_SAMPLER_PER_SERIES = 1 << 26
 OPT_DRAW_EIG = 1 << 27
+OPT_SMOOTHER_PER_SERIES = 1 << 28
 OPT_TEST_FAIL_AFTER_TABLES = 1 << 30
 ST_NONFINITE, ST_NOT_PD, ST_NOCONV = 1, 2, 4
 COMM_ID_BYTES = 128

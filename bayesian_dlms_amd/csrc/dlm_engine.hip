@@ -558,6 +558,38 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   }
   return DLM_OK;
 }
+// Shared factors of the RTS smoother (literal Q1; dlm_sampler16.hip): the tables are made on the second stream -- a filter and a smoother
+// run of ONE wave on a series of zeros -- while the batch is filtered on the first.  The workspace is the backward sampler's (e->sampws).
+int start_rts_tables(dlm_engine* e, const KArgs& k, dlm::RtsTabs& tb) {
+  const size_t need = dlm::rts_shared_ws_bytes(k);
+  if (need > e->sampws_bytes) {
+    if (e->sampws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->sampws)); e->sampws = nullptr; e->sampws_bytes = 0; }
+    HIP_TRY(e, hipMalloc(&e->sampws, need));
+    e->sampws_bytes = need;
+  }
+  const size_t cneed = sizeof(double) * dlm::covtabs_doubles(k.d, k.T);   // the forward covariance table of the shared-covariance kernels
+  if (cneed > e->covws_bytes) {
+    if (e->covws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->covws)); e->covws = nullptr; e->covws_bytes = 0; }
+    HIP_TRY(e, hipMalloc((void**)&e->covws, cneed));
+    e->covws_bytes = cneed;
+  }
+  int rc = ensure_route(e, (size_t)k.N);
+  if (rc || (rc = ensure_cov_stream(e))) return rc;
+  dlm::rts_shared_carve(e->sampws, k, tb);
+  dlm::CovTabs ctb{};
+  dlm::covtabs_carve(e->covws, k.d, k.T, ctb);
+  HIP_TRY(e, dlm::launch_rts_shared_cov(k, e->sparse_k, e->sp_dev, tb, ctb, e->stream));   // the forward covariances: in front of the batch's forward pass
+  HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));
+  e->cov_busy = true;                                                 // (from here on every exit path joins the stream: AuxScope)
+  HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
+  HIP_TRY(e, dlm::launch_rts_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));   // J_t, S_t: beside it
+  // The table run keeps a whole CU to itself (whole_cu_lds): it has to be resident before the forward pass fills every CU with its
+  // workgroups, or it waits for that kernel's last wave.  The gap marks of the call -- a 40 us kernel the backward pass needs anyway -- go
+  // in between on the engine's stream.
+  HIP_TRY(e, dlm::launch_rts_shared_mark(k, e->route, e->stream));
+  HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
+  return DLM_OK;
+}
 int ensure_shared(dlm_engine* e, const KArgs& k, dlm::CovTabs& tb, bool with_backward) {
   const size_t need = sizeof(double) * dlm::covtabs_doubles(k.d, k.T);
   if (need > e->covws_bytes) {
@@ -1113,10 +1145,21 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
     if ((rc = mark(e, 2))) return rc;
     return st.finish(opts->flags & DLM_OPT_ASYNC);
   }
+  // literal Q1 on the structured d <= 15 path: J_t, S_t once per call where the batch shares V, W, C0 (k_mean_rts16)
+  const bool rts_shared = (k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1) && !fused_fast && fast_shape_ok(k) && e->sparse_k > 0 && !use_lane(k) &&
+                          !(k.packed & 1) && dlm::rts_shared_eligible(k);
+  dlm::RtsTabs rtb{};
+  if (rts_shared && (rc = start_rts_tables(e, k, rtb))) return rc;
   if ((rc = run_filter(e, k, fused_fast))) return rc;
   if ((rc = mark(e, 1))) return rc;
   k.filt_in = k.filt;
-  if ((rc = run_smoother(e, k, fused_fast))) return rc;
+  if (rts_shared) {
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));   // the tables
+    e->cov_busy = false;
+    k.route = e->route; k.route_take = 0;
+    e->variant = "sparse16-rts";
+    HIP_TRY(e, dlm::launch_rts_shared_means(k, e->sparse_k, e->sp_dev, rtb, e->stream));
+  } else if ((rc = run_smoother(e, k, fused_fast))) return rc;
   if ((rc = mark(e, 2))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);
 }

@@ -187,6 +187,10 @@ constexpr int SF_ENT = 34;                 // 272 bytes per component: sixteen l
 constexpr int SF_ROW = 16 * SF_ENT;
 constexpr int SF_SLOT = 4096;              // LDS bytes of a ring slot (15 * 272 = 4080 at most travel)
 constexpr int SF_AHEAD = 8;                // the filtered means are requested this many steps ahead
+// shared factors of the RTS smoother (k_smoother_rts16<EXP>, k_mean_rts16): a row of RtsTabs::jrows
+constexpr int RJ_ENT = 18;                 // 144 bytes per component: sixteen lanes' 16-byte LDS reads fall into distinct banks
+constexpr int RJ_ROW = 16 * RJ_ENT;
+constexpr int RS_SLOT = 1936;              // LDS bytes of a record slot: a record of d = 15 is 1920 bytes, + 16
 // Stretches: steps t at the top of one start from scratch (k_sampler_sp16, every series).  32 steps long -- and 16 below step SF_SHORT_END, where
 // the filtered covariance of a typical model is still moving and every step of a stretch is computed in full: the longest stretch is what the
 // draw kernel of a shared-factor call waits for (C3: the table 1.24 -> 0.7 ms, no longer behind the forward mean kernel).
@@ -806,8 +810,12 @@ __global__ __launch_bounds__(256) void k_mark_gaps(const double* __restrict__ y,
 // with J = mm(G C, Rinv).  Rinv is the warm-started Newton-Schulz inverse of the sampler above; once the filtered
 // covariance has stopped moving, J and R+ are those of the step before and a step is two products.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K, class Tab>
-__global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __restrict__ sp) {
+// EXP (shared factors, below): the series is the one series of zeros; the J_t^T of every full step goes to RtsTabs::jrows, the smoothed
+// records -- a.smooth = RtsTabs::srec -- are the S_t table.
+template <int K, class Tab, bool EXP = false>
+__global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __restrict__ sp, RtsTabs tb) {
+  if (!EXP && a.route && (a.route[blockIdx.x] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
+  if constexpr (EXP) __builtin_amdgcn_s_setprio(3);   // the table's one wave runs beside the kernel that filters the batch and is what the mean kernel waits for
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 4 * 16];
   double* img = lds;       double* inv = lds + IMG;
   double* mv = inv + IMG;  double* sv = mv + 16;   double* uv = sv + 16;
@@ -837,18 +845,20 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
     Wt[r] = va[r] ? W0[i + c * d] : 0.0;
   }
   const int offM = (vc && g == 0) ? c * 8 : OOB;
-  const __amdgpu_buffer_rsrc_t rin = mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
+  const int rstr = (EXP && tb.crec) ? tb.crec_stride : recb;   // bytes between the input records (the table run may read the rows of a covariance table)
+  const __amdgpu_buffer_rsrc_t rin = (EXP && tb.crec) ? mk_rsrc(tb.crec, (size_t)(T + 1) * rstr) : mk_rsrc(a.filt_in + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
   const __amdgpu_buffer_rsrc_t rout = mk_rsrc(a.smooth + (size_t)n * (T + 1) * rec, (size_t)(T + 1) * recb);
   int st = 0;
   d4 S, Rinv = {0.0, 0.0, 0.0, 0.0};
   bool warm = false;
   {   // init = last filter state (Smoothing.scala:59-61)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { S[r] = bld(rin, offC[r], T * recb); bst(rout, offC[r], T * recb, S[r]); }
-    const double mc = bld(rin, vc ? c * 8 : OOB, T * recb);
+    for (int r = 0; r < 4; ++r) { S[r] = bld(rin, offC[r], T * rstr); bst(rout, offC[r], T * recb, S[r]); }
+    const double mc = bld(rin, vc ? c * 8 : OOB, T * rstr);
     bst(rout, offM, T * recb, mc);
     if (g == 0) sv[c] = mc;
     wave_sync();
+    if constexpr (EXP) { if (lane == 0) tb.need[T] = 0; }
   }
   d4 Cp = {0.0, 0.0, 0.0, 0.0}, JTs = Cp, Js = Cp, Rs = Cp;   // steady-state reuse (see k_sampler_sp16)
   bool have = false;
@@ -859,8 +869,8 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
   {
     const int tp = T > 0 ? T - 1 : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
-    nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
+    for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * rstr);
+    nm = bld(rin, vc ? c * 8 : OOB, tp * rstr);
   }
   double scol = 0.0;
   for (int t = T - 1; t >= 0; --t) {
@@ -872,8 +882,8 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
     {
       const int tp = t > 0 ? t - 1 : 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * recb);
-      nm = bld(rin, vc ? c * 8 : OOB, tp * recb);
+      for (int r = 0; r < 4; ++r) nC[r] = bld(rin, offC[r], tp * rstr);
+      nm = bld(rin, vc ? c * 8 : OOB, tp * rstr);
     }
     if (a.w_tstride) {
 #pragma unroll
@@ -898,6 +908,7 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
         a1 = s_;
       }
       JT = JTs; J = Js; R = Rs;
+      if constexpr (EXP) { if (lane == 0) tb.need[t] = 0; }
     } else {
       to_img(C, img, g, c);
       wave_sync();
@@ -963,6 +974,14 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
       }
       JT = mm(Rinv, GC, d);                             // J^T = R+^-1 G C
       J = mm(GC, Rinv, d);                              // J   = C G^T R+^-1
+      if constexpr (EXP) {                              // column c of J^T, as k_mean_rts16's lane c takes it
+        double* row = tb.jrows + (size_t)t * RJ_ROW + c * RJ_ENT;
+        if (vc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) row[4 * r + g] = JT[r];
+        }
+        if (lane == 0) tb.need[t] = 1;
+      }
       Cp = C; JTs = JT; Js = J; Rs = R; have = true; gprev = gi; dtprev = dt;
       {
         double mx = fmax(fmax(fabs(C[0]), fabs(C[1])), fmax(fabs(C[2]), fabs(C[3])));
@@ -990,6 +1009,189 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
   for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(S[r]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
+  if (!EXP && a.route && a.counters && lane == 0) atomicAdd(&a.counters[3], 1ull);   // a series of a shared-factor call that computed its own
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shared factors of the RTS smoother.  J_t and S_t (Smoothing.scala:38-47) depend on V, W, C0 and the time grid, not on the data:
+// where the batch shares them and a series has no missing observation, k_smoother_rts16 above computes the same J_t, S_t -- d^3
+// work and a chain of eight matrix products per step -- in every series.  Here it runs ONCE, with EXP set, on the filter records of
+// a series of zeros (made beside the batch's forward pass), and every series runs k_mean_rts16: four series per wave (lane 16 j + c =
+// component c of series j), per step
+//     a+ = G m_t,   s_t = m_t + J_t (s_{t+1} - a+),   record t = [ s_t | S_t of the table ]
+// in the operations of k_smoother_rts16, one for one (the gather of G in table order, matTvec's four chains and their (0 + 1) +
+// (2 + 3) sum): the records are bit for bit those of the per-series kernel.  Column c of J^T lives in registers and is replaced
+// where the table has a row for the step (RtsTabs::need: a full step of the table run; the others reuse J as the per-series kernel
+// does); J rows and S_t records travel two steps ahead by LDS DMA from L2, the four series' filtered means SF_AHEAD steps ahead
+// from the heads of their filter records; a record leaves as 16-byte pieces: the table's S_t with s_t patched into the first d doubles.
+//   row t of RtsTabs::jrows (RJ_ROW doubles): per component c < d  [ J_t^T[0..15][c] | 2 pad ]
+// NP: store instructions per step (64-lane groups of 16-byte pieces covering four records, rounded up to 2, 4, 6, 8);
+// NRS / NRJ: DMA instructions per S_t record / per J row -- exact, the waits below count them.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bst128(__amdgpu_buffer_rsrc_t r, int voff, int soff, d2 x) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = {(unsigned)__double2loint(x[0]), (unsigned)__double2hiint(x[0]), (unsigned)__double2loint(x[1]), (unsigned)__double2hiint(x[1])};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ d2 lds_read128v(unsigned addr) {
+  d2 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int NP>
+__device__ __forceinline__ void lds_wait_np(d2 (&pc)[NP]) {
+  static_assert(NP == 2 || NP == 4 || NP == 6 || NP == 8, "pieces");
+  if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1])::"memory");
+  else if constexpr (NP == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3])::"memory");
+  else if constexpr (NP == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]), "+v"(pc[4]), "+v"(pc[5])::"memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]), "+v"(pc[4]), "+v"(pc[5]), "+v"(pc[6]), "+v"(pc[7])::"memory");
+}
+
+template <int K, int NP, int NRS, int NRJ>
+__global__ __launch_bounds__(64, 3) void k_mean_rts16(KArgs a, const SparseT* __restrict__ sp, RtsTabs tb) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * 64 + 2 * (RS_SLOT / 8) + 2 * RJ_ROW + SF_AHEAD * 64];
+  const int lane = threadIdx.x, j = lane >> 4, c = lane & 15;
+  const int n0 = 4 * blockIdx.x;
+  if (n0 >= a.N) return;
+  const int nser = a.N - n0 < 4 ? a.N - n0 : 4;
+  const bool have = j < nser;
+  const int n = have ? n0 + j : n0;                 // (a row without a series shadows the first: loads stay in bounds, nothing is stored)
+  const bool dead = !have || a.route[n] != 0;       // a series with a missing observation: k_smoother_rts16 serves it
+  unsigned deadmask = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) deadmask |= (__builtin_amdgcn_readlane((int)dead, 16 * q) & 1) << q;
+  if (deadmask == 0xfu) return;
+  double* vU = lds;            // s_{t+1} - a+   [4][16]
+  double* vH = vU + 64;        // the first 16 doubles of each series' smoothed record
+  char* ring = (char*)(vH + 64);                    // two S_t slots, two J slots, then the slots of the means
+  const int d = a.d, T = a.T, rec = d + d * d, recb = rec * 8;
+  const bool vc = c < d;
+  int idx[K];
+  double val[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) { idx[s] = (16 * j + sp[0].idx[c][s]) * 8; val[s] = vc ? sp[0].val[c][s] : 0.0; }
+  const size_t sbytes = (size_t)(T + 1) * recb;
+  const i4 rmean = rsrc_words((const char*)a.filt_in + (size_t)n0 * sbytes, (unsigned)((size_t)nser * sbytes));
+  const i4 rjt = rsrc_words(tb.jrows, (unsigned)((size_t)(T + 1) * RJ_ROW * 8));
+  const i4 rst = rsrc_words(tb.srec, (unsigned)sbytes);
+  const __amdgpu_buffer_rsrc_t rout = mk_rsrc((char*)a.smooth + (size_t)n0 * sbytes, (size_t)nser * sbytes);
+  const int mvoff = (lane < 32 && (lane >> 3) < nser) ? (int)((size_t)(lane >> 3) * sbytes) + (lane & 7) * 16 : OOB;   // 16 doubles from the head of each record
+  const unsigned sring_lds = lds_addr_of(ring), jring_lds = sring_lds + 2 * RS_SLOT, mring_lds = jring_lds + 2 * (RJ_ROW * 8);
+  const unsigned vH_lds = lds_addr_of(vH);
+  const int npc = rec / 2;                           // 16-byte pieces of a record
+  const int nj16 = d * (RJ_ENT / 2);                 // ... of a J row that travel
+  auto dma_means = [&](unsigned lds_addr, int soff) {
+    lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    if (lane < 32)   // 4 x 8 pieces; the other lanes' LDS destinations lie beyond the slot
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(mvoff), "s"(rmean), "s"(soff) : "memory");
+  };
+  unsigned psrc[NP];
+  int pdst[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int q = 64 * k + lane, sj = q / npc, pp = q - sj * npc;
+    pdst[k] = (sj < nser && !((deadmask >> (sj & 3)) & 1u)) ? (int)((size_t)sj * sbytes) + pp * 16 : OOB;
+    psrc[k] = pp < 8 ? (0x80000000u | (unsigned)((16 * (sj & 3) + 2 * pp) * 8)) : (unsigned)(pp * 16);
+  }
+  const unsigned ptd = (unsigned)(c * 8);            // double c of the S_t record: what the head of a record holds beyond the mean
+  const unsigned char* need = tb.need;
+
+  double Jc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Jc[k] = 0.0;
+  auto read_J = [&](unsigned slot) {
+    const unsigned base = slot + (vc ? c : 0) * (RJ_ENT * 8);
+    d2 q[8];
+    q[0] = lds_read128<0>(base); q[1] = lds_read128<16>(base); q[2] = lds_read128<32>(base); q[3] = lds_read128<48>(base);
+    q[4] = lds_read128<64>(base); q[5] = lds_read128<80>(base); q[6] = lds_read128<96>(base); q[7] = lds_read128<112>(base);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])::"memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { Jc[2 * k] = q[k][0]; Jc[2 * k + 1] = q[k][1]; }   // (a lane beyond d holds component 0's: finite, and what it computes is never used)
+  };
+  // the record of step t: the head from vH, the rest from the S_t slot; then the slots of step t are free for step t - 2
+  auto emit = [&](int t, unsigned sslot, unsigned jslot, unsigned mslot, bool nd2) {
+    d2 pc[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) pc[k] = lds_read128v((psrc[k] & 0x80000000u) ? vH_lds + (psrc[k] & 0x7fffffffu) : sslot + psrc[k]);
+    lds_wait_np<NP>(pc);
+    dma_means(mslot, (t > SF_AHEAD ? t - SF_AHEAD : 0) * recb);
+    if (nd2) dma_row<NRJ>(rjt, jslot, (t - 2) * (RJ_ROW * 8), lane, nj16);
+    dma_row<NRS>(rst, sslot, (t > 1 ? t - 2 : 0) * recb, lane, npc);
+    const int so = t * recb;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) bst128(rout, pdst[k], so, pc[k]);
+  };
+
+  // requests: the means of steps T .. T - SF_AHEAD + 1, the S_t records T and T - 1, the J row of step T - 1 (its first step is a full one)
+  for (int k = 0; k < SF_AHEAD; ++k) { const int tk = T - k > 0 ? T - k : 0; dma_means(mring_lds + ((T - k) & (SF_AHEAD - 1)) * 512, tk * recb); }
+  dma_row<NRS>(rst, sring_lds + (T & 1) * RS_SLOT, T * recb, lane, npc);
+  dma_row<NRS>(rst, sring_lds + ((T - 1) & 1) * RS_SLOT, (T - 1) * recb, lane, npc);
+  // need[t], need[t - 1], need[t - 2] as the loop goes down: bit (s & 63) of the mask of s's block of 64 steps
+  unsigned long long nmask = 0;
+  auto need_of = [&](int s_) -> bool {
+    if (s_ < 0) return false;
+    if (s_ == T || (s_ & 63) == 63) { const int b = (s_ & ~63) + lane; nmask = __ballot(b <= T && need[b] != 0); }
+    return ((nmask >> (s_ & 63)) & 1ull) != 0;
+  };
+  bool nd0 = need_of(T), nd1 = need_of(T - 1), nd2 = need_of(T - 2);
+  (void)nd0;
+  if (nd1) dma_row<NRJ>(rjt, jring_lds + ((T - 1) & 1) * (RJ_ROW * 8), (T - 1) * (RJ_ROW * 8), lane, nj16);
+  double sc;
+  {   // s_T = m_T, S_T = C_T (Smoothing.scala:59-61): the table's record T
+    vm_wait<0>();
+    wave_sync();
+    const unsigned sslot = sring_lds + (T & 1) * RS_SLOT, mslot = mring_lds + (T & (SF_AHEAD - 1)) * 512;
+    double mr = lds_read64<0>(mslot + lane * 8), td = lds_read64<0>(sslot + ptd);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(td)::"memory");
+    sc = vc ? mr : 0.0;
+    vH[lane] = vc ? mr : td;
+    wave_sync();
+    emit(T, sslot, jring_lds + (T & 1) * (RJ_ROW * 8), mslot, nd2);
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    nd0 = nd1; nd1 = nd2; nd2 = need_of(t - 2);
+    // A step issues, in this order: the request for the means (SF_AHEAD steps ahead), for a J row (two steps ahead, when it exists), for
+    // an S_t record (two steps ahead), its NP stores.  Operations younger than the request for record t (issued by step t + 2): that step's
+    // stores, then step t + 1: means, J row t - 1 (when it exists), record t - 1, stores.  The J row of step t is older than its record, the
+    // means older still.  (Step T - 1: everything it reads was waited for before step T.)
+    if (nd1) vm_wait<2 * NP + 1 + NRS + NRJ>(); else vm_wait<2 * NP + 1 + NRS>();
+    const unsigned sslot = sring_lds + (t & 1) * RS_SLOT, jslot = jring_lds + (t & 1) * (RJ_ROW * 8), mslot = mring_lds + (t & (SF_AHEAD - 1)) * 512;
+    double mr = lds_read64<0>(mslot + lane * 8), td = lds_read64<0>(sslot + ptd);
+    double mg[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) mg[s] = lds_read64<0>(mslot + idx[s]);
+    if constexpr (K == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(td), "+v"(mg[0])::"memory");
+    else if constexpr (K == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(td), "+v"(mg[0]), "+v"(mg[1])::"memory");
+    else if constexpr (K == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(td), "+v"(mg[0]), "+v"(mg[1]), "+v"(mg[2])::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mr), "+v"(td), "+v"(mg[0]), "+v"(mg[1]), "+v"(mg[2]), "+v"(mg[3])::"memory");
+    if (nd0) read_J(jslot);
+    const double mc = vc ? mr : 0.0;
+    double a1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < K; ++s) a1 = fma(vc ? mg[s] : 0.0, val[s], a1);
+    vU[lane] = vc ? sc - a1 : 0.0;
+    wave_sync();
+    double ch[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ch[g] = fma(Jc[4 * r + g], vU[16 * j + 4 * r + g], ch[g]);
+    const double scol = mc + ((ch[0] + ch[1]) + (ch[2] + ch[3]));
+    vH[lane] = vc ? scol : td;
+    wave_sync();
+    emit(t, sslot, jslot, mslot, nd2);
+    sc = vc ? scol : 0.0;
+  }
+  vm_wait<0>();   // no DMA may still be writing this block's LDS when the wave ends
+  const int stz = tb.status[0];
+  const unsigned long long badl = __ballot(!dead && vc && !isfinite(sc));
+  if (!dead && c == 0) {
+    const int sj = stz | (((badl >> (16 * j)) & 0xffffull) ? DLM_ST_NONFINITE : 0);
+    if (a.status && sj) atomicOr(&a.status[n], sj);
+  }
+  const unsigned long long live = __ballot(!dead && c == 0);
+  if (a.counters && lane == 0) atomicAdd(&a.counters[2], (unsigned long long)__builtin_popcountll(live));
 }
 
 }  // namespace s16
@@ -1010,10 +1212,10 @@ hipError_t launch_sparse16_sampler(const KArgs& a, int K, const SparseT* tabs_de
 template <class Tab>
 static hipError_t launch_rts_t(const KArgs& a, int K, const Tab* tabs_dev, hipStream_t s) {
   switch (K) {
-    case 1: hipLaunchKernelGGL((s16::k_smoother_rts16<1, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 2: hipLaunchKernelGGL((s16::k_smoother_rts16<2, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 3: hipLaunchKernelGGL((s16::k_smoother_rts16<3, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
-    case 4: hipLaunchKernelGGL((s16::k_smoother_rts16<4, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev); break;
+    case 1: hipLaunchKernelGGL((s16::k_smoother_rts16<1, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, RtsTabs{}); break;
+    case 2: hipLaunchKernelGGL((s16::k_smoother_rts16<2, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, RtsTabs{}); break;
+    case 3: hipLaunchKernelGGL((s16::k_smoother_rts16<3, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, RtsTabs{}); break;
+    case 4: hipLaunchKernelGGL((s16::k_smoother_rts16<4, Tab>), dim3(a.N), dim3(64), 0, s, a, tabs_dev, RtsTabs{}); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1147,6 +1349,103 @@ hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs
   KArgs kg = a;   // the series with a missing observation: their own factors
   kg.route_take = 1;
   return launch_sampler_t(kg, K, tabs_dev, s);
+}
+
+// ---- shared factors of the RTS smoother ------------------------------------------------------------------------------------------
+#ifndef DLM_RTS_SHARED_MIN
+#define DLM_RTS_SHARED_MIN 1024
+#endif
+bool rts_shared_eligible(const KArgs& a) {
+  // (below one wave per SIMD the per-series kernel takes what the table run takes, and the mean kernel comes on top: 3.0 against 3.3 ms at 8 series)
+  return sampler_shared_model_ok(a) && a.y && !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_SMOOTHER_PER_SERIES)) &&
+         (a.N >= DLM_RTS_SHARED_MIN || (a.flags & DLM_OPT_NO_SMALL_BATCH));
+}
+size_t rts_shared_ws_bytes(const KArgs& a) {
+  const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d;
+  return up64(n1 * s16::RJ_ROW * 8) + up64(n1 * rec * 8) + up64(n1) + 64;
+}
+void rts_shared_carve(void* ws, const KArgs& a, RtsTabs& tb) {
+  const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d;
+  char* p = (char*)ws;
+  tb.jrows = (double*)p; p += up64(n1 * s16::RJ_ROW * 8);
+  tb.srec = (double*)p;  p += up64(n1 * rec * 8);
+  tb.need = (unsigned char*)p; p += up64(n1);
+  tb.status = (int*)p;
+  tb.crec = nullptr; tb.crec_stride = 0;
+}
+// the tables: the covariance-only filter (one wave; it stops where the recursion settles and a copy kernel fills the rows above) -- IN FRONT of
+// the batch's forward pass: beside it, with the memory system saturated by the batch's record stores, the one wave's dependent round trips
+// take ten times as long (0.22 -> 2.3 ms measured) -- then, beside the forward pass, the smoother with its export on, reading that table's rows
+// as its filter records
+hipError_t launch_rts_shared_cov(const KArgs& a, int K, const SparseT* tabs_dev, RtsTabs& tb, const CovTabs& ctb, hipStream_t s) {
+  hipError_t err = hipMemsetAsync(tb.status, 0, sizeof(int), s);
+  if (err != hipSuccess) return err;
+  KArgs kc = a;
+  kc.smooth = nullptr; kc.filt = nullptr; kc.stats = nullptr; kc.theta = nullptr; kc.z = nullptr;
+  tb.crec = ctb.ftab; tb.crec_stride = ctb.frow;
+  return launch_sparse16_cov_filter(kc, K, tabs_dev, ctb, s);
+}
+// Dynamic LDS that, with the kernel's static LDS, fills a CU's 160 KB: no other workgroup that uses LDS -- every batch kernel of this library --
+// becomes resident beside it.  A table run is ONE wave whose dependent chain is what the call waits for; on a CU it shares with eight waves
+// per SIMD of the batch's forward pass it queues behind their MFMAs (64 cycles of the pipe each) and LDS traffic at every link of the chain
+// (measured: 1.8 ms alone, 4.5 ms beside k_filter_sp16).  One CU of 256 is what the isolation costs the batch.
+template <class F>
+static size_t whole_cu_lds(F kernel) {
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, (const void*)kernel) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const size_t whole = 160 * 1024;
+  if (at.sharedSizeBytes >= whole) return 0;
+  const size_t dyn = whole - at.sharedSizeBytes;
+  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return dyn;
+}
+hipError_t launch_rts_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, hipStream_t s) {
+  KArgs kp = a;   // the covariances of every series without a missing observation, bit for bit
+  kp.N = 1; kp.y = nullptr; kp.m0_stride = 0; kp.filt_in = nullptr; kp.filt = nullptr; kp.smooth = tb.srec; kp.status = tb.status; kp.stats = nullptr; kp.loglik = nullptr;
+  kp.prior = nullptr; kp.fq = nullptr; kp.route = nullptr; kp.counters = nullptr; kp.theta = nullptr; kp.z = nullptr; kp.series_offset = 0; kp.plain = nullptr;
+  switch (K) {
+    case 1: hipLaunchKernelGGL((s16::k_smoother_rts16<1, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<1, SparseT, true>), s, kp, tabs_dev, tb); break;
+    case 2: hipLaunchKernelGGL((s16::k_smoother_rts16<2, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<2, SparseT, true>), s, kp, tabs_dev, tb); break;
+    case 3: hipLaunchKernelGGL((s16::k_smoother_rts16<3, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<3, SparseT, true>), s, kp, tabs_dev, tb); break;
+    case 4: hipLaunchKernelGGL((s16::k_smoother_rts16<4, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<4, SparseT, true>), s, kp, tabs_dev, tb); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_mean_rts(const KArgs& a, const SparseT* sp, const RtsTabs& tb, hipStream_t s) {
+  const dim3 grid((a.N + 3) / 4), blk(64);
+  const int d = a.d;   // store / DMA instructions per step: see k_mean_rts16
+  if (d <= 7) hipLaunchKernelGGL((s16::k_mean_rts16<K, 2, 1, 1>), grid, blk, 0, s, a, sp, tb);
+  else if (d <= 10) hipLaunchKernelGGL((s16::k_mean_rts16<K, 4, 1, 2>), grid, blk, 0, s, a, sp, tb);
+  else if (d <= 13) hipLaunchKernelGGL((s16::k_mean_rts16<K, 6, 2, 2>), grid, blk, 0, s, a, sp, tb);
+  else if (d == 14) hipLaunchKernelGGL((s16::k_mean_rts16<K, 8, 2, 2>), grid, blk, 0, s, a, sp, tb);
+  else hipLaunchKernelGGL((s16::k_mean_rts16<K, 8, 2, 3>), grid, blk, 0, s, a, sp, tb);
+  return hipGetLastError();
+}
+// route [N]: the series with a missing observation
+hipError_t launch_rts_shared_mark(const KArgs& a, unsigned char* route, hipStream_t s) {
+  if (!route || !a.y) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, route);
+  return hipGetLastError();
+}
+// a.route [N] as launch_rts_shared_mark left it; the mean-only kernel smooths the series without a gap, k_smoother_rts16 the others
+hipError_t launch_rts_shared_means(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, hipStream_t s) {
+  if (!a.route || !a.y) return hipErrorInvalidValue;
+  hipError_t err;
+  KArgs km = a;
+  km.route_take = 0;
+  switch (K) {
+    case 1: err = launch_mean_rts<1>(km, tabs_dev, tb, s); break;
+    case 2: err = launch_mean_rts<2>(km, tabs_dev, tb, s); break;
+    case 3: err = launch_mean_rts<3>(km, tabs_dev, tb, s); break;
+    case 4: err = launch_mean_rts<4>(km, tabs_dev, tb, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (err != hipSuccess) return err;
+  KArgs kg = a;   // the series with a missing observation: their own J_t, S_t
+  kg.route_take = 1;
+  return launch_rts_t(kg, K, tabs_dev, s);
 }
 
 // RTS smoother from filter records alone (a.filt_in -> a.smooth), textbook or literal Q1: structured d <= 15

@@ -84,6 +84,9 @@ enum {
                                            the symmetric eigendecomposition of H (MultivariateGaussianSvd.scala:13-22; eigenvalues ascending, the largest-|.| entry of each
                                            eigenvector positive -- LAPACK leaves the sign open), instead of the engine's lower Cholesky factor.  The same distribution,
                                            other draws; served by the general LDS kernel (d <= 53): for parity with the literal operation sequence, not for speed */
+  DLM_OPT_SMOOTHER_PER_SERIES = 1u << 28, /* dlm_filter_smooth_batch with DLM_OPT_SMOOTHER_COMPAT_Q1, structured d <= 15, p = 1: every series computes its own J_t and
+                                           S_t, also when the batch shares V, W, C0 on a regular grid (by default they are computed once per call and every series
+                                           without a missing observation runs only its mean recursion: the same records, bit for bit) */
   DLM_OPT_TEST_FAIL_AFTER_TABLES = 1u << 30, /* TEST HOOK (tests/test_shared_sampler_gpu.py): dlm_ffbs_batch returns DLM_ERR_UNSUPPORTED right after it has started the
                                            shared-factor tables and normals on the engine's auxiliary streams -- the error path that must leave the engine usable */
   DLM_OPT_SHARED_COV = 1u << 24         /* d <= 15, p = 1, regular grid, V, W, C0 shared by the batch: ONE wave runs the covariance recursions, every series

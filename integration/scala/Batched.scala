@@ -92,6 +92,7 @@ object Native {
   val SvdPerSeries = 1 << 25      // SVD filter: every series its own decompositions (default: once per call where V, W, C0 are shared; the same bits)
   val SamplerPerSeries = 1 << 26  // ffbs: every series its own J_t, H_t, chol(H_t) (default: once per call where V, W, C0 are shared -- the pooled Gibbs samplers; the same draws, bit for bit)
   val DrawEig = 1 << 27           // ffbs: draw with the reference's own factor, theta = h + E sqrt(Lambda) z from eigSym(H) (MultivariateGaussianSvd.scala:13-22), instead of the Cholesky factor
+  val SmootherPerSeries = 1 << 28 // filterSmooth with SmootherCompatQ1: every series its own J_t, S_t (default: once per call where V, W, C0 are shared; the same records, bit for bit)
   val NoSteady = 1 << 22          // every step recomputes the covariance recursion, also once it has settled (the reference's arithmetic, step for step)
   /** every reference quirk switched on: results are the reference's arithmetic, not the textbook's (SURVEY Q1 / Q2 / Q9) */
   val LiteralReference = SmootherCompatQ1 | SvdRawWQ2 | SvdSamplerQ9

@@ -1,0 +1,181 @@
+"""Shared factors of the literal-Q1 smoother ("next round" 9).
+
+`DLM_OPT_SMOOTHER_COMPAT_Q1` selects Smoothing.scala:44 as written (S_t = C_t + J_t (S_{t+1} - R_{t+1}) J_t, no transpose).  J_t and S_t
+depend on V, W, C0 and the grid, not on the data: where the batch shares them, `k_smoother_rts16` runs once per call on the filter
+records of a series of zeros and every series without a missing observation runs only its mean recursion against the tables
+(`k_mean_rts16`); a series with a gap is routed to the per-series kernel.  The arithmetic of every output element is the per-series
+kernel's, operation for operation: the parity bar is EQUALITY OF BITS with `DLM_OPT_SMOOTHER_PER_SERIES`, plus the usual tolerance
+against the oracle's literal smoother (Smoothing.scala:31-64)."""
+import numpy as np
+import pytest
+
+import oracle
+from bayesian_dlms_amd import _lib
+from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
+
+pytestmark = pytest.mark.gpu
+
+Q1 = _lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_NO_SMALL_BATCH    # (the shared route starts at 1024 series; the flag takes small batches there too)
+W_C2 = np.array([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4])
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bayesian_dlms_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def omodel(mat):
+    return oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
+
+
+def c2(T, wscale=1.0):
+    mod = Dlm.polynomial(1) + Dlm.seasonal(24, 6)
+    mat = materialise(mod, np.arange(1, T + 1, dtype=np.float64))
+    return mat, DlmParameters([[1.0]], np.diag(W_C2 * wscale), np.zeros(13), np.eye(13))
+
+
+def both(eng, mat, p, y, flags=0):
+    sh = eng.filter_smooth(mat, p, y, flags=flags | Q1 | _lib.OPT_COUNT_STEPS)
+    cnt = eng.last_counters()
+    assert eng.last_variant == "sparse16-rts"
+    ps = eng.filter_smooth(mat, p, y, flags=flags | Q1 | _lib.OPT_SMOOTHER_PER_SERIES | _lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2:] == (0, 0)
+    return sh, ps, cnt
+
+
+def same(a, b, what):
+    if np.array_equal(a, b, equal_nan=True):
+        return
+    ne = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b))))
+    raise AssertionError(f"{what}: {len(ne)} values differ; first at {ne[0].tolist()}: {a[tuple(ne[0])]!r} vs {b[tuple(ne[0])]!r}; "
+                         f"series {np.unique(ne[:, 0])[:8].tolist()}, t in [{ne[:, 1].min()}, {ne[:, 1].max()}], entries {np.unique(ne[:, 2])[:8].tolist()}")
+
+
+@pytest.mark.parametrize("flags", [0, _lib.OPT_NO_STEADY])
+@pytest.mark.parametrize("T,N", [(1000, 37), (1, 5), (2, 3), (3, 4), (40, 9), (63, 4), (64, 1), (65, 6), (129, 300), (700, 2)])
+def test_bit_for_bit_with_the_per_series_kernel(eng, T, N, flags):
+    mat, p = c2(T)
+    rng = np.random.default_rng(T + N)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    sh, ps, cnt = both(eng, mat, p, y, flags)
+    assert cnt[2] == N and cnt[3] == 0, cnt
+    same(sh["filt"], ps["filt"], "filtered records")
+    same(sh["smooth"], ps["smooth"], "smoothed records")
+    assert np.all(sh["status"] == 0) and np.all(ps["status"] == 0)
+    n = N // 2
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n])
+    s = oracle.smoother(omodel(mat), f, compat_q1=True)
+    np.testing.assert_allclose(sh["smooth"][n][:, :13], s["s"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sh["smooth"][n][:, 13:], s["S"], rtol=1e-8, atol=1e-9)
+    if T > 2:   # the literal form is not the textbook one (and not symmetric)
+        st = oracle.smoother(omodel(mat), f)
+        assert np.abs(s["S"] - st["S"]).max() > 1e-3
+
+
+def test_series_with_missing_observations_are_routed_to_their_own_recursion(eng):
+    T, N = 300, 67
+    mat, p = c2(T)
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    y[1, 0, 0] = np.nan
+    y[5, T - 1, 0] = np.nan
+    y[17, 100:110, 0] = np.nan
+    y[40, :, 0] = np.nan
+    y[66, 64, 0] = np.nan
+    sh, ps, cnt = both(eng, mat, p, y)
+    assert cnt[2] == N - 5 and cnt[3] == 5, cnt
+    same(sh["filt"], ps["filt"], "filtered records")
+    same(sh["smooth"], ps["smooth"], "smoothed records")
+    for n in (1, 17, 40, 2, 66):
+        f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n])
+        s = oracle.smoother(omodel(mat), f, compat_q1=True)
+        np.testing.assert_allclose(sh["smooth"][n][:, :13], s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(sh["smooth"][n][:, 13:], s["S"], rtol=1e-8, atol=1e-9)
+
+
+def test_per_series_prior_means_share_the_factors_other_parameters_do_not(eng):
+    T, N = 200, 6
+    mat, p = c2(T)
+    rng = np.random.default_rng(4)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1)
+    from bayesian_dlms_amd.engine import pack_params
+    V, vs, W, ws, m0, ms, C0, cs, vts, wts = pack_params(p, N)
+    m0s = rng.standard_normal((N, 13))
+    packed = (V, 0, W, 0, m0s.reshape(-1), 13, C0, 0, 0, 0)
+    sh = eng.filter_smooth(mat, packed, y, flags=Q1 | _lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2] == N
+    ps = eng.filter_smooth(mat, packed, y, flags=Q1 | _lib.OPT_SMOOTHER_PER_SERIES)
+    same(sh["smooth"], ps["smooth"], "smoothed records")
+    small = eng.filter_smooth(mat, packed, y, flags=_lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_COUNT_STEPS)   # six series: below the threshold, every series its own
+    assert eng.last_counters()[2:] == (0, 0)
+    same(small["smooth"], ps["smooth"], "smoothed records of the small batch")
+    plist = [DlmParameters(p.v * (1 + 0.1 * n), p.w, p.m0, p.c0) for n in range(N)]
+    out = eng.filter_smooth(mat, plist, y, flags=Q1 | _lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2:] == (0, 0)
+    f = oracle.kf_filter(omodel(mat), plist[3].v, p.w, p.m0, p.c0, y[3])
+    s = oracle.smoother(omodel(mat), f, compat_q1=True)
+    np.testing.assert_allclose(out["smooth"][3][:, 13:], s["S"], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("d,knz", [(1, 1), (2, 1), (3, 2), (6, 3), (7, 1), (8, 4), (10, 2), (11, 3), (12, 4), (14, 2), (15, 3)])
+def test_every_state_dimension_and_sparsity_instantiation(eng, d, knz):
+    """d = 1 .. 15 (the five store / DMA instantiations of k_mean_rts16) and 1 .. 4 nonzeros per row of G, a gap in one series, batches that
+    do not fill their last wave.  d <= 5 would take the lane kernels' forward pass: DLM_OPT_NO_LANE keeps the structured path."""
+    rng = np.random.default_rng(80 + 16 * knz + d)
+    T, N = 150, 7
+    knz = min(knz, d)
+    Gm = np.zeros((d, d))
+    coef = {1: [0.9], 2: [0.7, 0.25], 3: [0.6, 0.25, -0.2], 4: [0.5, 0.3, -0.2, 0.15]}[knz]
+    for i in range(d):
+        for s_, cf in enumerate(coef):
+            Gm[i, (i + s_) % d] += cf
+    Fv = rng.choice([1.0, 0.0, 0.5, -0.5], size=d).reshape(-1, 1)
+    Fv[0, 0] = 1.0
+    mat = materialise(Dlm(lambda t: Fv, lambda dt: Gm), np.arange(1, T + 1, dtype=np.float64))
+    p = DlmParameters([[0.7]], np.diag(rng.uniform(0.1, 0.5, d)), rng.standard_normal(d), np.eye(d))
+    y = rng.standard_normal((N, T, 1))
+    y[1, 70:73, 0] = np.nan
+    sh, ps, cnt = both(eng, mat, p, y, _lib.OPT_NO_LANE)
+    assert cnt[2] == N - 1 and cnt[3] == 1, cnt
+    same(sh["filt"], ps["filt"], "filtered records")
+    same(sh["smooth"], ps["smooth"], "smoothed records")
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[0])
+    s = oracle.smoother(omodel(mat), f, compat_q1=True)
+    np.testing.assert_allclose(sh["smooth"][0][:, d:], s["S"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sh["smooth"][0][:, :d], s["s"], rtol=1e-8, atol=1e-9)
+
+
+def test_smoothed_moments_only_and_repeated_calls_of_changing_size(eng):
+    """filt = NULL (the records stay in an engine workspace), then calls of other sizes on the same engine: the tables' workspace is re-carved."""
+    rng = np.random.default_rng(9)
+    ref = None
+    for T, N in ((120, 5), (400, 33), (50, 2), (400, 33)):
+        mat, p = c2(T)
+        y = np.random.default_rng(T * 7 + N).standard_normal((N, T, 1)).cumsum(axis=1) * 0.2
+        sh = eng.filter_smooth(mat, p, y, flags=Q1, want_filt=False)
+        ps = eng.filter_smooth(mat, p, y, flags=Q1 | _lib.OPT_SMOOTHER_PER_SERIES)
+        same(sh["smooth"], ps["smooth"], f"smoothed records T={T} N={N}")
+        if (T, N) == (400, 33):
+            if ref is None:
+                ref = np.array(sh["smooth"])
+            else:
+                same(np.array(sh["smooth"]), ref, "the same call again")
+
+
+def test_a_batch_above_the_threshold_takes_the_shared_route_by_default(eng):
+    """1100 series, no flag: the tables serve every series but the two with a gap."""
+    T, N = 60, 1100
+    mat, p = c2(T)
+    rng = np.random.default_rng(12)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3
+    y[7, 30, 0] = np.nan
+    y[1099, 0, 0] = np.nan
+    sh = eng.filter_smooth(mat, p, y, flags=_lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_COUNT_STEPS)
+    cnt = eng.last_counters()
+    assert cnt[2] == N - 2 and cnt[3] == 2, cnt
+    ps = eng.filter_smooth(mat, p, y, flags=_lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_SMOOTHER_PER_SERIES)
+    same(sh["filt"], ps["filt"], "filtered records")
+    same(sh["smooth"], ps["smooth"], "smoothed records")
