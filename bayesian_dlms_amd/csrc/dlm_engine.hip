@@ -578,15 +578,15 @@ int start_rts_tables(dlm_engine* e, const KArgs& k, dlm::RtsTabs& tb) {
   dlm::rts_shared_carve(e->sampws, k, tb);
   dlm::CovTabs ctb{};
   dlm::covtabs_carve(e->covws, k.d, k.T, ctb);
+  HIP_TRY(e, dlm::launch_rts_shared_mark(k, e->route, tb, e->stream));                     // the series with a gap; where they are the majority, no tables (tb.skip)
   HIP_TRY(e, dlm::launch_rts_shared_cov(k, e->sparse_k, e->sp_dev, tb, ctb, e->stream));   // the forward covariances: in front of the batch's forward pass
   HIP_TRY(e, hipEventRecord(e->cov_ev[0], e->stream));
   e->cov_busy = true;                                                 // (from here on every exit path joins the stream: AuxScope)
   HIP_TRY(e, hipStreamWaitEvent(e->cov_stream, e->cov_ev[0], 0));
   HIP_TRY(e, dlm::launch_rts_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));   // J_t, S_t: beside it
   // The table run keeps a whole CU to itself (whole_cu_lds): it has to be resident before the forward pass fills every CU with its
-  // workgroups, or it waits for that kernel's last wave.  The gap marks of the call -- a 40 us kernel the backward pass needs anyway -- go
+  // workgroups, or it waits for that kernel's last wave.  The caller launches the gap count of the forward pass (mark_plain: a 30 us kernel)
   // in between on the engine's stream.
-  HIP_TRY(e, dlm::launch_rts_shared_mark(k, e->route, e->stream));
   HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
   return DLM_OK;
 }
@@ -1127,14 +1127,24 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   if ((rc = st.commit())) return rc;
   if ((rc = analyse_g(e, k, model->G, opts->mem == DLM_MEM_HOST))) return rc;
   if (want_packed && (rc = packed_path(e, k))) return rc;
-  const bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
+  bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
   if (want_packed) k.packed = 3;   // filtered and smoothed records both leave packed
+  // Structured d <= 15 path, V, W, C0 shared by the batch: J_t, S_t of the RTS recursion once per call, every series its mean recursion
+  // (k_smoother_rts16 with its export on + k_mean_rts16).  Literal Q1: from 1024 series; textbook: from 8192 series and when
+  // the caller takes the filtered records too (without them the per-series path keeps them packed in a workspace).
+  const bool q1 = (k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1) != 0;
+  const bool rts_shared = fast_shape_ok(k) && e->sparse_k > 0 && !use_lane(k) && !k.packed && !(k.flags & DLM_OPT_SHARED_COV) &&
+                          (q1 ? !fused_fast : (filt != nullptr && fast_smoother_ok(e, k))) && dlm::rts_shared_eligible(k, !q1);
+  // (textbook: the series with a missing observation keep the information-form kernel, k_smoother_sp16, and the forward pass its side records for
+  //  them -- the RTS kernel per series is five times slower; literal Q1 has only that kernel)
   if (!filt) {   // smoothed moments only: the filtered records stay in an engine workspace, packed on the structured path
     k.packed |= (fast_smoother_ok(e, k) && e->sparse_k > 0 && !use_lane(k)) ? 1 : 0;
     if ((rc = ensure_fws(e, (k.packed & 1) ? N * (T + 1) * (size_t)dlm::packed_rec_bytes((int)d) : N * (T + 1) * rec * sizeof(double)))) return rc;
     k.filt = e->fws;
   }
   if ((rc = mark(e, 0))) return rc;
+  dlm::RtsTabs rtb{};
+  if (rts_shared && (rc = start_rts_tables(e, k, rtb))) return rc;
   if ((rc = mark_plain(e, k))) return rc;
   if (filt && fast_smoother_ok(e, k) && use_shared_cov(e, k)) {
     dlm::CovTabs tb;
@@ -1145,20 +1155,22 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
     if ((rc = mark(e, 2))) return rc;
     return st.finish(opts->flags & DLM_OPT_ASYNC);
   }
-  // literal Q1 on the structured d <= 15 path: J_t, S_t once per call where the batch shares V, W, C0 (k_mean_rts16)
-  const bool rts_shared = (k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1) && !fused_fast && fast_shape_ok(k) && e->sparse_k > 0 && !use_lane(k) &&
-                          !(k.packed & 1) && dlm::rts_shared_eligible(k);
-  dlm::RtsTabs rtb{};
-  if (rts_shared && (rc = start_rts_tables(e, k, rtb))) return rc;
   if ((rc = run_filter(e, k, fused_fast))) return rc;
+  if (rts_shared) {
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));   // the tables (in front of the timing mark: the backward time is the mean kernel's)
+    e->cov_busy = false;
+  }
   if ((rc = mark(e, 1))) return rc;
   k.filt_in = k.filt;
   if (rts_shared) {
-    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev[1], 0));   // the tables
-    e->cov_busy = false;
     k.route = e->route; k.route_take = 0;
-    e->variant = "sparse16-rts";
-    HIP_TRY(e, dlm::launch_rts_shared_means(k, e->sparse_k, e->sp_dev, rtb, e->stream));
+    e->variant = "sparse16-rts-shared";
+    HIP_TRY(e, dlm::launch_rts_shared_means(k, e->sparse_k, e->sp_dev, rtb, q1, e->stream));
+    if (!q1) {
+      KArgs kg = k;
+      kg.route_take = 1;
+      HIP_TRY(e, dlm::launch_sparse16_smoother(kg, e->sparse_k, e->sp_dev, e->side, e->stream));
+    }
   } else if ((rc = run_smoother(e, k, fused_fast))) return rc;
   if ((rc = mark(e, 2))) return rc;
   return st.finish(opts->flags & DLM_OPT_ASYNC);

@@ -117,6 +117,7 @@ struct CovTabs {
                   //   for the backward kernel (a sequential stream instead of 112 bytes out of every 1456-byte record); nullptr: dlm_filter_batch
   double* sc;     // (unused: the smoothed means of the record-writer experiment, profiles/r03_notes.md)
   int frow, brow;
+  const int* skip;   // nullable: nonzero on the device -- the tables are not wanted after all (most series of the call have a gap): the covariance-only filter returns at once
 };
 size_t covtabs_doubles(int d, int T);   // doubles of the table block (everything but eq)
 void covtabs_carve(double* base, int d, int T, CovTabs& t);
@@ -158,7 +159,7 @@ hipError_t launch_sampler_shared_normals(const KArgs& a, double* z4, hipStream_t
 // a.route [N] is filled here (series with a missing observation), the mean-only kernel draws for the others, k_sampler_sp16 for these
 hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs_dev, const SampTabs& tb, hipStream_t s);
 
-// Shared factors of the RTS smoother (literal Q1, Smoothing.scala:38-47; dlm_sampler16.hip): k_smoother_rts16 runs once, on the
+// Shared factors of the RTS smoother (Smoothing.scala:38-47, textbook or literal Q1; dlm_sampler16.hip): k_smoother_rts16 runs once, on the
 // filter records of a series of zeros, into these tables; every series without a missing observation runs the mean recursion against them
 // (k_mean_rts16, four series per wave), the others k_smoother_rts16 as always.  Bit for bit the per-series kernel's records.
 struct RtsTabs {
@@ -168,15 +169,17 @@ struct RtsTabs {
   int* status;           // status of the zero series' two kernels, for every series served by the tables
   const double* crec;    // the covariances exist already: records crec_stride bytes apart (the forward table of the shared-covariance kernels, CovTabs::ftab)
   int crec_stride;
+  int* gaps;             // the number of series with a missing observation (launch_rts_shared_mark)
+  int* skip;             // 1: more than half of the series have one -- the tables are not made, every series is routed to the per-series kernel
 };
-bool rts_shared_eligible(const KArgs& a);
+bool rts_shared_eligible(const KArgs& a, bool textbook);   // textbook: the call asks for S = C - J (R+ - S+) J^T (the default): a larger batch is needed to pay for the tables
 size_t rts_shared_ws_bytes(const KArgs& a);
 void rts_shared_carve(void* ws, const KArgs& a, RtsTabs& tb);
 // the tables: the covariance-only filter into ctb.ftab (launch_sparse16_cov_filter), then the smoother with its export on (both one wave)
 hipError_t launch_rts_shared_cov(const KArgs& a, int K, const SparseT* tabs_dev, RtsTabs& tb, const CovTabs& ctb, hipStream_t s);
 hipError_t launch_rts_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, hipStream_t s);
-hipError_t launch_rts_shared_mark(const KArgs& a, unsigned char* route, hipStream_t s);   // KArgs::route of the call from its observations
-hipError_t launch_rts_shared_means(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, hipStream_t s);
+hipError_t launch_rts_shared_mark(const KArgs& a, unsigned char* route, const RtsTabs& tb, hipStream_t s);   // KArgs::route of the call from its observations; tb.gaps, tb.skip
+hipError_t launch_rts_shared_means(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, bool own_rts, hipStream_t s);
 
 // the same for 16 <= d <= 48 (dlm_wave48.hip): rows of 64 x (4 DT^2 + 16 DT) doubles, per lane [ J^T tiles | row `lane` of L ]
 bool wave48_sampler_shared_model_ok(const KArgs& a);

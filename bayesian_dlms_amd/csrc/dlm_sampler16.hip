@@ -789,14 +789,30 @@ __global__ __launch_bounds__(64, 3) void k_mean_sampler_sp16(KArgs a, const Spar
 }
 
 // route[n] = 1: the series has a missing observation
-__global__ __launch_bounds__(256) void k_mark_gaps(const double* __restrict__ y, int N, int T, unsigned char* __restrict__ route) {
+__global__ __launch_bounds__(256) void k_mark_gaps(const double* __restrict__ y, int N, int T, unsigned char* __restrict__ route, int* __restrict__ count = nullptr) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const double* yn = y + (size_t)n * T;
+  const bool live = n < N;   // (no early return: the workgroup meets at the barriers below)
+  const double* yn = y + (size_t)(live ? n : 0) * T;
   bool gap = false;
-  for (int t = lane; t < T; t += 64) { const double v = yn[t]; gap |= !(v == v); }
+  if (live) for (int t = lane; t < T; t += 64) { const double v = yn[t]; gap |= !(v == v); }
   const bool any = __ballot(gap) != 0ull;
-  if (lane == 0) route[n] = any ? 1 : 0;
+  if (live && lane == 0) route[n] = any ? 1 : 0;
+  if (count) {   // one atomic per workgroup of four series
+    __shared__ int found;
+    if (threadIdx.x == 0) found = 0;
+    __syncthreads();
+    if (lane == 0 && any) atomicAdd(&found, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && found) atomicAdd(count, found);
+  }
+}
+// More than half of the series have a gap: the tables would serve too few of them to be worth one wave's 2-3 ms beside the forward pass (and
+// the per-series kernel's launch for the rest): every series is routed to the per-series kernel and the table kernels return at once.
+__global__ __launch_bounds__(256) void k_rts_decide(unsigned char* __restrict__ route, int N, const int* __restrict__ gaps, int* __restrict__ skip) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const bool sk = 2 * (long long)gaps[0] > (long long)N;
+  if (n == 0) skip[0] = sk ? 1 : 0;
+  if (sk && n < N) route[n] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -815,6 +831,7 @@ __global__ __launch_bounds__(256) void k_mark_gaps(const double* __restrict__ y,
 template <int K, class Tab, bool EXP = false>
 __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __restrict__ sp, RtsTabs tb) {
   if (!EXP && a.route && (a.route[blockIdx.x] != 0) != (a.route_take != 0)) return;   // shared-factor call: only the series routed here
+  if constexpr (EXP) { if (tb.skip && *tb.skip) return; }   // (the call found that it does not want the tables)
   if constexpr (EXP) __builtin_amdgcn_s_setprio(3);   // the table's one wave runs beside the kernel that filters the batch and is what the mean kernel waits for
   __shared__ __attribute__((aligned(16))) double lds[2 * IMG + 4 * 16];
   double* img = lds;       double* inv = lds + IMG;
@@ -1009,7 +1026,6 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
   for (int r = 0; r < 4; ++r) bad |= va[r] && !isfinite(S[r]);
   if (__ballot(bad) != 0ull) st |= DLM_ST_NONFINITE;
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
-  if (!EXP && a.route && a.counters && lane == 0) atomicAdd(&a.counters[3], 1ull);   // a series of a shared-factor call that computed its own
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1060,6 +1076,11 @@ __global__ __launch_bounds__(64, 3) void k_mean_rts16(KArgs a, const SparseT* __
   unsigned deadmask = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) deadmask |= (__builtin_amdgcn_readlane((int)dead, 16 * q) & 1) << q;
+  if (a.counters && lane == 0) {   // the wave's series that are served here, and those that are left to the per-series kernel
+    const int routed = __builtin_popcount(deadmask & ((1u << nser) - 1u));
+    if (nser - routed) atomicAdd(&a.counters[2], (unsigned long long)(nser - routed));
+    if (routed) atomicAdd(&a.counters[3], (unsigned long long)routed);
+  }
   if (deadmask == 0xfu) return;
   double* vU = lds;            // s_{t+1} - a+   [4][16]
   double* vH = vU + 64;        // the first 16 doubles of each series' smoothed record
@@ -1190,8 +1211,6 @@ __global__ __launch_bounds__(64, 3) void k_mean_rts16(KArgs a, const SparseT* __
     const int sj = stz | (((badl >> (16 * j)) & 0xffffull) ? DLM_ST_NONFINITE : 0);
     if (a.status && sj) atomicOr(&a.status[n], sj);
   }
-  const unsigned long long live = __ballot(!dead && c == 0);
-  if (a.counters && lane == 0) atomicAdd(&a.counters[2], (unsigned long long)__builtin_popcountll(live));
 }
 
 }  // namespace s16
@@ -1330,7 +1349,7 @@ hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs
   if (!a.route) return hipErrorInvalidValue;
   hipError_t err;
   if (tb.mc4) { /* the mean-only forward kernel has marked the series it left */ }
-  else if (a.y) hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, a.route);
+  else if (a.y) hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, a.route, (int*)nullptr);
   else if ((err = hipMemsetAsync(a.route, 0, (size_t)a.N, s)) != hipSuccess) return err;
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;
@@ -1353,16 +1372,22 @@ hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs
 
 // ---- shared factors of the RTS smoother ------------------------------------------------------------------------------------------
 #ifndef DLM_RTS_SHARED_MIN
-#define DLM_RTS_SHARED_MIN 1024
+#define DLM_RTS_SHARED_MIN 1024            // literal Q1: against k_smoother_rts16 per series
 #endif
-bool rts_shared_eligible(const KArgs& a) {
-  // (below one wave per SIMD the per-series kernel takes what the table run takes, and the mean kernel comes on top: 3.0 against 3.3 ms at 8 series)
-  return sampler_shared_model_ok(a) && a.y && !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_SMOOTHER_PER_SERIES)) &&
-         (a.N >= DLM_RTS_SHARED_MIN || (a.flags & DLM_OPT_NO_SMALL_BATCH));
+#ifndef DLM_RTS_SHARED_MIN_TEXTBOOK
+#define DLM_RTS_SHARED_MIN_TEXTBOOK 8192   // textbook covariance: against k_smoother_sp16 per series
+#endif
+// The table run is one wave's 2.3 ms (C2, T = 1000) whatever the batch: what the batch must be worth.  Literal Q1: below one wave per SIMD
+// the per-series kernel takes what the table run takes and the mean kernel comes on top (3.0 against 3.3 ms at 8 series).  Textbook: the
+// per-series information-form kernel takes 4.6 ms at 5000 series, 6.8 at 7500, 9.0 at 10 000 against 5.3 / 6.5 / 7.8 ms through the tables.
+// DLM_OPT_NO_STEADY asks for every series' own recursion at every step: never through the tables.
+bool rts_shared_eligible(const KArgs& a, bool textbook) {
+  return sampler_shared_model_ok(a) && a.y && !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_SMOOTHER_PER_SERIES | DLM_OPT_NO_STEADY)) &&
+         (a.N >= (textbook ? DLM_RTS_SHARED_MIN_TEXTBOOK : DLM_RTS_SHARED_MIN) || (a.flags & DLM_OPT_NO_SMALL_BATCH));
 }
 size_t rts_shared_ws_bytes(const KArgs& a) {
   const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d;
-  return up64(n1 * s16::RJ_ROW * 8) + up64(n1 * rec * 8) + up64(n1) + 64;
+  return up64(n1 * s16::RJ_ROW * 8) + up64(n1 * rec * 8) + up64(n1) + 64;   // (64: status block of 16 ints)
 }
 void rts_shared_carve(void* ws, const KArgs& a, RtsTabs& tb) {
   const size_t n1 = (size_t)a.T + 1, rec = (size_t)a.d + (size_t)a.d * a.d;
@@ -1370,7 +1395,7 @@ void rts_shared_carve(void* ws, const KArgs& a, RtsTabs& tb) {
   tb.jrows = (double*)p; p += up64(n1 * s16::RJ_ROW * 8);
   tb.srec = (double*)p;  p += up64(n1 * rec * 8);
   tb.need = (unsigned char*)p; p += up64(n1);
-  tb.status = (int*)p;
+  tb.status = (int*)p; tb.gaps = tb.status + 8; tb.skip = tb.status + 9;
   tb.crec = nullptr; tb.crec_stride = 0;
 }
 // the tables: the covariance-only filter (one wave; it stops where the recursion settles and a copy kernel fills the rows above) -- IN FRONT of
@@ -1378,12 +1403,12 @@ void rts_shared_carve(void* ws, const KArgs& a, RtsTabs& tb) {
 // take ten times as long (0.22 -> 2.3 ms measured) -- then, beside the forward pass, the smoother with its export on, reading that table's rows
 // as its filter records
 hipError_t launch_rts_shared_cov(const KArgs& a, int K, const SparseT* tabs_dev, RtsTabs& tb, const CovTabs& ctb, hipStream_t s) {
-  hipError_t err = hipMemsetAsync(tb.status, 0, sizeof(int), s);
-  if (err != hipSuccess) return err;
   KArgs kc = a;
   kc.smooth = nullptr; kc.filt = nullptr; kc.stats = nullptr; kc.theta = nullptr; kc.z = nullptr;
   tb.crec = ctb.ftab; tb.crec_stride = ctb.frow;
-  return launch_sparse16_cov_filter(kc, K, tabs_dev, ctb, s);
+  CovTabs cs = ctb;
+  cs.skip = tb.skip;
+  return launch_sparse16_cov_filter(kc, K, tabs_dev, cs, s);
 }
 // Dynamic LDS that, with the kernel's static LDS, fills a CU's 160 KB: no other workgroup that uses LDS -- every batch kernel of this library --
 // becomes resident beside it.  A table run is ONE wave whose dependent chain is what the call waits for; on a CU it shares with eight waves
@@ -1423,14 +1448,19 @@ static hipError_t launch_mean_rts(const KArgs& a, const SparseT* sp, const RtsTa
   else hipLaunchKernelGGL((s16::k_mean_rts16<K, 8, 2, 3>), grid, blk, 0, s, a, sp, tb);
   return hipGetLastError();
 }
-// route [N]: the series with a missing observation
-hipError_t launch_rts_shared_mark(const KArgs& a, unsigned char* route, hipStream_t s) {
+// route [N]: the series with a missing observation -- or, where more than half of them have one, every series (tb.skip: no tables)
+hipError_t launch_rts_shared_mark(const KArgs& a, unsigned char* route, const RtsTabs& tb, hipStream_t s) {
   if (!route || !a.y) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, route);
+  hipError_t err = hipMemsetAsync(tb.status, 0, 16 * sizeof(int), s);   // the zero series' status, the gap count, the decision
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(s16::k_mark_gaps, dim3((a.N + 3) / 4), dim3(256), 0, s, a.y, a.N, a.T, route, tb.gaps);
+  if ((err = hipGetLastError()) != hipSuccess) return err;
+  hipLaunchKernelGGL(s16::k_rts_decide, dim3((a.N + 255) / 256), dim3(256), 0, s, route, a.N, (const int*)tb.gaps, tb.skip);
   return hipGetLastError();
 }
 // a.route [N] as launch_rts_shared_mark left it; the mean-only kernel smooths the series without a gap, k_smoother_rts16 the others
-hipError_t launch_rts_shared_means(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, hipStream_t s) {
+// (own_rts; otherwise the caller launches its per-series kernel for them)
+hipError_t launch_rts_shared_means(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, bool own_rts, hipStream_t s) {
   if (!a.route || !a.y) return hipErrorInvalidValue;
   hipError_t err;
   KArgs km = a;
@@ -1442,7 +1472,7 @@ hipError_t launch_rts_shared_means(const KArgs& a, int K, const SparseT* tabs_de
     case 4: err = launch_mean_rts<4>(km, tabs_dev, tb, s); break;
     default: return hipErrorInvalidValue;
   }
-  if (err != hipSuccess) return err;
+  if (err != hipSuccess || !own_rts) return err;
   KArgs kg = a;   // the series with a missing observation: their own J_t, S_t
   kg.route_take = 1;
   return launch_rts_t(kg, K, tabs_dev, s);

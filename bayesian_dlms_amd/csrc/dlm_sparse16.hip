@@ -673,7 +673,8 @@ __global__ __launch_bounds__(256, SIM ? 4 : FI_WAVES) void k_filter_sp16(KArgs a
 // the covariance-only run: one wave (a: N = 1, filt = the C_t table)
 template <int K>
 __global__ __launch_bounds__(64) void k_cov_filter_sp16(KArgs a, const SparseT* __restrict__ sp, double* __restrict__ side,
-                                                        double* __restrict__ kftab) {
+                                                        double* __restrict__ kftab, const int* __restrict__ skip) {
+  if (skip && *skip) return;   // (the call found that it does not want the tables)
   __shared__ __attribute__((aligned(16))) double lds[4 * WAVE_LDS];
   __builtin_amdgcn_s_setprio(3);   // one wave that every mean kernel of the call waits for, possibly beside a kernel that fills the device
   filter_body<K, false, false, false, true>(a, sp, side, nullptr, lds, kftab);
@@ -1714,6 +1715,7 @@ void covtabs_carve(double* base, int d, int T, CovTabs& t) {
   const size_t rec = (size_t)(d + d * d), n1 = (size_t)T + 1;
   t.frow = (int)(rec * 8 + 128); t.brow = (int)(2 * rec * 8 + 128);
   t.ftab = base; t.btab = t.ftab + n1 * (rec + 16); t.cside = t.btab + n1 * (2 * rec + 16);
+  t.skip = nullptr;
 }
 bool shared_cov_eligible(const KArgs& a) {
   return a.d <= 15 && a.p == 1 && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !a.v_stride && !a.w_stride &&
@@ -1828,7 +1830,7 @@ static hipError_t launch_cf(const KArgs& a, const SparseT* sp, const CovTabs& tb
   if (err != hipSuccess) return err;
   KArgs k = cov_args(a, tb);
   k.settle_step = (a.flags & DLM_OPT_NO_STEADY) ? nullptr : settle;
-  hipLaunchKernelGGL((k_cov_filter_sp16<K>), dim3(1), dim3(64), 0, s, k, sp, tb.cside, tb.ftab + (a.d + a.d * a.d));
+  hipLaunchKernelGGL((k_cov_filter_sp16<K>), dim3(1), dim3(64), 0, s, k, sp, tb.cside, tb.ftab + (a.d + a.d * a.d), tb.skip);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   hipLaunchKernelGGL(k_cov_fill_sp16, dim3(a.T + 1), dim3(64), 0, s, tb.ftab, tb.frow / 8, tb.cside, (const int*)settle, a.T);
   return hipGetLastError();

@@ -298,8 +298,14 @@ def add_secondary(line, args, ctx):
     line["config"]["value_missing_0.05"] = miss["value"]
     line["config"]["ms_per_step_full_recursion"] = full["ms_per_step"]
     line["config"]["ms_per_step_missing_0.05"] = miss["ms_per_step"]
-    sec = {"c2_full_recursion": brief(full), "c2_missing_0.05": brief(miss)}
+    # the headline shares J_t, S_t across the batch where V, W, C0 are shared; with DLM_OPT_SMOOTHER_PER_SERIES every series
+    # runs its own covariance recursions in both passes (the steady-state shortcut still on): the per-series kernels' figure
+    own = run(flags=_lib.OPT_SMOOTHER_PER_SERIES, steps=10, warmup=3)
+    line["config"]["value_per_series_factors"] = own["value"]
+    line["config"]["ms_per_step_per_series_factors"] = own["ms_per_step"]
+    sec = {"c2_full_recursion": brief(full), "c2_missing_0.05": brief(miss), "c2_per_series_factors": brief(own)}
     sec["c2_literal_q1"] = brief(run(semantics="literal-q1", steps=3, warmup=1))
+    sec["c2_literal_q1_per_series_factors"] = brief(run(semantics="literal-q1", flags=_lib.OPT_SMOOTHER_PER_SERIES, steps=3, warmup=1))
     sec["c2_shared_covariance_opt_in"] = brief(run(flags=_lib.OPT_SHARED_COV, steps=5, warmup=1))
     sec["c3_reference_sampler"] = brief(run(config="c3", sampler="reference", steps=3, warmup=2))
     sec["c3_reference_sampler_own_factors"] = brief(run(config="c3", sampler="reference", flags=_lib.OPT_SAMPLER_PER_SERIES, steps=2, warmup=2))   # every series its own J_t, H_t, chol(H_t)
@@ -451,6 +457,13 @@ def run_one(args, ctx):
             # forward: read y, write [m|C]; backward: read [m|C], write [s|S] (8p + 24 (d + d^2) = 4376 B, packed 2504)
             fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * recw, 16.0 * recw, "GB/s", HBM_PEAK_GBS, "hbm"
             names = ("k_filter_", "k_smoother_")
+            if variant == "sparse16-rts-shared":
+                # shared factors: J_t, S_t come from the call's tables; the backward kernel reads the head of a filtered record (16
+                # doubles: the mean) and writes the smoothed record -- the bytes this algorithm has to move, not SURVEY 8d's read + write of whole records
+                bwd_u = 128.0 + 8.0 * recw
+                names = ("k_filter_", "k_mean_")
+                moved_note = ("algorithmic bytes of the shared-factor backward pass: 128 B of each filtered record in, the smoothed record out (1584 B per series-step); "
+                              "SURVEY 8d's 2912 B (whole filtered record in) would price the same launch at `achieved_by_contract_bytes`")
         elif cfg == "c3" and variant.endswith("-shared") and args.sampler == "reference":
             # shared factors and no filter records: the call does not move SURVEY 8d's 2920 B per series-step any more --
             # forward: y in, the compact means out (512 B per four series); draw: those means and the normals in.  The bytes MOVED:
@@ -491,7 +504,7 @@ def run_one(args, ctx):
         scale = 1e9 if unit == "GB/s" else 1e12
         achieved = dom_u * nt / (dom_ms * 1e-3) / scale
         short = {"sparse16": "sp16", "mfma16": "mfma16", "wave-mfma": "w48", "tiled-mfma": "tiled", "sparse16-sampler": "sp16", "sparse16-rts": "rts16", "wave-sampler": "w48", "wave-simsmooth": "w48",
-                 "sparse16-simsmooth": "sp16", "svd-jacobi": "", "sparse16-sampler-shared": "sp16", "wave-sampler-shared": "w48"}.get(variant, variant)
+                 "sparse16-simsmooth": "sp16", "svd-jacobi": "", "sparse16-sampler-shared": "sp16", "wave-sampler-shared": "w48", "sparse16-rts-shared": "rts16"}.get(variant, variant)
         kname = (names[1] if dom_is_bwd else names[0]) + short
         workloads = {
             "c2": f"C2: seasonal DLM polynomial(1)|+|seasonal(24,6), d=13, p=1, {job_series} series x T={T}, fused filter+smooth (dlm_filter_smooth_batch)",
@@ -524,6 +537,8 @@ def run_one(args, ctx):
                          "forward_ms": f_ms, "backward_ms": b_ms},
             "status_nonzero_series": status_bad,
         }
+        if cfg == "c2" and variant == "sparse16-rts-shared" and dom_is_bwd:
+            line["roofline"]["achieved_by_contract_bytes"] = 16.0 * recw * nt / (dom_ms * 1e-3) / scale
         tr_bytes, tr_note = traffic_from_profiles(kname, args)
         line["roofline"]["traffic"] = tr_bytes
         if tr_note:

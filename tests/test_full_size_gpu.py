@@ -20,11 +20,20 @@ def eng():
     return Engine(0)
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_device_memory():
+    """The outputs of a full-size call are 29 GB apiece: hand torch's cached blocks back after every test, or the engine's own hipMalloc
+    (workspaces of the next configuration) finds the device full."""
+    yield
+    import torch
+    torch.cuda.empty_cache()
+
+
 def _om(mat):
     return oracle.Model(mat.d, mat.p, mat.T, mat.F, mat.G, mat.g_index, mat.dt, mat.f_stride)
 
 
-def _properties(eng, mat, p, y, pick, expect_variant, tol_f, tol_s):
+def _properties(eng, mat, p, y, pick, expect_variant, tol_f, tol_s, sub_flags=_lib.OPT_FORCE_WAVE):
     import torch
     d = mat.d
     out = eng.filter_smooth(mat, p, y)
@@ -42,8 +51,9 @@ def _properties(eng, mat, p, y, pick, expect_variant, tol_f, tol_s):
     S = sm[:64, :, d:].reshape(64, T1, d, d)
     assert float((S - S.transpose(-1, -2)).abs().max()) <= 1e-9 * float(S.abs().max())
     # (i) independence: the picked series on their own, bit for bit
-    # the same kernels as the full batch: a handful of series alone would take the workgroup-per-series kernels at d >= 16
-    sub = eng.filter_smooth(mat, p, y[pick], flags=_lib.OPT_FORCE_WAVE)
+    # the same kernels as the full batch: a handful of series alone would take the workgroup-per-series kernels at d >= 16, and at d <= 15
+    # their own covariance recursions instead of the call's shared tables (DLM_OPT_NO_SMALL_BATCH: the large batch's route)
+    sub = eng.filter_smooth(mat, p, y[pick], flags=sub_flags)
     assert torch.equal(sub["filt"], filt[pick]) and torch.equal(sub["smooth"], sm[pick])
     # (iv) oracle at full length
     for n in pick[:2]:
@@ -65,7 +75,10 @@ def test_c2_full_size_properties(eng):
     yh = simulate(mat, p, 10000, seed=20261004)
     yh[np.random.default_rng(1).random(yh.shape) < 0.03] = np.nan
     y = torch.as_tensor(yh, device="cuda")
-    _properties(eng, mat, p, y, [0, 4999, 9999, 1234, 7777], "sparse16", 1e-8, 1e-7)
+    # (every series has a gap: the call decides on the device to make no tables and runs the per-series kernels)
+    _properties(eng, mat, p, y, [0, 4999, 9999, 1234, 7777], "sparse16-rts-shared", 1e-8, 1e-7, _lib.OPT_NO_SMALL_BATCH)
+    eng.filter_smooth(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2:] == (0, 10000)
 
 
 def test_c2_full_size_steady_state_path(eng):
@@ -77,8 +90,15 @@ def test_c2_full_size_steady_state_path(eng):
     mod, p = seasonal_c2()
     mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
     y = torch.as_tensor(simulate(mat, p, 10000, seed=20261005), device="cuda")
-    _properties(eng, mat, p, y, [0, 4999, 9999, 4321], "sparse16", 1e-8, 1e-7)
-    a = eng.filter_smooth(mat, p, y)
+    _properties(eng, mat, p, y, [0, 4999, 9999, 4321], "sparse16-rts-shared", 1e-8, 1e-7, _lib.OPT_NO_SMALL_BATCH)   # J_t, S_t from the call's tables
+    own = eng.filter_smooth(mat, p, y, flags=_lib.OPT_SMOOTHER_PER_SERIES | _lib.OPT_COUNT_STEPS)                   # every series its own (information form)
+    assert eng.last_variant == "sparse16" and eng.last_counters()[2:] == (0, 0)
+    a = eng.filter_smooth(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
+    assert eng.last_counters()[2:] == (10000, 0)
+    assert torch.equal(a["filt"], own["filt"])
+    assert float((a["smooth"] - own["smooth"]).abs().max()) <= 1e-10 * float(own["smooth"].abs().max())
+    del own
+    torch.cuda.empty_cache()
     C = a["filt"][:, :, 13:]
     assert torch.equal(C[:, 900], C[:, 600])                       # frozen covariances on the settled stretch
     b = eng.filter_smooth(mat, p, y, flags=_lib.OPT_NO_STEADY)

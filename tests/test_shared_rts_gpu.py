@@ -1,4 +1,4 @@
-"""Shared factors of the literal-Q1 smoother ("next round" 9).
+"""Shared factors of the RTS smoother, literal Q1 and textbook ("next round" 9).
 
 `DLM_OPT_SMOOTHER_COMPAT_Q1` selects Smoothing.scala:44 as written (S_t = C_t + J_t (S_{t+1} - R_{t+1}) J_t, no transpose).  J_t and S_t
 depend on V, W, C0 and the grid, not on the data: where the batch shares them, `k_smoother_rts16` runs once per call on the filter
@@ -40,7 +40,7 @@ def c2(T, wscale=1.0):
 def both(eng, mat, p, y, flags=0):
     sh = eng.filter_smooth(mat, p, y, flags=flags | Q1 | _lib.OPT_COUNT_STEPS)
     cnt = eng.last_counters()
-    assert eng.last_variant == "sparse16-rts"
+    assert eng.last_variant == "sparse16-rts-shared"
     ps = eng.filter_smooth(mat, p, y, flags=flags | Q1 | _lib.OPT_SMOOTHER_PER_SERIES | _lib.OPT_COUNT_STEPS)
     assert eng.last_counters()[2:] == (0, 0)
     return sh, ps, cnt
@@ -54,7 +54,7 @@ def same(a, b, what):
                          f"series {np.unique(ne[:, 0])[:8].tolist()}, t in [{ne[:, 1].min()}, {ne[:, 1].max()}], entries {np.unique(ne[:, 2])[:8].tolist()}")
 
 
-@pytest.mark.parametrize("flags", [0, _lib.OPT_NO_STEADY])
+@pytest.mark.parametrize("flags", [0])
 @pytest.mark.parametrize("T,N", [(1000, 37), (1, 5), (2, 3), (3, 4), (40, 9), (63, 4), (64, 1), (65, 6), (129, 300), (700, 2)])
 def test_bit_for_bit_with_the_per_series_kernel(eng, T, N, flags):
     mat, p = c2(T)
@@ -179,3 +179,98 @@ def test_a_batch_above_the_threshold_takes_the_shared_route_by_default(eng):
     ps = eng.filter_smooth(mat, p, y, flags=_lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_SMOOTHER_PER_SERIES)
     same(sh["filt"], ps["filt"], "filtered records")
     same(sh["smooth"], ps["smooth"], "smoothed records")
+
+
+def test_every_step_in_full_means_every_series_its_own(eng):
+    """DLM_OPT_NO_STEADY asks for the reference's work, every series' own recursion at every step: the tables are not used."""
+    T, N = 80, 1100
+    mat, p = c2(T)
+    y = np.random.default_rng(13).standard_normal((N, T, 1)).cumsum(axis=1) * 0.3
+    for sem in (_lib.OPT_SMOOTHER_COMPAT_Q1, 0):
+        eng.filter_smooth(mat, p, y, flags=sem | _lib.OPT_NO_SMALL_BATCH | _lib.OPT_NO_STEADY | _lib.OPT_COUNT_STEPS)
+        assert eng.last_counters()[2:] == (0, 0)
+        assert eng.last_variant in ("sparse16", "sparse16-rts")
+
+
+# ---- the textbook covariance (the default semantics) through the same tables ----------------------------------------------------------
+
+TB = _lib.OPT_NO_SMALL_BATCH
+
+
+@pytest.mark.parametrize("T,N", [(1000, 37), (1, 5), (2, 3), (65, 6), (129, 300)])
+def test_textbook_through_the_tables_is_the_rts_kernel_bit_for_bit_and_the_default_kernel_to_rounding(eng, T, N):
+    """Above 8192 series (DLM_OPT_NO_SMALL_BATCH here) the DEFAULT call takes the tables: S = C - J (R+ - S+) J^T from k_smoother_rts16's table
+    run, the means from k_mean_rts16.  Equal bit for bit to the per-series RTS kernel on the same filter records (dlm_smooth_batch); equal to
+    the default per-series kernel (information form, k_smoother_sp16) and to the oracle within rounding."""
+    mat, p = c2(T)
+    rng = np.random.default_rng(T + N)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3 + rng.standard_normal((N, T, 1))
+    sh = eng.filter_smooth(mat, p, y, flags=TB | _lib.OPT_COUNT_STEPS)
+    cnt = eng.last_counters()
+    assert eng.last_variant == "sparse16-rts-shared" and cnt[2] == N and cnt[3] == 0, (eng.last_variant, cnt)
+    own = eng.filter_smooth(mat, p, y, flags=TB | _lib.OPT_SMOOTHER_PER_SERIES | _lib.OPT_COUNT_STEPS)
+    assert eng.last_variant == "sparse16" and eng.last_counters()[2:] == (0, 0)
+    same(sh["filt"], own["filt"], "filtered records")
+    rts = eng.smooth(mat, p, sh["filt"])
+    assert eng.last_variant == "sparse16-rts"
+    same(sh["smooth"], rts["smooth"], "smoothed records against the per-series RTS kernel")
+    scale = np.abs(own["smooth"]).max()
+    assert np.abs(sh["smooth"] - own["smooth"]).max() <= 1e-9 * scale
+    n = N // 2
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n])
+    s = oracle.smoother(omodel(mat), f)
+    np.testing.assert_allclose(sh["smooth"][n][:, :13], s["s"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(sh["smooth"][n][:, 13:], s["S"], rtol=1e-8, atol=1e-9)
+
+
+def test_textbook_routes_gaps_and_keeps_the_default_below_the_threshold(eng):
+    T, N = 200, 41
+    mat, p = c2(T)
+    rng = np.random.default_rng(21)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3
+    y[3, 50:60, 0] = np.nan
+    y[40, T - 1, 0] = np.nan
+    sh = eng.filter_smooth(mat, p, y, flags=TB | _lib.OPT_COUNT_STEPS)
+    cnt = eng.last_counters()
+    assert cnt[2] == N - 2 and cnt[3] == 2, cnt
+    rts = eng.smooth(mat, p, sh["filt"])
+    own = eng.filter_smooth(mat, p, y, flags=TB | _lib.OPT_SMOOTHER_PER_SERIES)
+    gap = np.zeros(N, bool); gap[[3, 40]] = True
+    same(sh["smooth"][~gap], rts["smooth"][~gap], "smoothed records against the per-series RTS kernel")
+    same(sh["smooth"][gap], own["smooth"][gap], "series with a gap: the information-form kernel's records, as without the tables")
+    same(sh["filt"], own["filt"], "filtered records")
+    for n in (3, 40, 0):
+        f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[n])
+        s = oracle.smoother(omodel(mat), f)
+        np.testing.assert_allclose(sh["smooth"][n][:, :13], s["s"], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(sh["smooth"][n][:, 13:], s["S"], rtol=1e-8, atol=1e-9)
+    # no flag, 41 series: the per-series information-form kernel as before
+    eng.filter_smooth(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
+    assert eng.last_variant == "sparse16" and eng.last_counters()[2:] == (0, 0)
+    # the smoothed moments alone (filt = NULL): the per-series path, whose filtered records stay packed in a workspace
+    eng.filter_smooth(mat, p, y, flags=TB | _lib.OPT_COUNT_STEPS, want_filt=False)
+    assert eng.last_variant == "sparse16" and eng.last_counters()[2:] == (0, 0)
+
+
+@pytest.mark.parametrize("sem", [0, _lib.OPT_SMOOTHER_COMPAT_Q1])
+def test_a_batch_whose_series_mostly_have_gaps_makes_no_tables(eng, sem):
+    """More than half of the series with a missing observation: decided on the device -- the table kernels return at once and every series takes
+    the per-series kernel (the counters say so); exactly half: the tables serve the other half."""
+    T, N = 120, 20
+    mat, p = c2(T)
+    rng = np.random.default_rng(31)
+    y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3
+    own = None
+    for ngap in (11, 10):
+        yy = y.copy()
+        yy[:ngap, 40, 0] = np.nan
+        sh = eng.filter_smooth(mat, p, yy, flags=sem | TB | _lib.OPT_COUNT_STEPS)
+        cnt = eng.last_counters()
+        assert (cnt[2], cnt[3]) == ((0, N) if ngap == 11 else (N - ngap, ngap)), (ngap, cnt)
+        own = eng.filter_smooth(mat, p, yy, flags=sem | TB | _lib.OPT_SMOOTHER_PER_SERIES)
+        if ngap == 11 or sem:
+            same(sh["smooth"], own["smooth"], "smoothed records")
+        else:
+            same(sh["smooth"][:ngap], own["smooth"][:ngap], "smoothed records of the series with a gap")
+            assert np.abs(sh["smooth"] - own["smooth"]).max() <= 1e-9 * np.abs(own["smooth"]).max()
+        same(sh["filt"], own["filt"], "filtered records")
