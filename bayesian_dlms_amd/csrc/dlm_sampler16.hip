@@ -1375,11 +1375,12 @@ hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs
 #define DLM_RTS_SHARED_MIN 1024            // literal Q1: against k_smoother_rts16 per series
 #endif
 #ifndef DLM_RTS_SHARED_MIN_TEXTBOOK
-#define DLM_RTS_SHARED_MIN_TEXTBOOK 8192   // textbook covariance: against k_smoother_sp16 per series
+#define DLM_RTS_SHARED_MIN_TEXTBOOK 6144   // textbook covariance: against k_smoother_sp16 per series
 #endif
 // The table run is one wave's 2.3 ms (C2, T = 1000) whatever the batch: what the batch must be worth.  Literal Q1: below one wave per SIMD
-// the per-series kernel takes what the table run takes and the mean kernel comes on top (3.0 against 3.3 ms at 8 series).  Textbook: the
-// per-series information-form kernel takes 4.6 ms at 5000 series, 6.8 at 7500, 9.0 at 10 000 against 5.3 / 6.5 / 7.8 ms through the tables.
+// the per-series kernel takes what the table run takes and the mean kernel comes on top (3.0 against 3.3 ms at 8 series).  Textbook
+// (tools/sweep_rts_threshold.sh, profiles/r04_rts_threshold.json): the per-series information-form kernels take 4.79 / 6.56 / 7.46 / 9.27 / 17.6 ms at
+// 5000 / 6500 / 7500 / 10 000 / 20 000 series against 5.48 / 6.25 / 6.71 / 7.96 / 15.3 ms through the tables: from six waves per SIMD.
 // DLM_OPT_NO_STEADY asks for every series' own recursion at every step: never through the tables.
 bool rts_shared_eligible(const KArgs& a, bool textbook) {
   return sampler_shared_model_ok(a) && a.y && !(a.flags & (DLM_OPT_FORCE_GENERIC | DLM_OPT_SMOOTHER_PER_SERIES | DLM_OPT_NO_STEADY)) &&
@@ -1414,14 +1415,18 @@ hipError_t launch_rts_shared_cov(const KArgs& a, int K, const SparseT* tabs_dev,
 // becomes resident beside it.  A table run is ONE wave whose dependent chain is what the call waits for; on a CU it shares with eight waves
 // per SIMD of the batch's forward pass it queues behind their MFMAs (64 cycles of the pipe each) and LDS traffic at every link of the chain
 // (measured: 1.8 ms alone, 4.5 ms beside k_filter_sp16).  One CU of 256 is what the isolation costs the batch.
-template <class F>
+template <int TAG, class F>   // TAG: one static per kernel (instantiations of one template share their function type)
 static size_t whole_cu_lds(F kernel) {
-  hipFuncAttributes at;
-  if (hipFuncGetAttributes(&at, (const void*)kernel) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  const size_t whole = 160 * 1024;
-  if (at.sharedSizeBytes >= whole) return 0;
-  const size_t dyn = whole - at.sharedSizeBytes;
-  if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  auto ask = [&]() -> size_t {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, (const void*)kernel) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const size_t whole = 160 * 1024;
+    if (at.sharedSizeBytes >= whole) return 0;
+    const size_t dyn = whole - at.sharedSizeBytes;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return dyn;
+  };
+  static const size_t dyn = ask();
   return dyn;
 }
 hipError_t launch_rts_shared_tables(const KArgs& a, int K, const SparseT* tabs_dev, const RtsTabs& tb, hipStream_t s) {
@@ -1429,10 +1434,10 @@ hipError_t launch_rts_shared_tables(const KArgs& a, int K, const SparseT* tabs_d
   kp.N = 1; kp.y = nullptr; kp.m0_stride = 0; kp.filt_in = nullptr; kp.filt = nullptr; kp.smooth = tb.srec; kp.status = tb.status; kp.stats = nullptr; kp.loglik = nullptr;
   kp.prior = nullptr; kp.fq = nullptr; kp.route = nullptr; kp.counters = nullptr; kp.theta = nullptr; kp.z = nullptr; kp.series_offset = 0; kp.plain = nullptr;
   switch (K) {
-    case 1: hipLaunchKernelGGL((s16::k_smoother_rts16<1, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<1, SparseT, true>), s, kp, tabs_dev, tb); break;
-    case 2: hipLaunchKernelGGL((s16::k_smoother_rts16<2, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<2, SparseT, true>), s, kp, tabs_dev, tb); break;
-    case 3: hipLaunchKernelGGL((s16::k_smoother_rts16<3, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<3, SparseT, true>), s, kp, tabs_dev, tb); break;
-    case 4: hipLaunchKernelGGL((s16::k_smoother_rts16<4, SparseT, true>), dim3(1), dim3(64), whole_cu_lds(s16::k_smoother_rts16<4, SparseT, true>), s, kp, tabs_dev, tb); break;
+    case 1: hipLaunchKernelGGL((s16::k_smoother_rts16<1, SparseT, true>), dim3(1), dim3(64), whole_cu_lds<1>(s16::k_smoother_rts16<1, SparseT, true>), s, kp, tabs_dev, tb); break;
+    case 2: hipLaunchKernelGGL((s16::k_smoother_rts16<2, SparseT, true>), dim3(1), dim3(64), whole_cu_lds<2>(s16::k_smoother_rts16<2, SparseT, true>), s, kp, tabs_dev, tb); break;
+    case 3: hipLaunchKernelGGL((s16::k_smoother_rts16<3, SparseT, true>), dim3(1), dim3(64), whole_cu_lds<3>(s16::k_smoother_rts16<3, SparseT, true>), s, kp, tabs_dev, tb); break;
+    case 4: hipLaunchKernelGGL((s16::k_smoother_rts16<4, SparseT, true>), dim3(1), dim3(64), whole_cu_lds<4>(s16::k_smoother_rts16<4, SparseT, true>), s, kp, tabs_dev, tb); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

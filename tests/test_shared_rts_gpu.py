@@ -199,7 +199,7 @@ TB = _lib.OPT_NO_SMALL_BATCH
 
 @pytest.mark.parametrize("T,N", [(1000, 37), (1, 5), (2, 3), (65, 6), (129, 300)])
 def test_textbook_through_the_tables_is_the_rts_kernel_bit_for_bit_and_the_default_kernel_to_rounding(eng, T, N):
-    """Above 8192 series (DLM_OPT_NO_SMALL_BATCH here) the DEFAULT call takes the tables: S = C - J (R+ - S+) J^T from k_smoother_rts16's table
+    """From 6144 series (DLM_OPT_NO_SMALL_BATCH here) the DEFAULT call takes the tables: S = C - J (R+ - S+) J^T from k_smoother_rts16's table
     run, the means from k_mean_rts16.  Equal bit for bit to the per-series RTS kernel on the same filter records (dlm_smooth_batch); equal to
     the default per-series kernel (information form, k_smoother_sp16) and to the oracle within rounding."""
     mat, p = c2(T)
