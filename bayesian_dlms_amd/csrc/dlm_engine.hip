@@ -1145,6 +1145,8 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   if ((rc = mark(e, 0))) return rc;
   dlm::RtsTabs rtb{};
   if (rts_shared && (rc = start_rts_tables(e, k, rtb))) return rc;
+  if (rts_shared && (k.flags & DLM_OPT_TEST_FAIL_AFTER_TABLES))   // test hook: an error exit with the second stream busy
+    return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_TEST_FAIL_AFTER_TABLES");
   if ((rc = mark_plain(e, k))) return rc;
   if (filt && fast_smoother_ok(e, k) && use_shared_cov(e, k)) {
     dlm::CovTabs tb;

@@ -87,7 +87,7 @@ enum {
   DLM_OPT_SMOOTHER_PER_SERIES = 1u << 28, /* dlm_filter_smooth_batch with DLM_OPT_SMOOTHER_COMPAT_Q1, structured d <= 15, p = 1: every series computes its own J_t and
                                            S_t, also when the batch shares V, W, C0 on a regular grid (by default they are computed once per call and every series
                                            without a missing observation runs only its mean recursion: the same records, bit for bit) */
-  DLM_OPT_TEST_FAIL_AFTER_TABLES = 1u << 30, /* TEST HOOK (tests/test_shared_sampler_gpu.py): dlm_ffbs_batch returns DLM_ERR_UNSUPPORTED right after it has started the
+  DLM_OPT_TEST_FAIL_AFTER_TABLES = 1u << 30, /* TEST HOOK (tests/test_shared_sampler_gpu.py, test_shared_rts_gpu.py): dlm_ffbs_batch / dlm_filter_smooth_batch return DLM_ERR_UNSUPPORTED right after they have started the
                                            shared-factor tables and normals on the engine's auxiliary streams -- the error path that must leave the engine usable */
   DLM_OPT_SHARED_COV = 1u << 24         /* d <= 15, p = 1, regular grid, V, W, C0 shared by the batch: ONE wave runs the covariance recursions, every series
                                            only its mean recursions against their tables; a series with a missing observation runs its own recursion

@@ -274,3 +274,52 @@ def test_a_batch_whose_series_mostly_have_gaps_makes_no_tables(eng, sem):
             same(sh["smooth"][:ngap], own["smooth"][:ngap], "smoothed records of the series with a gap")
             assert np.abs(sh["smooth"] - own["smooth"]).max() <= 1e-9 * np.abs(own["smooth"]).max()
         same(sh["filt"], own["filt"], "filtered records")
+
+
+def test_asynchronous_calls_back_to_back_and_an_engine_destroyed_with_the_tables_in_flight():
+    """Rules A and B of DESIGN.md 4.12 on this route: DLM_OPT_ASYNC calls of different sizes one behind the other on one engine (the second re-carves
+    the tables' workspace while the first call's kernels may still run on two streams), then an engine closed right after such a call."""
+    import torch
+    from bayesian_dlms_amd.engine import Engine
+    rng = np.random.default_rng(17)
+    e2 = Engine(0)
+    calls = []
+    for T, N, sem in ((300, 3000, 0), (500, 1500, _lib.OPT_SMOOTHER_COMPAT_Q1), (200, 6000, 0), (500, 1500, 0)):
+        mat, p = c2(T)
+        yd = torch.as_tensor(rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3, device="cuda:0")
+        out = e2.filter_smooth(mat, p, yd, flags=sem | TB | _lib.OPT_ASYNC)
+        assert e2.last_variant == "sparse16-rts-shared"
+        calls.append((mat, p, yd, sem, out))
+    e2.sync()
+    for mat, p, yd, sem, out in calls:
+        ref = e2.filter_smooth(mat, p, yd, flags=sem | TB)
+        assert torch.equal(out["smooth"], ref["smooth"]) and torch.equal(out["filt"], ref["filt"])
+        assert int(out["status"].abs().sum().item()) == 0
+    mat, p, yd, sem, _ = calls[2]
+    out = e2.filter_smooth(mat, p, yd, flags=TB | _lib.OPT_ASYNC)
+    e2.close()                                            # the table run and the batch's kernels are in flight
+    torch.cuda.synchronize()
+    assert torch.equal(out["smooth"], calls[2][4]["smooth"])
+    e3 = Engine(0)                                        # the device is fine afterwards
+    ref = e3.filter_smooth(mat, p, yd, flags=TB)
+    assert torch.equal(ref["smooth"], out["smooth"])
+    e3.close()
+
+
+def test_an_error_exit_with_the_table_run_in_flight_leaves_the_engine_usable(eng):
+    """DLM_OPT_TEST_FAIL_AFTER_TABLES: the call fails right after it has started the covariance filter and the table run.  The next calls -- a larger
+    one that re-sizes the tables' workspace, then the call itself -- are bit for bit what a fresh engine gives (rule A: the exit joined the stream)."""
+    from bayesian_dlms_amd.engine import EngineError
+    rng = np.random.default_rng(23)
+    for sem in (0, _lib.OPT_SMOOTHER_COMPAT_Q1):
+        mat, p = c2(400)
+        y = rng.standard_normal((600, 400, 1)).cumsum(axis=1) * 0.3
+        ref = eng.filter_smooth(mat, p, y, flags=sem | TB)
+        with pytest.raises(EngineError):
+            eng.filter_smooth(mat, p, y, flags=sem | TB | _lib.OPT_TEST_FAIL_AFTER_TABLES)
+        mat2, p2 = c2(700)
+        big = eng.filter_smooth(mat2, p2, np.concatenate([y, y[:, ::-1]], axis=1)[:, :700], flags=sem | TB)
+        assert np.all(big["status"] == 0)
+        out = eng.filter_smooth(mat, p, y, flags=sem | TB)
+        same(out["smooth"], ref["smooth"], "smoothed records after the failed call")
+        same(out["filt"], ref["filt"], "filtered records after the failed call")
