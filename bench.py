@@ -87,10 +87,7 @@ def profile_tag(args):
     opts = [(args.flags != 0, f"flags{args.flags}"), (args.missing > 0.0, "missing" + str(args.missing).replace(".", "")),
             (args.semantics != "textbook", "semantics" + args.semantics.replace("-", "")), (args.series is not None, f"series{args.series}"),
             (args.config in ("c3", "c4g") and args.sampler != "reference", "sampler" + args.sampler)]
-    on = [name for cond, name in opts if cond]
-    if len(on) > 1:
-        return None
-    return tag + (on[0] if on else "")
+    return tag + "".join(name for cond, name in opts if cond)   # (several options: in this order, as the script lists them)
 
 
 def traffic_from_profiles(kernel, args):

@@ -7,7 +7,7 @@ set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r04; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 FILTER=${1:-.}
-CONFIGS=("c2" "c2 --flags 4194304" "c2 --missing 0.05" "c2 --semantics literal-q1" "c3" "c3 --flags 67108864" "c3 --series 1250" "c3 --sampler simsmooth" "c4" "c4 --flags 4194304" "c4g" "c4g --flags 67108864" "c5")
+CONFIGS=("c2" "c2 --flags 268435456" "c2 --flags 4194304" "c2 --missing 0.05" "c2 --semantics literal-q1" "c2 --flags 268435456 --semantics literal-q1" "c3" "c3 --flags 67108864" "c3 --series 1250" "c3 --sampler simsmooth" "c4" "c4 --flags 4194304" "c4g" "c4g --flags 67108864" "c5")
 for c in "${CONFIGS[@]}"; do
   tag=$(echo $c | tr -d ' -.')
   if ! echo "$tag" | grep -Eq "$FILTER"; then continue; fi
@@ -25,7 +25,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", ".")
 def source_of(k):
     if "svd" in k: return "dlm_svd.hip"
     if "w48" in k: return "dlm_wave48.hip"
-    if any(s in k for s in ("k_sampler_sp16", "k_mean_sampler_sp16", "k_smoother_rts16", "k_normals4", "k_mark_gaps")): return "dlm_sampler16.hip"
+    if any(s in k for s in ("k_sampler_sp16", "k_mean_sampler_sp16", "rts16", "k_rts_decide", "k_normals4", "k_mark_gaps")): return "dlm_sampler16.hip"
     if "sp16" in k or "k_count_gaps" in k: return "dlm_sparse16.hip"
     if "tiled" in k: return "dlm_tiled.hip"
     if "generic" in k or "stats_pool" in k: return "dlm_generic.hip"
