@@ -789,6 +789,175 @@ __global__ __launch_bounds__(256) void k_svd_mean_filter(KArgs a, const double* 
   if (a.status && lane == 0 && st) atomicOr(&a.status[n], st);
 }
 
+// ---------------------------------------------------------------------------------------
+// The same mean recursion, four series per wave (round 4): lane 16 j + c = component c of series j of the wave's four consecutive series.
+// k_svd_mean_filter above gives a whole wave to one series and 13 of its 64 lanes to the arithmetic: 10 000 waves of ~200 instructions per
+// step are issue-bound (6.7 ms for 15.7 GB of records: 2.3 TB/s).  Here the table row is shared by four series (one LDS DMA, broadcast
+// reads), every operation of a series' step is the one of k_svd_mean_filter in the same order -- a = G m, f = F^T a, e, tv = vv e,
+// gs = F tv, yv_i = dc_i^2 sum_l uc[l][i] gs_l, m_i = a_i + sum_l uc[i][l] yv_l, all sums ascending from their first term -- so the records
+// are the same bits, and the four records leave as one stream of 8-byte stores (records are 2 d + d^2 doubles: 8-byte aligned only).
+// NS: store instructions per step = ceil(4 (2 d + d^2) / 64) rounded up to 4, 8, 13 or 18 (an instruction whose lanes all lie beyond the
+// records is still issued: the waits count it).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double svd_row_pick(double v, int lane, int src) {   // the value of lane src (0..15, wave-uniform) of this lane's 16-lane row
+  const int a_ = ((lane & 48) + src) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(a_, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(a_, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int NS>
+__global__ __launch_bounds__(64, 3) void k_svd_mean_filter4(KArgs a, const double* __restrict__ tab, int tstride, const double* __restrict__ aux,
+                                                            const int* __restrict__ cov_status, double* __restrict__ rec_out) {
+  extern __shared__ __attribute__((aligned(16))) char ring[];      // two table slots of tstride doubles (+ 16 bytes each)
+  __shared__ __attribute__((aligned(16))) double lds[5 * 64];
+  const int lane = threadIdx.x, j = lane >> 4, c = lane & 15;
+  const int n0 = 4 * blockIdx.x;
+  if (n0 >= a.N) return;
+  const int nser = a.N - n0 < 4 ? a.N - n0 : 4;
+  const bool have = j < nser;
+  const int n = have ? n0 + j : n0;                 // (a row without a series shadows the first: loads stay in bounds, nothing is stored)
+  const int d = a.d, T = a.T, dd = d * d, srec = 2 * d + dd, rowb = tstride * 8;
+  const bool vc = c < d;
+  double* vM = lds;            // m   [4][16]
+  double* vA = vM + 64;        // a
+  double* vG = vA + 64;        // gs
+  double* vY = vG + 64;        // yv
+  double* vF = vY + 64;        // F (16), then unused
+  const double* m0 = a.m0 + (size_t)n * a.m0_stride;
+  const double* y = a.y + (size_t)n * T;
+  const size_t sbytes = (size_t)(T + 1) * srec * 8;
+  const int OOBo = 0x7ffffff0;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((char*)rec_out + (size_t)n0 * sbytes, 0, (int)((size_t)nser * sbytes), 0x00020000);
+  double Gi[16];               // row c of G
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Gi[k] = (vc && k < d) ? a.G[c + k * d] : 0.0;
+  const double s00 = aux[0];
+  const double vv = fma(s00, s00, 0.0);               // (vm^T vm)[0][0]
+  const double Fl = vc ? a.F[c] : 0.0;
+  if (lane < 16) vF[lane] = Fl;
+  const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ring;
+  const unsigned vM_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)vM;
+  const unsigned long long ta = (unsigned long long)tab;
+  const i4s rtab = {__builtin_amdgcn_readfirstlane((int)(unsigned)ta), __builtin_amdgcn_readfirstlane((int)(unsigned)((ta >> 32) & 0xffffu)),
+                    __builtin_amdgcn_readfirstlane((int)((size_t)(T + 1) * rowb)), 0x00020000};
+  const int n16 = rowb / 16;
+  bool dead = !have;
+  // the four records as one stream of doubles: double q = 64 k + lane is double q % srec of series q / srec; the first d of a record are its mean (vM)
+  unsigned psrc[NS];
+  int pdst[NS], pser[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int q = 64 * k + lane, sj = q / srec, pp = q - sj * srec;
+    pser[k] = sj < 4 ? sj : 4;
+    pdst[k] = sj < nser ? (int)((size_t)sj * sbytes) + pp * 8 : OOBo;
+    psrc[k] = pp < d ? (0x80000000u | (unsigned)((16 * (sj & 3) + pp) * 8)) : (unsigned)(pp * 8);
+  }
+  unsigned deadmask = 0;
+  auto read_doubles = [&](unsigned slot, double (&v)[NS]) {   // this lane's doubles of the four records: the means from vM, the rest from the table row
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const unsigned ad = (psrc[k] & 0x80000000u) ? vM_lds + (psrc[k] & 0x7fffffffu) : slot + psrc[k];
+      asm volatile("ds_read_b64 %0, %1" : "=v"(v[k]) : "v"(ad) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < NS; ++k) asm volatile("" : "+v"(v[k]));
+  };
+  auto store_doubles = [&](const double (&v)[NS], int so, unsigned dm) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const unsigned lo = (unsigned)__double2loint(v[k]), hi = (unsigned)__double2hiint(v[k]);
+      const unsigned __attribute__((ext_vector_type(2))) w = {lo, hi};
+      __builtin_amdgcn_raw_buffer_store_b64(w, rout, ((dm >> pser[k]) & 1u) ? OOBo : pdst[k], so, 0);
+    }
+  };
+  svd_dma_row(rtab, ring_lds, 0, lane, n16);
+  svd_dma_row(rtab, ring_lds + rowb + 16, rowb, lane, n16);
+  double mi = vc ? m0[c] : 0.0;
+  vM[lane] = mi;
+  double yk[4];                                      // the observations of this row's series, 64 steps at a time
+#pragma unroll
+  for (int k = 0; k < 4; ++k) yk[k] = (16 * k + c < T) ? y[16 * k + c] : 0.0;
+  asm volatile("" ::"v"(yk[0]), "v"(yk[1]), "v"(yk[2]), "v"(yk[3]));
+  ssync();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows 0 and 1
+  {   // record 0: [m0 | dc0 | uc0]
+    deadmask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) deadmask |= (__builtin_amdgcn_readlane((int)dead, 16 * q) & 1) << q;
+    deadmask |= 16u;
+    double v[NS];
+    read_doubles(ring_lds, v);
+    svd_dma_row(rtab, ring_lds, (T >= 2 ? 2 : T) * rowb, lane, n16);
+    store_doubles(v, 0, deadmask);
+  }
+  for (int t = 0; t < T; ++t) {
+    if (t > 0 && (t & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) yk[k] = (t + 16 * k + c < T) ? y[t + 16 * k + c] : 0.0;
+      asm volatile("" ::"v"(yk[0]), "v"(yk[1]), "v"(yk[2]), "v"(yk[3]));
+    }
+    const int kk = (t >> 4) & 3;
+    const double yt = svd_row_pick(kk == 0 ? yk[0] : kk == 1 ? yk[1] : kk == 2 ? yk[2] : yk[3], lane, t & 15);
+    if (!dead && !(yt == yt)) {   // a missing observation: the factors of this series are its own -- k_svd_filter takes it (all of it)
+      dead = true;
+      if (c == 0) a.route[n] = 1;
+    }
+    deadmask = 16u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) deadmask |= (__builtin_amdgcn_readlane((int)dead, 16 * q) & 1) << q;
+    if ((deadmask & 15u) == 15u) break;
+    // operations issued after the request for row t + 1: the NS stores of record t - 1, the request for row t + 2 (>= 1), the NS stores of record t
+    if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS + 1) : "memory");
+    const unsigned slot = ring_lds + ((t + 1) & 1) * (rowb + 16);
+    const double* row = (const double*)(ring + ((t + 1) & 1) * (rowb + 16));
+    // a = G m
+    double ai = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < d) ai = fma(Gi[k], vM[16 * j + k], ai);
+    vA[lane] = vc ? ai : 0.0;
+    ssync();
+    double fs = 0.0;
+    for (int k = 0; k < d; ++k) fs = fma(vF[k], vA[16 * j + k], fs);
+    const double e = yt - fs;
+    const double tv = fma(vv, e, 0.0);
+    vG[lane] = vc ? fma(Fl, tv, 0.0) : 0.0;              // gs = F tv
+    ssync();
+    double yv = 0.0;
+    if (vc) {
+      double s_ = 0.0;
+      for (int l = 0; l < d; ++l) s_ = fma(row[2 * d + l + c * d], vG[16 * j + l], s_);   // uc[l][i]
+      const double dci = row[d + c];
+      yv = dci * dci * s_;
+    }
+    vY[lane] = vc ? yv : 0.0;
+    ssync();
+    if (vc) {
+      double s_ = ai;
+      for (int l = 0; l < d; ++l) s_ = fma(row[2 * d + c + l * d], vY[16 * j + l], s_);   // uc[i][l]
+      mi = s_;
+    }
+    ssync();                                             // (the reads of vM by this step's a = G m are done)
+    vM[lane] = vc ? mi : 0.0;
+    ssync();
+    double v[NS];
+    read_doubles(slot, v);
+    { const int tn = t + 3 <= T ? t + 3 : T; svd_dma_row(rtab, slot, tn * rowb, lane, n16); }
+    store_doubles(v, (t + 1) * srec * 8, deadmask);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be writing this block's LDS when the wave ends
+  int st = cov_status[0];
+  const unsigned long long badl = __ballot(!dead && vc && !isfinite(mi));
+  if (have && c == 0) {
+    if (!dead) {
+      a.route[n] = 0;
+      const int sj = st | (((badl >> (16 * j)) & 0xffffull) ? DLM_ST_NONFINITE : 0);
+      if (a.status && sj) atomicOr(&a.status[n], sj);
+    }
+  }
+  const unsigned long long live = __ballot(have && !dead && c == 0);
+  if (a.counters && lane == 0 && live) atomicAdd(&a.counters[2], (unsigned long long)__builtin_popcountll(live));
+}
+
 bool svd_shared_eligible(const KArgs& a) {
   return a.d <= 16 && a.p == 1 && !a.g_index && !a.dt && !a.f_stride && !a.v_tstride && !a.w_tstride && !a.v_stride && !a.w_stride && !a.c0_stride &&
          !(a.flags & (DLM_OPT_SVD_PER_SERIES | DLM_OPT_FORCE_GENERIC));
@@ -809,9 +978,21 @@ hipError_t launch_svd_filter_shared(const KArgs& a, double* svd_rec, double* ws,
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;
   km.route = route; km.route_take = 0;
+#ifdef DLM_SVD_MEAN_ONE_PER_WAVE
   const int wpb = 4;
   hipLaunchKernelGGL(k_svd_mean_filter, dim3((a.N + wpb - 1) / wpb), dim3(64 * wpb), (size_t)wpb * 2 * (tstride * 8 + 16), s, km, (const double*)tab, tstride,
                      (const double*)aux, (const int*)cst, svd_rec);
+#else
+  {
+    const dim3 grid((a.N + 3) / 4), blk(64);
+    const size_t ring = 2 * ((size_t)tstride * 8 + 16);
+    const int ns = (4 * srec + 63) / 64;
+    if (ns <= 4) hipLaunchKernelGGL(k_svd_mean_filter4<4>, grid, blk, ring, s, km, (const double*)tab, tstride, (const double*)aux, (const int*)cst, svd_rec);
+    else if (ns <= 8) hipLaunchKernelGGL(k_svd_mean_filter4<8>, grid, blk, ring, s, km, (const double*)tab, tstride, (const double*)aux, (const int*)cst, svd_rec);
+    else if (ns <= 13) hipLaunchKernelGGL(k_svd_mean_filter4<13>, grid, blk, ring, s, km, (const double*)tab, tstride, (const double*)aux, (const int*)cst, svd_rec);
+    else hipLaunchKernelGGL(k_svd_mean_filter4<18>, grid, blk, ring, s, km, (const double*)tab, tstride, (const double*)aux, (const int*)cst, svd_rec);
+  }
+#endif
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs kg = a;
   kg.route = route; kg.route_take = 1;
