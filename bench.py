@@ -448,13 +448,20 @@ def run_one(args, ctx):
 
     if rank == 0:
         moved_note = None
+        route_note = None
         f_ms, b_ms = float(np.mean(fwd_ms)), float(np.mean(bwd_ms))
         nt = float(N) * T
         if cfg == "c2":
             # forward: read y, write [m|C]; backward: read [m|C], write [s|S] (8p + 24 (d + d^2) = 4376 B, packed 2504)
             fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * recw, 16.0 * recw, "GB/s", HBM_PEAK_GBS, "hbm"
             names = ("k_filter_", "k_smoother_")
-            if variant == "sparse16-rts-shared":
+            tables_served = bool(steady_fraction and steady_fraction.get("shared_covariance_series", 0) * 2 > N)
+            if variant == "sparse16-rts-shared" and not tables_served:
+                # the call decided on the device to make no tables (most series have a gap): the per-series kernels ran
+                names = ("k_filter_", "k_smoother_")
+                variant = "sparse16-rts" if args.semantics == "literal-q1" else "sparse16"
+                route_note = "sparse16-rts-shared route, no tables made (decided on the device): per-series kernels"
+            elif variant == "sparse16-rts-shared":
                 # shared factors: J_t, S_t come from the call's tables; the backward kernel reads the head of a filtered record (16
                 # doubles: the mean) and writes the smoothed record -- the bytes this algorithm has to move, not SURVEY 8d's read + write of whole records
                 bwd_u = 128.0 + 8.0 * recw
@@ -534,6 +541,8 @@ def run_one(args, ctx):
                          "forward_ms": f_ms, "backward_ms": b_ms},
             "status_nonzero_series": status_bad,
         }
+        if route_note:
+            line["config"]["route_note"] = route_note
         if cfg == "c2" and variant == "sparse16-rts-shared" and dom_is_bwd:
             line["roofline"]["achieved_by_contract_bytes"] = 16.0 * recw * nt / (dom_ms * 1e-3) / scale
         tr_bytes, tr_note = traffic_from_profiles(kname, args)
