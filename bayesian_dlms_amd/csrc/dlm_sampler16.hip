@@ -1044,10 +1044,13 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
 // NP: store instructions per step (64-lane groups of 16-byte pieces covering four records, rounded up to 2, 4, 6, 8);
 // NRS / NRJ: DMA instructions per S_t record / per J row -- exact, the waits below count them.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef DLM_RTS_STORE_AUX
+#define DLM_RTS_STORE_AUX 2   // nt: the records are written once and read by nobody in this call; non-temporal stores leave the table rows and the means in L2
+#endif
 __device__ __forceinline__ void bst128(__amdgpu_buffer_rsrc_t r, int voff, int soff, d2 x) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   const u4 v = {(unsigned)__double2loint(x[0]), (unsigned)__double2hiint(x[0]), (unsigned)__double2loint(x[1]), (unsigned)__double2hiint(x[1])};
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, DLM_RTS_STORE_AUX);
 }
 __device__ __forceinline__ d2 lds_read128v(unsigned addr) {
   d2 v;
