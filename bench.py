@@ -504,6 +504,10 @@ def run_one(args, ctx):
             fwd_u, bwd_u, unit, peak, bound = 8.0 * q + 8.0 * (2 * d + d * d), 0.0, "GB/s", HBM_PEAK_GBS, "hbm"
             names = ("k_svd_filter", "")
         dom_is_bwd = b_ms >= f_ms and bwd_u > 0
+        if cfg == "c2" and variant == "sparse16-rts-shared":
+            # forward_ms of this route is three kernels and a wait (covariance-only filter 0.22 ms + k_filter_sp16 2.9 + what is left of the table run);
+            # backward_ms is ONE launch, k_mean_rts16, the longest kernel of the call: that is the kernel priced here
+            dom_is_bwd = True
         dom_u, dom_ms = (bwd_u, b_ms) if dom_is_bwd else (fwd_u, f_ms)
         scale = 1e9 if unit == "GB/s" else 1e12
         achieved = dom_u * nt / (dom_ms * 1e-3) / scale
