@@ -576,6 +576,9 @@ def run_one(args, ctx):
                      # the fraction of the copy rate is that of the bytes really moved
                 line["roofline"]["traffic_GBps"] = tr / (dom_ms * 1e-3) / 1e9
                 line["roofline"]["frac_of_measured"] = line["roofline"]["traffic_GBps"] / pm
+            if line["roofline"].get("frac_of_measured", 0) and line["roofline"]["frac_of_measured"] > 1.0:
+                line["roofline"]["peak_measured_note"] = ("peak_measured is a device copy (one read stream + one write stream); a kernel that mostly writes is not bound by it: "
+                                                          "write-only kernels reach 5.6-6.2 TB/s on this pool (tools/micro, profiles/r04_notes.md section 9)")
             line["roofline"]["path_GBps"] = (fwd_u + bwd_u) * nt / ((f_ms + b_ms) * 1e-3) / 1e9
         if cfg in ("c3", "c4g"):
             st = last["state"]
