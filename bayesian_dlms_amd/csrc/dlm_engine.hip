@@ -1130,15 +1130,15 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
   if (want_packed) k.packed = 3;   // filtered and smoothed records both leave packed
   // Structured d <= 15 path, V, W, C0 shared by the batch: J_t, S_t of the RTS recursion once per call, every series its mean recursion
-  // (k_smoother_rts16 with its export on + k_mean_rts16).  Literal Q1: from 1024 series; textbook: from 6144 series and when
-  // the caller takes the filtered records too (without them the per-series path keeps them packed in a workspace).
+  // (k_smoother_rts16 with its export on + k_mean_rts16).  Literal Q1: from 1024 series; textbook: from 6144 series (a caller
+  // that does not take the filtered records gets them written to the engine's workspace, dense: the mean kernel reads their first 128 bytes).
   const bool q1 = (k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1) != 0;
   const bool rts_shared = fast_shape_ok(k) && e->sparse_k > 0 && !use_lane(k) && !k.packed && !(k.flags & DLM_OPT_SHARED_COV) &&
-                          (q1 ? !fused_fast : (filt != nullptr && fast_smoother_ok(e, k))) && dlm::rts_shared_eligible(k, !q1);
+                          (q1 ? !fused_fast : fast_smoother_ok(e, k)) && dlm::rts_shared_eligible(k, !q1);
   // (textbook: the series with a missing observation keep the information-form kernel, k_smoother_sp16, and the forward pass its side records for
   //  them -- the RTS kernel per series is five times slower; literal Q1 has only that kernel)
   if (!filt) {   // smoothed moments only: the filtered records stay in an engine workspace, packed on the structured path
-    k.packed |= (fast_smoother_ok(e, k) && e->sparse_k > 0 && !use_lane(k)) ? 1 : 0;
+    k.packed |= (fast_smoother_ok(e, k) && e->sparse_k > 0 && !use_lane(k) && !rts_shared) ? 1 : 0;
     if ((rc = ensure_fws(e, (k.packed & 1) ? N * (T + 1) * (size_t)dlm::packed_rec_bytes((int)d) : N * (T + 1) * rec * sizeof(double)))) return rc;
     k.filt = e->fws;
   }

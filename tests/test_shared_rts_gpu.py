@@ -247,9 +247,10 @@ def test_textbook_routes_gaps_and_keeps_the_default_below_the_threshold(eng):
     # no flag, 41 series: the per-series information-form kernel as before
     eng.filter_smooth(mat, p, y, flags=_lib.OPT_COUNT_STEPS)
     assert eng.last_variant == "sparse16" and eng.last_counters()[2:] == (0, 0)
-    # the smoothed moments alone (filt = NULL): the per-series path, whose filtered records stay packed in a workspace
-    eng.filter_smooth(mat, p, y, flags=TB | _lib.OPT_COUNT_STEPS, want_filt=False)
-    assert eng.last_variant == "sparse16" and eng.last_counters()[2:] == (0, 0)
+    # the smoothed moments alone (filt = NULL): the same route, the filtered records in the engine's workspace -- the same smoothed records
+    only = eng.filter_smooth(mat, p, y, flags=TB | _lib.OPT_COUNT_STEPS, want_filt=False)
+    assert eng.last_variant == "sparse16-rts-shared" and eng.last_counters()[2:] == (N - 2, 2)
+    same(only["smooth"], sh["smooth"], "smoothed records without the filtered ones")
 
 
 @pytest.mark.parametrize("sem", [0, _lib.OPT_SMOOTHER_COMPAT_Q1])
