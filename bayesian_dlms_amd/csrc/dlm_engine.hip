@@ -1130,7 +1130,7 @@ int dlm_filter_smooth_batch(dlm_engine* e, const dlm_model_desc* model,
   bool fused_fast = fast_smoother_ok(e, k) || use_tiled(k);
   if (want_packed) k.packed = 3;   // filtered and smoothed records both leave packed
   // Structured d <= 15 path, V, W, C0 shared by the batch: J_t, S_t of the RTS recursion once per call, every series its mean recursion
-  // (k_smoother_rts16 with its export on + k_mean_rts16).  Literal Q1: from 1024 series; textbook: from 6144 series (a caller
+  // (k_smoother_rts16 with its export on + k_mean_rts16).  Literal Q1: from 2048 series; textbook: from 6144 series (a caller
   // that does not take the filtered records gets them written to the engine's workspace, dense: the mean kernel reads their first 128 bytes).
   const bool q1 = (k.flags & DLM_OPT_SMOOTHER_COMPAT_Q1) != 0;
   const bool rts_shared = fast_shape_ok(k) && e->sparse_k > 0 && !use_lane(k) && !k.packed && !(k.flags & DLM_OPT_SHARED_COV) &&

@@ -1375,13 +1375,14 @@ hipError_t launch_sampler_shared_draw(const KArgs& a, int K, const SparseT* tabs
 
 // ---- shared factors of the RTS smoother ------------------------------------------------------------------------------------------
 #ifndef DLM_RTS_SHARED_MIN
-#define DLM_RTS_SHARED_MIN 1024            // literal Q1: against k_smoother_rts16 per series
+#define DLM_RTS_SHARED_MIN 2048            // literal Q1: against k_smoother_rts16 per series
 #endif
 #ifndef DLM_RTS_SHARED_MIN_TEXTBOOK
 #define DLM_RTS_SHARED_MIN_TEXTBOOK 6144   // textbook covariance: against k_smoother_sp16 per series
 #endif
-// The table run is one wave's 2.3 ms (C2, T = 1000) whatever the batch: what the batch must be worth.  Literal Q1: below one wave per SIMD
-// the per-series kernel takes what the table run takes and the mean kernel comes on top (3.0 against 3.3 ms at 8 series).  Textbook
+// The table run is one wave's 2.3 ms (C2, T = 1000) whatever the batch: what the batch must be worth.  Literal Q1
+// (tools/sweep_rts_threshold_q1.sh, profiles/r04_rts_threshold_q1.json): the per-series kernel takes 2.53 / 2.72 / 3.74 / 6.98 ms at 512 / 1024 / 2048 / 4096
+// series against 2.90 / 3.47 / 3.77 / 4.44 ms through the tables -- up to two waves per SIMD it takes what the table run takes, and the mean kernel comes on top.  Textbook
 // (tools/sweep_rts_threshold.sh, profiles/r04_rts_threshold.json): the per-series information-form kernels take 4.79 / 6.56 / 7.46 / 9.27 / 17.6 ms at
 // 5000 / 6500 / 7500 / 10 000 / 20 000 series against 5.48 / 6.25 / 6.71 / 7.96 / 15.3 ms through the tables: from six waves per SIMD.
 // DLM_OPT_NO_STEADY asks for every series' own recursion at every step: never through the tables.

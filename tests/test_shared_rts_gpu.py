@@ -15,7 +15,7 @@ from bayesian_dlms_amd.dlm import Dlm, DlmParameters, materialise
 
 pytestmark = pytest.mark.gpu
 
-Q1 = _lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_NO_SMALL_BATCH    # (the shared route starts at 1024 series; the flag takes small batches there too)
+Q1 = _lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_NO_SMALL_BATCH    # (the shared route starts at 2048 series; the flag takes small batches there too)
 W_C2 = np.array([0.01, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4, 0.2, 0.4, 0.5, 0.2, 0.1, 0.4])
 
 
@@ -166,13 +166,13 @@ def test_smoothed_moments_only_and_repeated_calls_of_changing_size(eng):
 
 
 def test_a_batch_above_the_threshold_takes_the_shared_route_by_default(eng):
-    """1100 series, no flag: the tables serve every series but the two with a gap."""
-    T, N = 60, 1100
+    """2100 series, no flag: the tables serve every series but the two with a gap."""
+    T, N = 60, 2100
     mat, p = c2(T)
     rng = np.random.default_rng(12)
     y = rng.standard_normal((N, T, 1)).cumsum(axis=1) * 0.3
     y[7, 30, 0] = np.nan
-    y[1099, 0, 0] = np.nan
+    y[2099, 0, 0] = np.nan
     sh = eng.filter_smooth(mat, p, y, flags=_lib.OPT_SMOOTHER_COMPAT_Q1 | _lib.OPT_COUNT_STEPS)
     cnt = eng.last_counters()
     assert cnt[2] == N - 2 and cnt[3] == 2, cnt
