@@ -186,7 +186,7 @@ int main(int argc, char** argv) {
         }
         // (a batch of this size shares J_t, S_t through the call's tables where a series has no gap, the single series above runs its own
         //  information-form recursion: two algorithms, both within the steady-state shortcut's 1e-12 of the largest covariance entry per step of
-        //  the exact recursion -- 2e-11 from the oracle on this model, tools/rts_accuracy_probe.py; the series with a gap, 3 and 4999, take the same
+        //  the exact recursion -- 2e-11 from the oracle on this model, tests/rts_accuracy_probe.py; the series with a gap, 3 and 4999, take the same
         //  kernel in both calls)
         expect(e1 < 1e-12 && e2 < ((n == 3 || n == 4999) ? 1e-11 : 2e-10), "C2-sized batch: device-resident records equal the host-mode ones");
         double dl = 0; for (int i = 0; i < d; ++i) dl = std::max(dl, std::fabs(ds[T].mt[i] - df[T].mt[i]));

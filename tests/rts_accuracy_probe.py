@@ -1,5 +1,5 @@
 """How far is the shared-factor RTS route (k_smoother_rts16's tables + k_mean_rts16) from the information-form per-series kernel and from the
-oracle, on the C2 model at T = 1000?  python tools/rts_accuracy_probe.py"""
+oracle, on the C2 model at T = 1000?  (Under tests/: the oracle is test infrastructure.)  python tests/rts_accuracy_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np

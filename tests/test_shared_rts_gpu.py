@@ -324,3 +324,17 @@ def test_an_error_exit_with_the_table_run_in_flight_leaves_the_engine_usable(eng
         out = eng.filter_smooth(mat, p, y, flags=sem | TB)
         same(out["smooth"], ref["smooth"], "smoothed records after the failed call")
         same(out["filt"], ref["filt"], "filtered records after the failed call")
+
+
+def test_accuracy_of_the_tables_against_the_oracle_at_full_length(eng):
+    """C2 at T = 1000: the tables' records, the per-series information-form kernel's and the oracle's (what tests/rts_accuracy_probe.py prints): both
+    routes stay within the steady-state shortcut's budget of the exact recursion -- a few 1e-11 absolute on records whose largest entries are 3.5 and 12 --
+    and the every-step kernels within 1e-13."""
+    T, N = 1000, 16
+    mat, p = c2(T)
+    y = np.random.default_rng(0).standard_normal((N, T, 1)).cumsum(axis=1) * 0.3
+    f = oracle.kf_filter(omodel(mat), p.v, p.w, p.m0, p.c0, y[0])
+    s = oracle.smoother(omodel(mat), f)
+    for flags, tol in ((TB, 2e-10), (_lib.OPT_SMOOTHER_PER_SERIES, 2e-10), (_lib.OPT_NO_STEADY, 1e-13)):
+        sm = np.array(eng.filter_smooth(mat, p, y, flags=flags)["smooth"])[0]
+        assert np.abs(sm[:, :13] - s["s"]).max() <= tol and np.abs(sm[:, 13:] - s["S"]).max() <= tol, (flags, np.abs(sm[:, :13] - s["s"]).max(), np.abs(sm[:, 13:] - s["S"]).max())
