@@ -41,14 +41,14 @@ __global__ __launch_bounds__(64 * WPB) void k_io(double* out, const double* tab,
     if (MEANS) dma(rmean, ldsm + (s & 7) * 512, mvoff, t * (MEANS == 2 ? 512 : recb), lane < 32);
     if (TABLE == 1 || (TABLE == 2 && wave == 0)) { dma(rtab, ldst + (s & 1) * 2048, lane * 16, t * recb, true); dma(rtab, ldst + (s & 1) * 2048 + 1024, lane * 16 + 1024, t * recb, lane + 64 < npc); }
     constexpr int PER = 6 + (MEANS ? 1 : 0) + (TABLE ? 2 : 0);
-    if (MEANS || TABLE) vm_wait<PER + 6>();
+    if ((MEANS || TABLE) && !(AUX & 256)) vm_wait<PER + 6>();
     if (TABLE == 2) __builtin_amdgcn_s_barrier();
-    if (MEANS || TABLE) v += my[(s & 1) * 256 + lane] * 1e-9 + mym[(s & 7) * 64 + lane] * 1e-9;
+    if ((MEANS || TABLE) && !(AUX & 256)) v += my[(s & 1) * 256 + lane] * 1e-9 + mym[(s & 7) * 64 + lane] * 1e-9;
     const int so = t * recb;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const u4 w = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v), (unsigned)k, (unsigned)lane};
-      __builtin_amdgcn_raw_buffer_store_b128(w, rout, pdst[k], so, AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(w, rout, pdst[k], so, AUX & 255);
     }
     v += 1e-3;
   }
@@ -85,5 +85,8 @@ int main() {
   run("scattered means + row per wave, stores sc0 sc1 nt", L(1, 1, 19, 1));
   run("compact means + row per wave, stores nt", L(2, 1, 2, 1));
   run("stores only, nt", L(0, 0, 2, 1));
+  run("compact means requested but never waited for", L(2, 0, 256, 1));
+  run("scattered means + row requested but never waited for", L(1, 1, 256, 1));
+  run("scattered means + row requested but never waited for, stores nt", L(1, 1, 258, 1));
   return 0;
 }
