@@ -396,8 +396,10 @@ size_t svd_sampler_lds_bytes(int d, int p) { return sizeof(double) * (svd_nm(d, 
 // ---------------------------------------------------------------------------------------
 // rec_stride (doubles, 0: 2 d + d^2) / aux: the covariance-only run of the shared-factor path (k_svd_mean_filter below) writes its
 // records as padded table rows and leaves sqrt(V)^-1[0][0] in aux[0].
-template <int NM>
-__global__ __launch_bounds__(64, NM == 16 ? 4 : 1) void k_svd_filter(KArgs a, double* __restrict__ rec_out, int rec_stride, double* __restrict__ aux) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
+// LONE: the instantiation of the shared-factor table run -- ONE wave whose dependent chain the whole call waits for: no occupancy bound, so that
+// none of its values is spilled (the batch instantiation trades 15 spilled values for a fourth wave per SIMD).
+template <int NM, bool LONE = false>
+__global__ __launch_bounds__(64, (NM == 16 && !LONE) ? 4 : 1) void k_svd_filter(KArgs a, double* __restrict__ rec_out, int rec_stride, double* __restrict__ aux) {   // 128 VGPRs (15 spilled): 14 one-wave workgroups per CU instead of 12 -- the rotation rounds are latency-bound (C5 84.8 -> 81.9 ms)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = blockIdx.x, lane = threadIdx.x;
   const int d = a.d, p = a.p, T = a.T, dd = d * d, srec = rec_stride ? rec_stride : 2 * d + dd;
@@ -974,7 +976,7 @@ hipError_t launch_svd_filter_shared(const KArgs& a, double* svd_rec, double* ws,
   if (err != hipSuccess) return err;
   KArgs kc = a;
   kc.N = 1; kc.y = zeros; kc.m0 = zeros; kc.m0_stride = 0; kc.status = cst; kc.counters = nullptr; kc.route = nullptr;
-  hipLaunchKernelGGL(k_svd_filter<16>, dim3(1), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kc, tab, tstride, aux);
+  hipLaunchKernelGGL((k_svd_filter<16, true>), dim3(1), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kc, tab, tstride, aux);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;
   km.route = route; km.route_take = 0;
