@@ -384,11 +384,13 @@ __device__ __forceinline__ SvdLds carve_filter(double* sm, int d, int p) {
   L.tmp = nullptr; L.sWb = nullptr;
   return L;
 }
-size_t svd_filter_lds_bytes(int d, int p) {
+__device__ __host__ inline size_t svd_filter_lds_doubles(int d, int p) {
   const int n = d > p ? d : p, nm = svd_nm(d, p), sl = nm + 1;
-  const size_t dbl = (size_t)(8 * nm + 3 * n * sl + d * sl + p * sl + svd_stack_doubles(d, p) + nm / 2 + nm + 2);   // (+ 2: the state of the steady-state test behind gs)
-  return sizeof(double) * dbl + 16;
+  return (size_t)(8 * nm + 3 * n * sl + d * sl + p * sl + svd_stack_doubles(d, p) + nm / 2 + nm + 2);   // (+ 2: the state of the steady-state test behind gs)
 }
+size_t svd_filter_lds_bytes(int d, int p) { return sizeof(double) * svd_filter_lds_doubles(d, p) + 16; }
+// the table run's instantiation (LONE) also keeps G and F in LDS, behind everything else
+size_t svd_filter_lone_lds_bytes(int d, int p) { return sizeof(double) * (((svd_filter_lds_doubles(d, p) + 1) & ~(size_t)1) + (size_t)d * d + (size_t)d * p) + 16; }
 size_t svd_sampler_lds_bytes(int d, int p) { return sizeof(double) * (svd_nm(d, p) == 16 ? svd_sampler_lds_doubles<16>() : svd_sampler_lds_doubles<48>()) + 16; }
 
 // ---------------------------------------------------------------------------------------
@@ -464,9 +466,32 @@ __global__ __launch_bounds__(64, (NM == 16 && !LONE) ? 4 : 1) void k_svd_filter(
 #define SVD_T0
 #define SVD_T1
 #endif
+  // LONE (the shared-factor table run: a time-invariant model): G and F from LDS -- in the one wave's dependent chain a global load, even one that
+  // hits the cache, is several hundred cycles per matrix product
+  double* Gs = sm + ((svd_filter_lds_doubles(d, p) + 1) & ~(size_t)1);
+  double* Fs = Gs + dd;
+  // ... and the (row, column) of this lane's elements of a d x d matrix come from registers instead of an integer division per element and loop
+  int ki[4] = {0, 0, 0, 0}, kj[4] = {0, 0, 0, 0};
+  if constexpr (LONE) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) { const int k = lane + 64 * s_; ki[s_] = k % d; kj[s_] = k / d; }
+  }
+  auto each_dd = [&](auto&& f) {   // f(k, row, column) over this lane's elements k = lane, lane + 64, ... of a d x d matrix
+    if constexpr (LONE) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) { const int k = lane + 64 * s_; if (k < dd) f(k, ki[s_], kj[s_]); }
+    } else {
+      for (int k = lane; k < dd; k += 64) f(k, k % d, k / d);
+    }
+  };
+  if constexpr (LONE) {
+    for (int k = lane; k < dd; k += 64) Gs[k] = a.G[k];
+    for (int k = lane; k < d * p; k += 64) Fs[k] = a.F[k];
+    ssync();
+  }
   for (int t = 0; t < T; ++t) {
-    const double* Gt = a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
-    const double* Ft = a.F + (size_t)t * a.f_stride;
+    const double* Gt = LONE ? Gs : a.G + (size_t)(a.g_index ? a.g_index[t] : 0) * dd;
+    const double* Ft = LONE ? Fs : a.F + (size_t)t * a.f_stride;
     const double dt = a.dt ? a.dt[t] : 1.0;
     if ((t & 63) == 0) { warm_r = false; warm_c = false; }
     // V_t / W_t streams: step t runs with transformParams(p.copy(v = V_t)) / transformParams(p.copy(w = W_t))
@@ -508,13 +533,12 @@ __global__ __launch_bounds__(64, (NM == 16 && !LONE) ? 4 : 1) void k_svd_filter(
       reuse_r = settled && have_r && gi == gprev && dt == dtprev && !a.w_tstride && !(a.flags & DLM_OPT_FORCE_GENERIC);
       if (reuse_r) { ssync(); } else {
       have_r = true; have_c = false; gprev = gi; dtprev = dt;
-      for (int k = lane; k < dd; k += 64) {   // stack = [diag(dc) uc^T G^T ; Wadv sqrt(dt)]
-        const int i = k % d, j = k / d;
+      each_dd([&](int, int i, int j) {   // stack = [diag(dc) uc^T G^T ; Wadv sqrt(dt)]
         double s = 0.0;
         for (int l = 0; l < d; ++l) s = fma(M17(L.uc, l, i), Gt[j + l * d], s);
         STK(i, j) = L.dc[i] * s;
         STK(d + i, j) = M17(L.Wadv, i, j) * sdt;
-      }
+      });
       ssync();
       SVD_T0
       { const int rc = jacobi_svd<NM>(lane, 2 * d, d, stack, stl, L.ur, L.dr, warm_r); if (rc & 1) st |= DLM_ST_NOCONV; dbg_sw1 += rc >> 8; }   // dr = sigma, ur = V
@@ -542,7 +566,7 @@ __global__ __launch_bounds__(64, (NM == 16 && !LONE) ? 4 : 1) void k_svd_filter(
         L.e[j] = L.yv[j] - s;
       }
       for (int k = lane; k < pm * d; k += 64) {
-        const int i = k % pm, j = k / pm;
+        const int i = LONE ? 0 : k % pm, j = LONE ? k : k / pm;   // (LONE: p = 1, the one component observed)
         double s = 0.0;
         for (int l = 0; l < pm; ++l) s = fma(M17(L.sVinv, L.idx[i], L.idx[l]), Ft[j + L.idx[l] * d], s);
         STK(PK + i, j) = s;                    // vm fm^T, parked in rows PK.. of the stack
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(64, (NM == 16 && !LONE) ? 4 : 1) void k_svd_filter(
       if (!reuse_c) {
       // stack ((pm + d) x d) = [vm fm^T ur ; diag(1/dr)]
       for (int k = lane; k < pm * d; k += 64) {
-        const int i = k % pm, j = k / pm;
+        const int i = LONE ? 0 : k % pm, j = LONE ? k : k / pm;
         double s = 0.0;
         for (int l = 0; l < d; ++l) s = fma(STK(PK + i, l), M17(L.ur, l, j), s);
         STK(i, j) = s;
@@ -577,13 +601,12 @@ __global__ __launch_bounds__(64, (NM == 16 && !LONE) ? 4 : 1) void k_svd_filter(
       }
       // uc = ur V ; dc = 1 / sigma -- and how far they moved (steady-state test)
       double mxu = 0.0, dfu = 0.0, mxd = 0.0, dfd = 0.0;
-      for (int k = lane; k < dd; k += 64) {
-        const int i = k % d, j = k / d;
+      each_dd([&](int, int i, int j) {
         double s = 0.0;
         for (int l = 0; l < d; ++l) s = fma(M17(L.ur, i, l), M17(L.V, l, j), s);
         mxu = fmax(mxu, fabs(s)); dfu = fmax(dfu, fabs(s - M17(L.uc, i, j)));
         M17(L.uc, i, j) = s;
-      }
+      });
       for (int i = lane; i < d; i += 64) { const double v = 1.0 / L.sig[i]; mxd = fmax(mxd, fabs(v)); dfd = fmax(dfd, fabs(v - L.dc[i])); L.dc[i] = v; }
       for (int o_ = 32; o_ > 0; o_ >>= 1) { mxu = fmax(mxu, __shfl_xor(mxu, o_)); dfu = fmax(dfu, __shfl_xor(dfu, o_)); mxd = fmax(mxd, __shfl_xor(mxd, o_)); dfd = fmax(dfd, __shfl_xor(dfd, o_)); }
       {   // the larger of the two relative changes, in single precision (ratios of maxima)
@@ -629,7 +652,7 @@ __global__ __launch_bounds__(64, (NM == 16 && !LONE) ? 4 : 1) void k_svd_filter(
     ssync();
     double* o = out + (size_t)(t + 1) * srec;
     for (int i = lane; i < d; i += 64) { o[i] = L.m[i]; o[d + i] = L.dc[i]; }
-    for (int k = lane; k < dd; k += 64) o[2 * d + k] = M17(L.uc, k % d, k / d);
+    each_dd([&](int k, int i, int j) { o[2 * d + k] = M17(L.uc, i, j); });
   }
 #ifdef DLM_STAMP
   if (n == 0 && lane == 0 && a.status) { unsigned long long tend; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tend)::"memory"); a.status[1] = dbg_sw1; a.status[2] = dbg_sw2; a.status[3] = (int)(tj / T); a.status[4] = (int)((tend - tstart) / T); }
@@ -976,7 +999,7 @@ hipError_t launch_svd_filter_shared(const KArgs& a, double* svd_rec, double* ws,
   if (err != hipSuccess) return err;
   KArgs kc = a;
   kc.N = 1; kc.y = zeros; kc.m0 = zeros; kc.m0_stride = 0; kc.status = cst; kc.counters = nullptr; kc.route = nullptr;
-  hipLaunchKernelGGL((k_svd_filter<16, true>), dim3(1), dim3(64), svd_filter_lds_bytes(a.d, a.p), s, kc, tab, tstride, aux);
+  hipLaunchKernelGGL((k_svd_filter<16, true>), dim3(1), dim3(64), svd_filter_lone_lds_bytes(a.d, a.p), s, kc, tab, tstride, aux);
   if ((err = hipGetLastError()) != hipSuccess) return err;
   KArgs km = a;
   km.route = route; km.route_take = 0;
