@@ -906,7 +906,7 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) Wt[r] = va[r] ? (W0 + (size_t)t * a.w_tstride)[4 * r + g + c * d] : 0.0;
     }
-    if (g == 0) mv[c] = mc;
+    if (!EXP && g == 0) mv[c] = mc;   // (EXP: nobody reads the means of the series of zeros -- the table run leaves the mean recursion out of its chain)
     bool reuse = false;
     if (have && gi == gprev && dt == dtprev && !a.w_tstride) {
       bool moved = false;
@@ -917,12 +917,14 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
     d4 JT, J, R;
     double a1 = mc;
     if (reuse) {
-      wave_sync();
-      if (dt != 0.0) {
-        double s_ = 0.0;
+      if constexpr (!EXP) {
+        wave_sync();
+        if (dt != 0.0) {
+          double s_ = 0.0;
 #pragma unroll
-        for (int s = 0; s < K; ++s) s_ = fma(mv[ridx[s]], rval[s], s_);
-        a1 = s_;
+          for (int s = 0; s < K; ++s) s_ = fma(mv[ridx[s]], rval[s], s_);
+          a1 = s_;
+        }
       }
       JT = JTs; J = Js; R = Rs;
       if constexpr (EXP) { if (lane == 0) tb.need[t] = 0; }
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
         for (int s = 0; s < K; ++s) s_ = fma(row[ridx[s]], rval[s], s_);
         T1[r] = s_;
       }
-      if (dt != 0.0) {
+      if (!EXP && dt != 0.0) {
         double s_ = 0.0;
 #pragma unroll
         for (int s = 0; s < K; ++s) s_ = fma(mv[ridx[s]], rval[s], s_);
@@ -1006,9 +1008,11 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
         cmaxp = mx;
       }
     }
-    if (g == 0) uv[c] = vc ? sv[c] - a1 : 0.0;
-    wave_sync();
-    scol = mc + matTvec(JT, uv, g);                     // s = m + J (s+ - a+)
+    if constexpr (!EXP) {
+      if (g == 0) uv[c] = vc ? sv[c] - a1 : 0.0;
+      wave_sync();
+      scol = mc + matTvec(JT, uv, g);                   // s = m + J (s+ - a+)
+    }
     d4 X;
 #pragma unroll
     for (int r = 0; r < 4; ++r) X[r] = R[r] - S[r];     // R+ - S+
@@ -1017,9 +1021,11 @@ __global__ __launch_bounds__(64) void k_smoother_rts16(KArgs a, const Tab* __res
 #pragma unroll
     for (int r = 0; r < 4; ++r) { S[r] = va[r] ? C[r] - JXJ[r] : 0.0; bst(rout, offC[r], t * recb, S[r]); }
     bst(rout, offM, t * recb, scol);
-    wave_sync();
-    if (g == 0) sv[c] = vc ? scol : 0.0;
-    wave_sync();
+    if constexpr (!EXP) {
+      wave_sync();
+      if (g == 0) sv[c] = vc ? scol : 0.0;
+      wave_sync();
+    }
   }
   bool bad = vc && g == 0 && !isfinite(scol);
 #pragma unroll
