@@ -70,6 +70,7 @@ struct dlm_engine {
   hipEvent_t rng_ev = nullptr;
   hipStream_t cov_stream = nullptr;
   hipEvent_t cov_ev[2] = {nullptr, nullptr};
+  hipEvent_t rng_gate = nullptr;  // 16 <= d <= 48, records-free shared-factor FFBS: the end of the batch's forward pass, behind which the normals start
   hipEvent_t cov_ev2 = nullptr;   // behind the zero series' filter of a shared-factor table (its steady gain and settle step)
   // work of the CURRENT call is (or may be) in flight on the auxiliary streams and e->stream does not depend on it yet: set when the
   // first operation goes to the stream, cleared by aux_join / drain_all (the rules are written at aux_join)
@@ -519,7 +520,8 @@ int ensure_cov_stream(dlm_engine* e) {
 }
 // Shared factors of the reference-form backward sampler (dlm_sampler16.hip): the tables are made on the second
 // stream -- a filter and a sampler run of ONE wave on a series of zeros -- while the batch is filtered on the first.
-int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big, const double* crec = nullptr, int crec_stride = 0) {
+int start_sampler_normals(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big, hipEvent_t gate);
+int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big, const double* crec = nullptr, int crec_stride = 0, bool defer_normals = false) {
   const size_t need = big ? dlm::wave48_sampler_shared_ws_bytes(k) : dlm::sampler_shared_ws_bytes(k);
   if (need > e->sampws_bytes) {
     if (e->sampws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->sampws)); e->sampws = nullptr; e->sampws_bytes = 0; }
@@ -538,7 +540,14 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
   else HIP_TRY(e, dlm::launch_sampler_shared_tables(k, e->sparse_k, e->sp_dev, tb, e->cov_stream));
   HIP_TRY(e, hipEventRecord(e->cov_ev[1], e->cov_stream));
   tb.z4 = nullptr;
-  if (!k.z) {   // the normals of the call, on a stream of ordinary priority beside the batch's filter
+  if (defer_normals) return DLM_OK;   // (start_sampler_normals, behind the forward pass's launch)
+  return start_sampler_normals(e, k, tb, big, e->cov_ev[0]);
+}
+// The normals of the call (third stream).  `gate`: an event of the engine's stream the launch waits for -- the staging of the call (the draw kernel of the
+// call before has read its normals) or, 16 <= d <= 48, the END of the batch's forward pass: k_filter_w48 is one wave per SIMD and launched behind a
+// kernel of forty million threads it started 0.4 ms late (the normals are wanted last, by the draw kernel; they now run beside k_steady_filter_w48).
+int start_sampler_normals(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool big, hipEvent_t gate) {
+  if (!k.z) {
     const size_t zb = big ? dlm::wave48_sampler_shared_normals_bytes(k) : dlm::sampler_shared_normals_bytes(k);
     if (zb > e->zws_bytes) {
       if (e->zws) { { const int rcd = drain_all(e); if (rcd) return rcd; } HIP_TRY(e, hipFree(e->zws)); e->zws = nullptr; e->zws_bytes = 0; }
@@ -550,7 +559,7 @@ int start_sampler_tables(dlm_engine* e, const KArgs& k, dlm::SampTabs& tb, bool 
       HIP_TRY(e, hipEventCreateWithFlags(&e->rng_ev, hipEventDisableTiming));
     }
     e->rng_busy = true;
-    HIP_TRY(e, hipStreamWaitEvent(e->rng_stream, e->cov_ev[0], 0));   // (the draw kernel of the call before has read its normals)
+    HIP_TRY(e, hipStreamWaitEvent(e->rng_stream, gate, 0));
     if (big) HIP_TRY(e, dlm::launch_wave48_sampler_shared_normals(k, e->zws, e->rng_stream));
     else HIP_TRY(e, dlm::launch_sampler_shared_normals(k, e->zws, e->rng_stream));
     HIP_TRY(e, hipEventRecord(e->rng_ev, e->rng_stream));
@@ -767,6 +776,7 @@ void dlm_engine_destroy(dlm_engine* e) {
   if (e->rng_stream) (void)hipStreamDestroy(e->rng_stream);
   for (auto& ev : e->cov_ev) if (ev) (void)hipEventDestroy(ev);
   if (e->cov_ev2) (void)hipEventDestroy(e->cov_ev2);
+  if (e->rng_gate) (void)hipEventDestroy(e->rng_gate);
   if (e->cov_stream) (void)hipStreamDestroy(e->cov_stream);
   if (e->counters) (void)hipFree(e->counters);
   if (e->model_sum) (void)hipFree(e->model_sum);
@@ -1276,7 +1286,8 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       HIP_TRY(e, dlm::launch_sparse16_filter(kg, e->sparse_k, e->sp_dev, nullptr, nullptr, e->stream));
       k.filt_in = e->fws;
     } else {
-      if ((shared_factors || shared_big) && (rc = start_sampler_tables(e, k, stb, shared_big))) return rc;
+      const bool defer_z = norec && shared_big;   // (the normals start behind the forward pass: 8.64 -> 8.26 ms per C4 Gibbs iteration on one box)
+      if ((shared_factors || shared_big) && (rc = start_sampler_tables(e, k, stb, shared_big, nullptr, 0, defer_z))) return rc;
       if ((shared_factors || shared_big) && (k.flags & DLM_OPT_TEST_FAIL_AFTER_TABLES))   // test hook: an error exit with the auxiliary streams busy
         return fail(e, DLM_ERR_UNSUPPORTED, "DLM_OPT_TEST_FAIL_AFTER_TABLES");
       if (norec && shared_big) {
@@ -1291,6 +1302,11 @@ static int sampler_common(dlm_engine* e, const dlm_model_desc* model, const dlm_
       }
       if ((rc = run_filter(e, k, false))) return rc;
       if (norec && shared_big) {
+        if (defer_z) {
+          if (!e->rng_gate) HIP_TRY(e, hipEventCreateWithFlags(&e->rng_gate, hipEventDisableTiming));
+          HIP_TRY(e, hipEventRecord(e->rng_gate, e->stream));
+          if ((rc = start_sampler_normals(e, k, stb, true, e->rng_gate))) return rc;
+        }
         HIP_TRY(e, hipStreamWaitEvent(e->stream, e->cov_ev2, 0));   // the zero series' filter: the steady gain and the step it settled at
         HIP_TRY(e, dlm::launch_wave48_steady_filter(k, stb.ktab, stb.settle, e->stream));
       }
