@@ -317,3 +317,26 @@ def test_per_wave_kernels_keep_their_registers(tmp_path):
     assert of("k_smoother_w48ILi3ELi2ELi2ELi1E")[0] <= 96           # 16 values, in the full step
     assert of("k_steady_filter_w48ILi3ELi2ELi2ELi1E") == (0, 0)
     assert of("k_mean_sampler_w48ILi3ELi2ELb1E") == (0, 0) and of("k_mean_sampler_w48ILi3ELi2ELb0E") == (0, 0)
+
+
+def test_the_oracle_is_used_from_tests_smoke_and_the_cpu_baseline_only():
+    """oracle/ is test infrastructure: nothing under the package, tools/ or integration/ imports it (the product path must fail loudly without the HIP
+    library rather than fall back on it); bench.py uses it inside cpu_baseline only, __graft_entry__.py inside smoke() (and build(), which compiles it) only."""
+    import ast, glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append(node.lineno)
+        return tree, hits
+    for pat in ("bayesian_dlms_amd/*.py", "tools/*.py", "integration/**/*.py"):
+        for f in glob.glob(os.path.join(root, pat), recursive=True):
+            assert oracle_imports(f)[1] == [], f
+    for f, allowed in (("bench.py", ("cpu_baseline",)), ("__graft_entry__.py", ("smoke", "build"))):   # (build() compiles the checker: building it is not using it)
+        tree, hits = oracle_imports(os.path.join(root, f))
+        spans = [(n.lineno, n.end_lineno) for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name in allowed]
+        assert hits and all(any(a <= h <= b for a, b in spans) for h in hits), (f, hits, spans)
