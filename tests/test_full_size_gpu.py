@@ -108,6 +108,33 @@ def test_c2_full_size_steady_state_path(eng):
         assert diff <= 1e-10 * scale, (k, diff, scale)
 
 
+def test_c2_full_size_literal_q1_on_shared_factors(eng):
+    """The bench workload with Smoothing.scala:44 as written (DLM_OPT_SMOOTHER_COMPAT_Q1) at full size: the tables serve all 10 000 series; a handful of
+    series alone through the same route give the same bits (independence); the per-series kernel gives the same bits (DLM_OPT_SMOOTHER_PER_SERIES);
+    two series against the oracle's literal smoother at full length."""
+    import torch
+    from bench import seasonal_c2, simulate
+    mod, p = seasonal_c2()
+    mat = materialise(mod, np.arange(1, 1001, dtype=np.float64))
+    y = torch.as_tensor(simulate(mat, p, 10000, seed=20261006), device="cuda")
+    Q1 = _lib.OPT_SMOOTHER_COMPAT_Q1
+    a = eng.filter_smooth(mat, p, y, flags=Q1 | _lib.OPT_COUNT_STEPS)
+    assert eng.last_variant == "sparse16-rts-shared" and eng.last_counters()[2:] == (10000, 0)
+    assert int((a["status"] != 0).sum().item()) == 0
+    pick = [0, 4999, 9999, 777]
+    sub = eng.filter_smooth(mat, p, y[pick], flags=Q1 | _lib.OPT_NO_SMALL_BATCH)
+    assert torch.equal(sub["filt"], a["filt"][pick]) and torch.equal(sub["smooth"], a["smooth"][pick])
+    own = eng.filter_smooth(mat, p, y[:2048], flags=Q1 | _lib.OPT_SMOOTHER_PER_SERIES)
+    assert torch.equal(own["smooth"], a["smooth"][:2048])
+    del own
+    for n in pick[:2]:
+        f = oracle.kf_filter(_om(mat), p.v, p.w, p.m0, p.c0, y[n].cpu().numpy())
+        s_ = oracle.smoother(_om(mat), f, compat_q1=True)
+        sr = a["smooth"][n].cpu().numpy()
+        np.testing.assert_allclose(sr[:, :13], s_["s"], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(sr[:, 13:], s_["S"], rtol=1e-7, atol=1e-7)
+
+
 def test_c4_full_size_steady_state_path(eng):
     """BASELINE configs[3] without missing components: the covariance recursion settles within 30 steps and both per-wave passes
     stream records from then on.  Properties, oracle at full length, and the batch against DLM_OPT_NO_STEADY."""
