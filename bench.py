@@ -318,7 +318,7 @@ def add_secondary(line, args, ctx):
     line["config"]["value_per_series_factors"] = own["value"]
     line["config"]["ms_per_step_per_series_factors"] = own["ms_per_step"]
     sec = {"c2_full_recursion": brief(full), "c2_missing_0.05": brief(miss), "c2_per_series_factors": brief(own)}
-    sec["c2_literal_q1"] = brief(run(semantics="literal-q1", steps=3, warmup=1))
+    sec["c2_literal_q1"] = brief(run(semantics="literal-q1", steps=10, warmup=3))
     sec["c2_literal_q1_per_series_factors"] = brief(run(semantics="literal-q1", flags=_lib.OPT_SMOOTHER_PER_SERIES, steps=3, warmup=1))
     sec["c2_shared_covariance_opt_in"] = brief(run(flags=_lib.OPT_SHARED_COV, steps=5, warmup=1))
     sec["c3_reference_sampler"] = brief(run(config="c3", sampler="reference", steps=3, warmup=2))
